@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- decoded syndromes/s of the MI355X BP decoder on BASELINE.json's metric.
+
+One "step" = one batchdecode!-equivalent pass (ldpc_bp_decode_batch_device) over one
+HBM-resident batch of synthetic syndromes.  Default workload = BASELINE configs[2]:
+Gallager (4,8)-regular LDPC, n=16384, m=8192, row weight 8, batch 65536, max_iters 50,
+per = 0.10 ("full-50": above the BP threshold, so every syndrome runs all 50 iterations;
+SURVEY.md 8d).  N>1: every rank decodes its own 65536-syndrome shard (weak scaling, no
+data-path collective -- syndromes are independent).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with the extra objects
+  roofline     : algorithmic bytes (32*nnz per syndrome*iteration) / sweep-kernel time
+  cpu_baseline : the CPU oracle in its reference-faithful dense mode, bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (n, wr, wc, batch per GPU, per, max_iters)
+    "c3_full50": (16384, 8, 4, 65536, 0.10, 50),
+    "c3_realistic": (16384, 8, 4, 65536, 0.02, 50),
+    "c2_n1008": (1008, 6, 3, 4096, 0.01, 50),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def make_syndromes(torch, H_csr, n, batch, per, seed, device):
+    """Bernoulli(per) errors and their syndromes, generated on the device (synthetic data)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    indptr = torch.from_numpy(H_csr.indptr.astype(np.int64)).to(device)
+    cols = torch.from_numpy(H_csr.indices.astype(np.int64)).to(device)
+    s = H_csr.shape[0]
+    deg = int(H_csr.indptr[1] - H_csr.indptr[0])
+    regular = bool(np.all(np.diff(H_csr.indptr) == deg))
+    syn = torch.empty((batch, s), dtype=torch.uint8, device=device)
+    chunk = 4096
+    for b0 in range(0, batch, chunk):
+        b1 = min(batch, b0 + chunk)
+        e = (torch.rand((b1 - b0, n), generator=g, device=device) < per).to(torch.uint8)
+        if regular:
+            syn[b0:b1] = e[:, cols].view(b1 - b0, s, deg).sum(dim=2, dtype=torch.int32).remainder(2).to(torch.uint8)
+        else:
+            ge = e[:, cols].to(torch.int32)
+            cs = torch.cumsum(ge, dim=1)
+            cs = torch.cat([torch.zeros((b1 - b0, 1), dtype=cs.dtype, device=device), cs], dim=1)
+            syn[b0:b1] = (cs[:, indptr[1:]] - cs[:, indptr[:-1]]).remainder(2).to(torch.uint8)
+    return syn
+
+
+def cpu_baseline(H, per, max_iters, syn_sample, gpu_err, gpu_conv, budget_s=20.0):
+    """Oracle in reference-faithful DENSE mode (two dense s x n Float64 matrices, full reset
+    per decode, strided access: the cost structure of belief_propagation.jl:83-91,121-188),
+    single thread like the reference.  Also re-checks the GPU result on the sample."""
+    from oracle import BPOracle
+
+    oc = BPOracle(csc=(H.indptr, H.indices), shape=H.shape, per=per, max_iters=max_iters, dense=True)
+    done, t0, ok = 0, time.perf_counter(), True
+    for b in range(syn_sample.shape[0]):
+        err, conv = oc.decode(syn_sample[b])
+        ok = ok and bool(conv) == bool(gpu_conv[b]) and np.array_equal(err.astype(np.uint8), gpu_err[b])
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return done / dt, done, ok
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3_full50", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="syndromes per GPU (default: the workload's)")
+    ap.add_argument("--waves-per-tile", type=int, default=0)
+    ap.add_argument("--resident-tiles", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    import ldpcdecoders_jl_amd as ldpc
+
+    n, wr, wc, batch, per, max_iters = WORKLOADS[args.workload]
+    if args.batch:
+        batch = args.batch
+    H = ldpc.codes.parity_check_csc(n, wr, wc)
+    nnz = int(H.nnz)
+    dec = ldpc.BeliefPropagationDecoder(H, per, max_iters, device=local_rank,
+                                        waves_per_tile=args.waves_per_tile, resident_tiles=args.resident_tiles)
+    syn = make_syndromes(torch, H.tocsr(), n, batch, per, seed=1234 + rank, device=device)
+    err = torch.empty((batch, n), dtype=torch.uint8, device=device)
+    conv = torch.empty(batch, dtype=torch.uint8, device=device)
+    iters = torch.empty(batch, dtype=torch.int32, device=device)
+
+    def step():
+        dec.decode_batch_device(syn, err, conv, None, iters)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    # HIP-event times of the sweep kernel of the timed steps (the library keeps the events of
+    # its last 16 calls, recorded on the launch stream), read after the timed region
+    k = min(args.steps, 16)
+    per_call = [dec.last_timing(i) for i in range(k)]
+    sweep_ms = sum(t[0] for t in per_call) / k
+    total_ms = sum(t[1] for t in per_call) / k
+    sum_iters = per_call[0][2]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_syndromes = batch * world * args.steps
+        value = total_syndromes / elapsed
+        alg_bytes = float(sum_iters) * 32.0 * nnz        # 32*nnz B per syndrome*iteration
+        achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+        out = {
+            "metric": "decoded syndromes/sec (batchdecode!, 50 iters) + achieved HBM GB/s fraction",
+            "value": value,
+            "unit": "syndromes/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: Gallager ({wc},{wr})-regular LDPC n={n} m={H.shape[0]} nnz={nnz}, "
+                            f"batch={batch}/GPU, per={per}, max_iters={max_iters}, HBM-resident uint8 syndromes in, "
+                            f"uint8 hard decisions + converged + iteration counts out",
+                "global_batch": batch * world,
+                "parallelism": f"batch-sharded x{world} (independent syndromes, no data-path collective)",
+                "mean_iters": sum_iters / batch,
+                "converged_frac": float(conv.float().mean().item()),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "bp_tile_kernel",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "alg_bytes_per_launch": alg_bytes,
+                "kernel_ms": sweep_ms,
+                "pack_sweep_unpack_ms": total_ms,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            k = 64
+            cps, done, ok = cpu_baseline(H, per, max_iters, syn[:k].cpu().numpy(), err[:k].cpu().numpy(),
+                                         conv[:k].cpu().numpy())
+            out["cpu_baseline"] = {
+                "value": cps, "unit": "syndromes/s", "cores": 1, "kind": "port",
+                "sample": f"first {done} syndromes of the same batch, C oracle in reference-faithful dense mode "
+                          f"(2 dense {H.shape[0]}x{n} Float64 matrices, full reset! per decode), 1 thread; "
+                          f"the Julia reference itself cannot run here (no Julia runtime)",
+                "gpu_matches_oracle_on_sample": ok,
+            }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

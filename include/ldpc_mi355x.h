@@ -1,0 +1,152 @@
+/*
+ * ldpc_mi355x.h -- C ABI of libldpc_mi355x.so, the MI355X (gfx950) drop-in for
+ * the belief-propagation hot path of QuantumSavory/LDPCDecoders.jl.
+ *
+ * Every entry point names the reference interface it replaces (paths relative
+ * to the reference checkout).  The reference has no FFI of its own (it is pure
+ * Julia); these are the symbols a `ccall` shim binds -- see INTEGRATION.md and
+ * ldpcdecoders.jl_amd/julia/LDPCDecodersMI355X.jl.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no exceptions cross the boundary: every
+ *     call returns an ldpc_status and ldpc_last_error() holds the message of
+ *     the last failure on the calling thread.
+ *   - a handle is NOT re-entrant (neither is the reference decoder, whose
+ *     scratch is shared: belief_propagation.jl:58); different handles may be
+ *     used from different threads.
+ *   - batch layout is the memory image of the reference's column-major Julia
+ *     matrices: syndromes (s x B) = B contiguous runs of s bytes; errors
+ *     (n x B) = B contiguous runs of n bytes.
+ *   - the library never keeps a caller pointer after a call returns.
+ *   - there is NO CPU fallback: without a usable gfx950 device every compute
+ *     entry returns LDPC_ERR_NO_DEVICE.
+ */
+#ifndef LDPC_MI355X_H
+#define LDPC_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDPC_MI355X_ABI_VERSION 1
+
+typedef enum ldpc_status {
+    LDPC_OK = 0,
+    LDPC_ERR_INVALID_ARGUMENT = 1, /* shape / pointer / CSC-pattern errors (reference: AssertionError, BoundsError) */
+    LDPC_ERR_NO_DEVICE = 2,        /* no gfx950 device or HIP runtime unusable */
+    LDPC_ERR_HIP = 3,              /* a HIP call failed; text in ldpc_last_error() */
+    LDPC_ERR_OUT_OF_MEMORY = 4,
+    LDPC_ERR_UNSUPPORTED = 5
+} ldpc_status;
+
+typedef struct ldpc_bp_decoder ldpc_bp_decoder; /* opaque; owns device copies of H and the workspace */
+
+/* Sizes and tuning of a decoder, readable after create.
+ * Mirrors the public fields of `BeliefPropagationDecoder`
+ * (src/decoders/belief_propagation.jl:38-59: per, max_iters, s, n). */
+typedef struct ldpc_bp_info {
+    int64_t s, n, nnz;
+    int64_t max_iters;
+    double per;
+    int32_t max_check_degree, max_bit_degree;
+    int32_t device;           /* HIP device ordinal */
+    int32_t tile_syndromes;   /* syndromes decoded together by one workgroup (lane = syndrome) */
+    int32_t waves_per_tile;   /* wavefronts cooperating on one tile */
+    int32_t resident_tiles;   /* workspace slots = workgroups in the persistent grid */
+    int64_t workspace_bytes;  /* device bytes held by the handle */
+} ldpc_bp_info;
+
+/* Optional knobs; pass NULL to ldpc_bp_create for defaults.  Zero = default. */
+typedef struct ldpc_bp_options {
+    int32_t device;           /* HIP device ordinal; -1 = current device */
+    int32_t waves_per_tile;   /* 0 = auto */
+    int32_t resident_tiles;   /* 0 = auto (fills the chip) */
+    int32_t kernel_variant;   /* 0 = auto; see DESIGN.md */
+    int32_t reserved[12];
+} ldpc_bp_options;
+
+/* Library / ABI version and build target ("gfx950"). */
+int32_t ldpc_abi_version(void);
+const char *ldpc_build_target(void);
+
+/* Message of the last failed call on this thread ("" if none). */
+const char *ldpc_last_error(void);
+
+/* Number of usable gfx950 devices (0 when there is none; never fails). */
+int32_t ldpc_device_count(void);
+
+/*
+ * Replaces `BeliefPropagationDecoder(H, per::Float64, max_iters::Int)`
+ * (src/decoders/belief_propagation.jl:61-67) together with the scratch
+ * constructor (:20-22).
+ *
+ * H arrives as the CSC pattern that `sparse(H)` builds at :63 -- colptr[n+1],
+ * rowval[nnz], ZERO-based, row indices strictly ascending inside each column
+ * (Julia's SparseMatrixCSC invariant; the message products depend on that
+ * order).  Every stored entry is an edge, as in the reference, which walks
+ * `nzrange` without looking at the stored Bool (:128,137,155).  The transpose
+ * pattern (`sparse(H')`, :64) is derived inside.
+ */
+ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *colptr,
+                           const int64_t *rowval, double per, int64_t max_iters,
+                           const ldpc_bp_options *options, ldpc_bp_decoder **out);
+
+/* Frees device memory and the handle (the reference relies on Julia's GC). */
+ldpc_status ldpc_bp_destroy(ldpc_bp_decoder *dec);
+
+ldpc_status ldpc_bp_get_info(const ldpc_bp_decoder *dec, ldpc_bp_info *info);
+
+/*
+ * Replaces `batchdecode!(decoder, syndromes, errors, success)`
+ * (src/decoders/belief_propagation.jl:220-231; 3-argument form
+ * src/decoders/abstract_decoder.jl:44-48) and, with batch = 1,
+ * `decode!(decoder, syndrome)` (:121-188) including its leading `reset!`
+ * (:83-91, :122).  HOST buffers.
+ *
+ *   syndromes [batch][s] uint8   in : entry parity gives the sign (-1)^x (:136); an entry
+ *                                     other than 0/1 can never satisfy the convergence `==` (:181)
+ *   errors    [batch][n] uint8   out: hard decisions 0/1 of the last executed iteration (:164-168)
+ *   converged [batch]    uint8   out: 1 iff the syndrome was matched within max_iters (:180-184)
+ *   llr       [batch][n] double  out, may be NULL: scratch.log_probabs = log(1/temp) (:163)
+ *   iters     [batch]    int32   out, may be NULL: iterations executed (extension; reference has none)
+ *
+ * max_iters = 0 yields zeros / converged = 0 / llr = 0 exactly like the reference.
+ */
+ldpc_status ldpc_bp_decode_batch(ldpc_bp_decoder *dec, int64_t batch, const uint8_t *syndromes,
+                                 uint8_t *errors, uint8_t *converged, double *llr, int32_t *iters);
+
+/*
+ * Same contract with DEVICE pointers (HBM-resident batches: the multi-GPU
+ * shards of INTEGRATION.md, and bench.py).  Work is enqueued on `stream`
+ * (a hipStream_t passed as void*; NULL = the default stream) and is
+ * asynchronous; outputs are valid once the stream has been synchronised.
+ */
+ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *dec, int64_t batch,
+                                        const uint8_t *d_syndromes, uint8_t *d_errors,
+                                        uint8_t *d_converged, double *d_llr, int32_t *d_iters,
+                                        void *stream);
+
+/*
+ * Timing of the most recent ldpc_bp_decode_batch[_device] call, taken with HIP
+ * events on the stream the kernels were launched on.  Blocks until that call
+ * has finished.  sweep_ms = the message-passing kernel alone (the roofline
+ * kernel), total_ms = pack + sweeps + unpack.  sum_iters = sum over the batch
+ * of iterations executed (the factor of the algorithmic byte count,
+ * 32 * nnz bytes per syndrome * iteration).
+ */
+ldpc_status ldpc_bp_last_timing(ldpc_bp_decoder *dec, double *sweep_ms, double *total_ms,
+                                int64_t *sum_iters);
+
+/* Same for an earlier call: calls_back = 0 is the most recent batch call, 1 the
+ * one before, ... up to 15 (a ring of 16 event sets).  Lets a caller time K
+ * back-to-back asynchronous calls without synchronising between them. */
+ldpc_status ldpc_bp_call_timing(ldpc_bp_decoder *dec, int32_t calls_back, double *sweep_ms,
+                                double *total_ms, int64_t *sum_iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDPC_MI355X_H */

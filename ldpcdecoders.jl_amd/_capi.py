@@ -1,0 +1,116 @@
+"""ctypes binding of libldpc_mi355x.so (include/ldpc_mi355x.h).
+
+This is the same C ABI the Julia `ccall` shim binds.  There is
+no fallback of any kind: a missing library or a missing gfx950 device raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libldpc_mi355x.so")
+
+LDPC_OK = 0
+STATUS_NAMES = {
+    0: "LDPC_OK",
+    1: "LDPC_ERR_INVALID_ARGUMENT",
+    2: "LDPC_ERR_NO_DEVICE",
+    3: "LDPC_ERR_HIP",
+    4: "LDPC_ERR_OUT_OF_MEMORY",
+    5: "LDPC_ERR_UNSUPPORTED",
+}
+
+# every symbol include/ldpc_mi355x.h declares
+EXPORTED_SYMBOLS = (
+    "ldpc_abi_version",
+    "ldpc_build_target",
+    "ldpc_last_error",
+    "ldpc_device_count",
+    "ldpc_bp_create",
+    "ldpc_bp_destroy",
+    "ldpc_bp_get_info",
+    "ldpc_bp_decode_batch",
+    "ldpc_bp_decode_batch_device",
+    "ldpc_bp_last_timing",
+    "ldpc_bp_call_timing",
+)
+
+
+class LdpcError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+        self.message = message
+
+
+class BPInfo(ctypes.Structure):
+    _fields_ = [
+        ("s", ctypes.c_int64), ("n", ctypes.c_int64), ("nnz", ctypes.c_int64),
+        ("max_iters", ctypes.c_int64), ("per", ctypes.c_double),
+        ("max_check_degree", ctypes.c_int32), ("max_bit_degree", ctypes.c_int32),
+        ("device", ctypes.c_int32), ("tile_syndromes", ctypes.c_int32),
+        ("waves_per_tile", ctypes.c_int32), ("resident_tiles", ctypes.c_int32),
+        ("workspace_bytes", ctypes.c_int64),
+    ]
+
+
+class BPOptions(ctypes.Structure):
+    _fields_ = [
+        ("device", ctypes.c_int32), ("waves_per_tile", ctypes.c_int32),
+        ("resident_tiles", ctypes.c_int32), ("kernel_variant", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 12),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in ("ldpc_mi355x.hip", "bp_kernels.hpp", "Makefile")]
+    srcs.append(os.path.join(_HERE, "..", "include", "ldpc_mi355x.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(
+        os.path.getmtime(f) > os.path.getmtime(LIB_PATH) for f in srcs if os.path.exists(f))
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", CSRC, "libldpc_mi355x.so"])
+    return LIB_PATH
+
+
+_LIB = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load the HIP library; raises (never falls back) if it is not built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise LdpcError(2, f"{LIB_PATH} is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "or `make -C ldpcdecoders.jl_amd/csrc`. There is no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i64, i32, f64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_double
+    L.ldpc_abi_version.restype = i32
+    L.ldpc_build_target.restype = ctypes.c_char_p
+    L.ldpc_last_error.restype = ctypes.c_char_p
+    L.ldpc_device_count.restype = i32
+    L.ldpc_bp_create.restype = i32
+    L.ldpc_bp_create.argtypes = [i64, i64, i64, vp, vp, f64, i64, ctypes.POINTER(BPOptions), ctypes.POINTER(vp)]
+    L.ldpc_bp_destroy.restype = i32
+    L.ldpc_bp_destroy.argtypes = [vp]
+    L.ldpc_bp_get_info.restype = i32
+    L.ldpc_bp_get_info.argtypes = [vp, ctypes.POINTER(BPInfo)]
+    L.ldpc_bp_decode_batch.restype = i32
+    L.ldpc_bp_decode_batch.argtypes = [vp, i64, vp, vp, vp, vp, vp]
+    L.ldpc_bp_decode_batch_device.restype = i32
+    L.ldpc_bp_decode_batch_device.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
+    L.ldpc_bp_last_timing.restype = i32
+    L.ldpc_bp_last_timing.argtypes = [vp, ctypes.POINTER(f64), ctypes.POINTER(f64), ctypes.POINTER(i64)]
+    L.ldpc_bp_call_timing.restype = i32
+    L.ldpc_bp_call_timing.argtypes = [vp, i32, ctypes.POINTER(f64), ctypes.POINTER(f64), ctypes.POINTER(i64)]
+    _LIB = L
+    return L
+
+
+def check(status: int) -> None:
+    if status != LDPC_OK:
+        raise LdpcError(status, lib().ldpc_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,330 @@
+// bp_kernels.hpp -- gfx950 (MI355X, CDNA4) device code for the belief-propagation
+// message sweeps of LDPCDecoders.jl's BeliefPropagationDecoder.
+//
+// What is computed (reference: src/decoders/belief_propagation.jl):
+//   check-node sweep    :135-150   ordered prefix x suffix product in the odds domain
+//   variable-node sweep :152-178   ordered prefix x suffix product with NaN reset,
+//                                  posterior odds, hard decision, log(1/T)
+//   convergence test    :180-184   GF(2) parity of the hard decisions per check
+//
+// How it is laid out for the machine (nothing like the reference's dense s x n
+// matrices):
+//   * lane = syndrome.  A TILE is 64 syndromes = one wavefront wide.  Every
+//     edge message of a tile is one 512-byte row  msg[edge][64]  so any edge
+//     order is a perfectly coalesced wave access, and the serial, order-
+//     dependent products of the reference run unchanged inside one lane --
+//     bit-exactness by construction, no cross-lane re-association anywhere.
+//   * ONE message array per tile, updated IN PLACE: a check owns its edges
+//     during the check sweep (reads bit->check, writes check->bit into the same
+//     rows), a bit owns its edges during the variable sweep.  Rows are stored
+//     check-major (CSR order), so the check sweep streams contiguously and the
+//     variable sweep gathers/scatters whole 512-byte rows.
+//   * hard decisions and syndromes are 64-bit lane masks (one word per bit /
+//     per check and tile): the convergence test is XORs of words.
+//   * a workgroup owns a workspace slot and pulls tiles from a queue; it keeps
+//     iterating on its tile with workgroup barriers only (syndromes are
+//     independent, so there is no grid-wide synchronisation at all).
+//
+// Compiled with -ffp-contract=off: the reference (Julia) never fuses a*b+c.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ldpc {
+
+typedef unsigned long long u64;
+
+constexpr int kTile = 64;  // syndromes per tile == wavefront width on gfx950
+
+struct BPParams {
+    int s, n, nnz;
+    int max_iters;
+    int ntiles;
+    long long batch;
+    double r;  // channel odds per/(1-per)   (belief_propagation.jl:129,153)
+    // per-launch buffers
+    double *msg;          // [slots][nnz][64]   workspace, slot = blockIdx.x
+    u64 *errmask;         // [ntiles][n]
+    double *llr;          // [ntiles][n][64] or nullptr
+    int *iters;           // [batch] or nullptr
+    unsigned char *conv;  // [batch]
+    unsigned int *queue;  // tile queue head
+    u64 *sum_iters;       // accumulated iterations executed
+};
+
+__device__ __forceinline__ u64 wave_or(u64 v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffu), off, 64);
+        unsigned hi = __shfl_xor((unsigned)(v >> 32), off, 64);
+        v |= ((u64)hi << 32) | lo;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// check-node update for one check and 64 syndromes (one wave).
+// belief_propagation.jl:136-149.  `M` points at the check's first row + lane.
+// ---------------------------------------------------------------------------
+template <int DC>
+__device__ __forceinline__ void check_update(double *M, int deg, double sigma, bool first, double r)
+{
+    if (deg <= DC) {
+        double a[DC], pre[DC];
+#pragma unroll
+        for (int k = 0; k < DC; ++k)
+            if (k < deg) {
+                double m = first ? r : M[(size_t)k * kTile];
+                a[k] = 2.0 / (1.0 + m) - 1.0;            // :140 / :148 (same value both times)
+            }
+        double P = sigma;                                 // :136
+#pragma unroll
+        for (int k = 0; k < DC; ++k)
+            if (k < deg) { pre[k] = P; P = P * a[k]; }    // :139-140
+        double S = 1.0;                                   // :143
+#pragma unroll
+        for (int k = DC - 1; k >= 0; --k)
+            if (k < deg) {
+                double t = pre[k] * S;                    // :146
+                M[(size_t)k * kTile] = (1.0 - t) / (1.0 + t);  // :147
+                S = S * a[k];                             // :148
+            }
+    } else {
+        // Rare high-degree row: O(deg^2) recomputation of the prefix, still in place
+        // (position k is overwritten only after every prefix that needs it was formed).
+        double S = 1.0;
+        for (int k = deg - 1; k >= 0; --k) {
+            double P = sigma;
+            for (int q = 0; q < k; ++q) {
+                double m = first ? r : M[(size_t)q * kTile];
+                P = P * (2.0 / (1.0 + m) - 1.0);
+            }
+            double mk = first ? r : M[(size_t)k * kTile];
+            double ak = 2.0 / (1.0 + mk) - 1.0;
+            double t = P * S;
+            M[(size_t)k * kTile] = (1.0 - t) / (1.0 + t);
+            S = S * ak;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// variable-node update for one bit and 64 syndromes (one wave).
+// belief_propagation.jl:153-177.  Returns the posterior odds T.
+// `Mt` = tile message base + lane; pos = CSR positions of the bit's edges.
+// ---------------------------------------------------------------------------
+template <int DV>
+__device__ __forceinline__ double bit_update(double *Mt, const int *pos, int deg, double r)
+{
+    double F = r;                                         // :153
+    if (deg <= DV) {
+        double c[DV], pre[DV];
+        size_t at[DV];
+#pragma unroll
+        for (int k = 0; k < DV; ++k)
+            if (k < deg) {
+                at[k] = (size_t)pos[k] * kTile;
+                c[k] = Mt[at[k]];
+            }
+#pragma unroll
+        for (int k = 0; k < DV; ++k)
+            if (k < deg) {
+                pre[k] = F;                               // :156
+                F = F * c[k];                             // :157
+                if (F != F) F = 1.0;                      // :158-160
+            }
+        double G = 1.0;                                   // :170
+#pragma unroll
+        for (int k = DV - 1; k >= 0; --k)
+            if (k < deg) {
+                Mt[at[k]] = pre[k] * G;                   // :172 (unguarded, may be NaN)
+                G = G * c[k];                             // :173
+                if (G != G) G = 1.0;                      // :174-176
+            }
+    } else {
+        for (int k = 0; k < deg; ++k) {
+            F = F * Mt[(size_t)pos[k] * kTile];
+            if (F != F) F = 1.0;
+        }
+        double G = 1.0;
+        for (int k = deg - 1; k >= 0; --k) {
+            double Pk = r;
+            for (int q = 0; q < k; ++q) {
+                Pk = Pk * Mt[(size_t)pos[q] * kTile];
+                if (Pk != Pk) Pk = 1.0;
+            }
+            size_t a = (size_t)pos[k] * kTile;
+            double ck = Mt[a];
+            Mt[a] = Pk * G;
+            G = G * ck;
+            if (G != G) G = 1.0;
+        }
+    }
+    return F;
+}
+
+// ---------------------------------------------------------------------------
+// The message-passing kernel: persistent workgroups, one tile at a time.
+// ---------------------------------------------------------------------------
+// The Tanner graph (int32, device resident, read-only for the whole launch) and the
+// packed syndromes are separate __restrict__ arguments so that their wave-uniform reads
+// become scalar loads:
+//   row_ptr  [s+1]  CSR (check-major) edge ranges
+//   edge_bit [nnz]  bit of every CSR edge, ascending inside a check
+//   col_ptr  [n+1]  CSC (bit-major) edge ranges
+//   csc2csr  [nnz]  CSR position of every CSC edge, checks ascending inside a bit
+//   synmask  [ntiles][s], nevermask [ntiles] (lanes holding a syndrome entry other than 0/1)
+template <int DC, int DV, bool WANT_LLR, int THREADS>
+__global__ void __launch_bounds__(THREADS)
+bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restrict__ edge_bit,
+               const int *__restrict__ col_ptr, const int *__restrict__ csc2csr,
+               const u64 *__restrict__ synmask, const u64 *__restrict__ nevermask)
+{
+    __shared__ int sh_tile;
+    __shared__ u64 sh_mism[THREADS / 64];
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    constexpr int W = THREADS / 64;
+    const int s = p.s, n = p.n;
+    const double r = p.r;
+    double *const Mt = p.msg + (size_t)blockIdx.x * (size_t)p.nnz * kTile + lane;
+
+    for (;;) {
+        if (threadIdx.x == 0) sh_tile = (int)atomicAdd(p.queue, 1u);
+        __syncthreads();
+        const int tile = sh_tile;
+        if (tile >= p.ntiles) break;  // every wave of every workgroup reaches this
+
+        const u64 *syn = synmask + (size_t)tile * s;
+        u64 *em = p.errmask + (size_t)tile * n;
+        const long long b0 = (long long)tile * kTile;
+        const long long left = p.batch - b0;
+        const u64 valid = left >= kTile ? ~0ull : ((1ull << left) - 1ull);
+        const u64 never = nevermask[tile];
+        u64 active = valid;
+        int my_iters = 0;
+        int my_conv = 0;
+        int it = 0;
+
+        while (active != 0 && it < p.max_iters) {
+            ++it;
+            const bool first = (it == 1);
+            // ---- check-node sweep  (:135-150)
+            for (int i = w; i < s; i += W) {
+                const int e0 = row_ptr[i];
+                const int deg = row_ptr[i + 1] - e0;
+                const double sigma = ((syn[i] >> lane) & 1ull) ? -1.0 : 1.0;  // (-1)^syndrome[i] :136
+                check_update<DC>(Mt + (size_t)e0 * kTile, deg, sigma, first, r);
+            }
+            __syncthreads();
+            // ---- variable-node sweep  (:152-178)
+            for (int j = w; j < n; j += W) {
+                const int c0 = col_ptr[j];
+                const int deg = col_ptr[j + 1] - c0;
+                const double T = bit_update<DV>(Mt, csc2csr + c0, deg, r);
+                const u64 dec = __ballot(T >= 1.0);                            // :164-168
+                if (WANT_LLR) {
+                    if ((active >> lane) & 1ull)
+                        p.llr[((size_t)tile * n + j) * kTile + lane] = log(1.0 / T);  // :163
+                }
+                if (lane == 0) {
+                    u64 v = dec;
+                    if (active != ~0ull) v = (em[j] & ~active) | (dec & active);  // frozen lanes keep theirs
+                    em[j] = v;
+                }
+            }
+            __syncthreads();
+            // ---- convergence test (:180-184): lane = check, words = 64 syndromes
+            u64 mism = 0;
+            for (int i = w * 64 + lane; i < s; i += W * 64) {
+                u64 par = 0;
+                const int e1 = row_ptr[i + 1];
+                for (int e = row_ptr[i]; e < e1; ++e) par ^= em[edge_bit[e]];
+                mism |= par ^ syn[i];
+            }
+            mism = wave_or(mism);
+            if (lane == 0) sh_mism[w] = mism;
+            __syncthreads();
+            u64 U = never;
+#pragma unroll
+            for (int q = 0; q < W; ++q) U |= sh_mism[q];
+            const u64 newly = active & ~U;
+            if ((newly >> lane) & 1ull) { my_iters = it; my_conv = 1; }
+            active &= U;
+        }
+        if ((active >> lane) & 1ull) { my_iters = it; my_conv = 0; }
+        if (w == 0) {
+            if ((valid >> lane) & 1ull) {
+                p.conv[b0 + lane] = (unsigned char)my_conv;
+                if (p.iters) p.iters[b0 + lane] = my_iters;
+            } else {
+                my_iters = 0;
+            }
+            // sum of iterations executed, for the algorithmic byte count
+            int tot = my_iters;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
+            if (lane == 0) atomicAdd(p.sum_iters, (u64)tot);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// pack: syndromes uint8 [batch][s]  ->  lane masks synmask[tile][s] (+ nevermask)
+// one wave per (tile, 64 checks); lane = check.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) pack_syndromes_kernel(const unsigned char *syn, long long batch,
+                                                            int s, u64 *synmask, u64 *nevermask)
+{
+    const int tile = blockIdx.y;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const long long b0 = (long long)tile * kTile;
+    const int rows = (int)((batch - b0) < kTile ? (batch - b0) : kTile);
+    u64 m = 0, hi = 0;
+    if (i < s) {
+        const unsigned char *p = syn + (size_t)b0 * s + i;
+        for (int rr = 0; rr < rows; ++rr) {
+            unsigned v = p[(size_t)rr * s];
+            m |= (u64)(v & 1u) << rr;
+            hi |= (u64)(v > 1u) << rr;
+        }
+        synmask[(size_t)tile * s + i] = m;
+    }
+    hi = wave_or(hi);
+    if (threadIdx.x == 0 && hi) atomicOr(&nevermask[tile], hi);
+}
+
+// unpack: errmask[tile][n] -> errors uint8 [batch][n]; one wave per (tile, 64 bits)
+__global__ void __launch_bounds__(64) unpack_errors_kernel(const u64 *errmask, long long batch, int n,
+                                                           unsigned char *errors)
+{
+    const int tile = blockIdx.y;
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    const long long b0 = (long long)tile * kTile;
+    const int rows = (int)((batch - b0) < kTile ? (batch - b0) : kTile);
+    if (j >= n) return;
+    const u64 m = errmask[(size_t)tile * n + j];
+    unsigned char *o = errors + (size_t)b0 * n + j;
+    for (int rr = 0; rr < rows; ++rr) o[(size_t)rr * n] = (unsigned char)((m >> rr) & 1ull);
+}
+
+// llr transpose: llr_t[tile][n][64] -> llr[batch][n]; 64x64 tile through LDS
+__global__ void __launch_bounds__(256) unpack_llr_kernel(const double *llr_t, long long batch, int n,
+                                                         double *llr)
+{
+    __shared__ double t[64][65];
+    const int tile = blockIdx.y;
+    const int j0 = blockIdx.x * 64;
+    const long long b0 = (long long)tile * kTile;
+    const int rows = (int)((batch - b0) < kTile ? (batch - b0) : kTile);
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int jj = ty; jj < 64; jj += 4)
+        if (j0 + jj < n) t[jj][tx] = llr_t[((size_t)tile * n + j0 + jj) * kTile + tx];
+    __syncthreads();
+    for (int rr = ty; rr < rows; rr += 4)
+        if (j0 + tx < n) llr[(size_t)(b0 + rr) * n + j0 + tx] = t[tx][rr];
+}
+
+}  // namespace ldpc

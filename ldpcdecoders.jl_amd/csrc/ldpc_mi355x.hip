@@ -1,0 +1,459 @@
+// ldpc_mi355x.hip -- host side of libldpc_mi355x.so: the C ABI declared in
+// include/ldpc_mi355x.h, Tanner-graph preparation, workspace management and
+// kernel dispatch.  Device code lives in bp_kernels.hpp.
+//
+// Reference interfaces replaced (QuantumSavory/LDPCDecoders.jl):
+//   BeliefPropagationDecoder(H, per, max_iters)  src/decoders/belief_propagation.jl:61-67
+//   reset! + decode!                              :83-91, :121-188
+//   batchdecode!                                  :220-231, src/decoders/abstract_decoder.jl:31-48
+//
+// There is deliberately no CPU path in this file: if HIP or the device is not
+// usable every compute entry fails with a status code.
+#include "../../include/ldpc_mi355x.h"
+#include "bp_kernels.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace ldpc;
+
+namespace {
+
+thread_local std::string g_err;
+
+ldpc_status fail(ldpc_status st, const std::string &msg)
+{
+    g_err = msg;
+    return st;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (void)hipGetLastError();                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? LDPC_ERR_OUT_OF_MEMORY : LDPC_ERR_HIP,     \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                    \
+        }                                                                                      \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    ldpc_status ensure(size_t bytes)
+    {
+        if (bytes <= cap) return LDPC_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            p = nullptr;
+            return fail(LDPC_ERR_OUT_OF_MEMORY, "hipMalloc(" + std::to_string(bytes) + " B): " + hipGetErrorString(e));
+        }
+        cap = bytes;
+        return LDPC_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+typedef void (*bp_kernel_t)(BPParams, const int *, const int *, const int *, const int *, const u64 *,
+                            const u64 *);
+
+template <int DC, int DV, bool LLR>
+bp_kernel_t pick_threads(int threads)
+{
+    switch (threads) {
+    case 256: return bp_tile_kernel<DC, DV, LLR, 256>;
+    case 512: return bp_tile_kernel<DC, DV, LLR, 512>;
+    default: return bp_tile_kernel<DC, DV, LLR, 1024>;
+    }
+}
+
+template <int DC, bool LLR>
+bp_kernel_t pick_dv(int dv, int threads)
+{
+    if (dv <= 4) return pick_threads<DC, 4, LLR>(threads);
+    return pick_threads<DC, 16, LLR>(threads);
+}
+
+template <bool LLR>
+bp_kernel_t pick_dc(int dc, int dv, int threads)
+{
+    if (dc <= 8) return pick_dv<8, LLR>(dv, threads);
+    if (dc <= 16) return pick_dv<16, LLR>(dv, threads);
+    return pick_dv<32, LLR>(dv, threads);
+}
+
+bp_kernel_t pick_kernel(int dc, int dv, bool llr, int threads)
+{
+    return llr ? pick_dc<true>(dc, dv, threads) : pick_dc<false>(dc, dv, threads);
+}
+
+}  // namespace
+
+struct ldpc_bp_decoder {
+    int64_t s = 0, n = 0, nnz = 0, max_iters = 0;
+    double per = 0.0;
+    int device = 0;
+    int num_cus = 0;
+    int max_cdeg = 0, max_bdeg = 0;
+    int threads = 512;        // waves_per_tile * 64
+    int resident_tiles = 0;   // workspace slots
+    // device graph
+    DevBuf row_ptr, edge_bit, col_ptr, csc2csr;
+    // workspace
+    DevBuf msg;               // [resident_tiles][nnz][64] double
+    DevBuf ctrl;              // queue (u32) + sum_iters (u64), 64 B
+    // per-batch buffers (grow only)
+    DevBuf synmask, nevermask, errmask, llr_t;
+    // staging for the host-pointer entry
+    DevBuf st_syn, st_err, st_conv, st_llr, st_iters;
+    // timing ring: the last kRing batch calls keep their HIP events and iteration sums
+    static constexpr int kRing = 16;
+    hipEvent_t ev[kRing][4] = {};
+    bool timed[kRing] = {};
+    uint64_t ncalls = 0;
+
+    ~ldpc_bp_decoder()
+    {
+        DevBuf *all[] = {&row_ptr, &edge_bit, &col_ptr, &csc2csr, &msg, &ctrl, &synmask, &nevermask,
+                         &errmask, &llr_t, &st_syn, &st_err, &st_conv, &st_llr, &st_iters};
+        for (DevBuf *b : all) b->release();
+        for (auto &slot : ev)
+            for (hipEvent_t &e : slot)
+                if (e) (void)hipEventDestroy(e);
+    }
+};
+
+extern "C" {
+
+int32_t ldpc_abi_version(void) { return LDPC_MI355X_ABI_VERSION; }
+const char *ldpc_build_target(void) { return "gfx950"; }
+const char *ldpc_last_error(void) { return g_err.c_str(); }
+
+int32_t ldpc_device_count(void)
+{
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    int usable = 0;
+    for (int d = 0; d < cnt; ++d) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++usable;
+    }
+    return usable;
+}
+
+ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *colptr,
+                           const int64_t *rowval, double per, int64_t max_iters,
+                           const ldpc_bp_options *options, ldpc_bp_decoder **out)
+{
+    if (!out) return fail(LDPC_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    if (s < 0 || n < 0 || nnz < 0) return fail(LDPC_ERR_INVALID_ARGUMENT, "negative dimension");
+    if (!colptr || (nnz > 0 && !rowval)) return fail(LDPC_ERR_INVALID_ARGUMENT, "colptr/rowval is NULL");
+    if (max_iters < 0 || max_iters > INT32_MAX) return fail(LDPC_ERR_INVALID_ARGUMENT, "max_iters out of range");
+    if (s >= INT32_MAX || n >= INT32_MAX || nnz >= (int64_t)INT32_MAX / 64 * 8)
+        return fail(LDPC_ERR_UNSUPPORTED, "graph too large for 32-bit edge indexing");
+    if (colptr[0] != 0 || colptr[n] != nnz)
+        return fail(LDPC_ERR_INVALID_ARGUMENT, "colptr[0] must be 0 and colptr[n] must equal nnz (zero-based CSC)");
+    for (int64_t j = 0; j < n; ++j) {
+        if (colptr[j + 1] < colptr[j]) return fail(LDPC_ERR_INVALID_ARGUMENT, "colptr is not non-decreasing");
+        for (int64_t k = colptr[j]; k < colptr[j + 1]; ++k) {
+            if (rowval[k] < 0 || rowval[k] >= s)
+                return fail(LDPC_ERR_INVALID_ARGUMENT, "rowval entry outside [0, s)");
+            if (k > colptr[j] && rowval[k] <= rowval[k - 1])
+                return fail(LDPC_ERR_INVALID_ARGUMENT,
+                            "row indices must be strictly ascending inside each column (SparseMatrixCSC invariant)");
+        }
+    }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return fail(LDPC_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    }
+    int device = options ? options->device : -1;
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    if (device >= ndev) return fail(LDPC_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(LDPC_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+
+    ldpc_bp_decoder *d = new (std::nothrow) ldpc_bp_decoder();
+    if (!d) return fail(LDPC_ERR_OUT_OF_MEMORY, "host allocation failed");
+    d->s = s; d->n = n; d->nnz = nnz; d->max_iters = max_iters; d->per = per;
+    d->device = device;
+    d->num_cus = prop.multiProcessorCount;
+
+    // sparse(H') (belief_propagation.jl:64): CSR of H, bits ascending inside each check,
+    // plus for every CSC edge its position in that check-major order.
+    std::vector<int> row_ptr((size_t)s + 1, 0), edge_bit((size_t)std::max<int64_t>(nnz, 1)),
+        col_ptr((size_t)n + 1), csc2csr((size_t)std::max<int64_t>(nnz, 1));
+    for (int64_t k = 0; k < nnz; ++k) row_ptr[(size_t)rowval[k] + 1]++;
+    for (int64_t i = 0; i < s; ++i) {
+        d->max_cdeg = std::max(d->max_cdeg, row_ptr[(size_t)i + 1]);
+        row_ptr[(size_t)i + 1] += row_ptr[(size_t)i];
+    }
+    {
+        std::vector<int> fill(row_ptr.begin(), row_ptr.end() - 1);
+        for (int64_t j = 0; j < n; ++j) {
+            col_ptr[(size_t)j] = (int)colptr[j];
+            d->max_bdeg = std::max(d->max_bdeg, (int)(colptr[j + 1] - colptr[j]));
+            for (int64_t k = colptr[j]; k < colptr[j + 1]; ++k) {
+                int q = fill[(size_t)rowval[k]]++;
+                edge_bit[(size_t)q] = (int)j;
+                csc2csr[(size_t)k] = q;
+            }
+        }
+        col_ptr[(size_t)n] = (int)nnz;
+    }
+
+    ldpc_status st = LDPC_OK;
+    auto upload = [&](DevBuf &b, const std::vector<int> &v) -> ldpc_status {
+        ldpc_status r = b.ensure(std::max<size_t>(v.size(), 1) * sizeof(int));
+        if (r != LDPC_OK) return r;
+        if (hipMemcpy(b.p, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(LDPC_ERR_HIP, "hipMemcpy of the Tanner graph failed");
+        }
+        return LDPC_OK;
+    };
+    if ((st = upload(d->row_ptr, row_ptr)) != LDPC_OK || (st = upload(d->edge_bit, edge_bit)) != LDPC_OK ||
+        (st = upload(d->col_ptr, col_ptr)) != LDPC_OK || (st = upload(d->csc2csr, csc2csr)) != LDPC_OK) {
+        delete d;
+        return st;
+    }
+
+    // geometry: waves per tile and number of workspace slots (persistent workgroups)
+    int wpt = options ? options->waves_per_tile : 0;
+    if (wpt == 0) wpt = 8;
+    if (wpt != 4 && wpt != 8 && wpt != 16) {
+        delete d;
+        return fail(LDPC_ERR_INVALID_ARGUMENT, "waves_per_tile must be 0, 4, 8 or 16");
+    }
+    d->threads = wpt * 64;
+    bp_kernel_t kfn = pick_kernel(d->max_cdeg, d->max_bdeg, false, d->threads);
+    int blocks_per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, (const void *)kfn, d->threads, 0) != hipSuccess ||
+        blocks_per_cu <= 0) {
+        (void)hipGetLastError();
+        blocks_per_cu = 1;
+    }
+    int resident = options ? options->resident_tiles : 0;
+    if (resident <= 0) resident = blocks_per_cu * d->num_cus;
+    // keep the workspace inside a sane share of HBM (slots are nnz*512 B each)
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        size_t slot = (size_t)std::max<int64_t>(nnz, 1) * kTile * sizeof(double);
+        size_t budget = free_b / 2;
+        if ((size_t)resident * slot > budget) resident = (int)std::max<size_t>(budget / slot, 1);
+    } else {
+        (void)hipGetLastError();
+    }
+    d->resident_tiles = resident;
+    // the message workspace itself is allocated on first use, sized min(resident, tiles in the batch)
+
+    if ((st = d->ctrl.ensure(64 * ldpc_bp_decoder::kRing)) != LDPC_OK) { delete d; return st; }
+    for (auto &slot : d->ev)
+        for (hipEvent_t &e : slot) {
+            if (hipEventCreate(&e) != hipSuccess) {
+                (void)hipGetLastError();
+                delete d;
+                return fail(LDPC_ERR_HIP, "hipEventCreate failed");
+            }
+        }
+    *out = d;
+    return LDPC_OK;
+}
+
+ldpc_status ldpc_bp_destroy(ldpc_bp_decoder *dec)
+{
+    if (!dec) return LDPC_OK;
+    (void)hipSetDevice(dec->device);
+    (void)hipDeviceSynchronize();
+    delete dec;
+    return LDPC_OK;
+}
+
+ldpc_status ldpc_bp_get_info(const ldpc_bp_decoder *d, ldpc_bp_info *info)
+{
+    if (!d || !info) return fail(LDPC_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::memset(info, 0, sizeof *info);
+    info->s = d->s; info->n = d->n; info->nnz = d->nnz; info->max_iters = d->max_iters; info->per = d->per;
+    info->max_check_degree = d->max_cdeg; info->max_bit_degree = d->max_bdeg;
+    info->device = d->device; info->tile_syndromes = kTile; info->waves_per_tile = d->threads / 64;
+    info->resident_tiles = d->resident_tiles;
+    const DevBuf *all[] = {&d->row_ptr, &d->edge_bit, &d->col_ptr, &d->csc2csr, &d->msg, &d->ctrl, &d->synmask,
+                           &d->nevermask, &d->errmask, &d->llr_t, &d->st_syn, &d->st_err, &d->st_conv,
+                           &d->st_llr, &d->st_iters};
+    for (const DevBuf *b : all) info->workspace_bytes += (int64_t)b->cap;
+    return LDPC_OK;
+}
+
+ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const uint8_t *d_syn,
+                                        uint8_t *d_err, uint8_t *d_conv, double *d_llr, int32_t *d_iters,
+                                        void *stream_v)
+{
+    if (!d) return fail(LDPC_ERR_INVALID_ARGUMENT, "decoder is NULL");
+    if (batch < 0) return fail(LDPC_ERR_INVALID_ARGUMENT, "negative batch");
+    hipStream_t stream = (hipStream_t)stream_v;
+    const int slot = (int)(d->ncalls++ % ldpc_bp_decoder::kRing);
+    hipEvent_t *ev = d->ev[slot];
+    char *ctrl = (char *)d->ctrl.p + 64 * slot;
+    d->timed[slot] = false;
+    if (batch == 0) return LDPC_OK;
+    if ((d->s > 0 && !d_syn) || (d->n > 0 && !d_err) || !d_conv)
+        return fail(LDPC_ERR_INVALID_ARGUMENT, "syndromes/errors/converged pointer is NULL");
+    HIP_TRY(hipSetDevice(d->device));
+    const int64_t s = d->s, n = d->n;
+
+    if (d->max_iters == 0) {
+        // the loop at belief_propagation.jl:134 never runs: err = 0, log_probabs = 0, converged = false
+        if (n > 0) HIP_TRY(hipMemsetAsync(d_err, 0, (size_t)batch * n, stream));
+        HIP_TRY(hipMemsetAsync(d_conv, 0, (size_t)batch, stream));
+        if (d_llr && n > 0) HIP_TRY(hipMemsetAsync(d_llr, 0, (size_t)batch * n * sizeof(double), stream));
+        if (d_iters) HIP_TRY(hipMemsetAsync(d_iters, 0, (size_t)batch * sizeof(int32_t), stream));
+        return LDPC_OK;
+    }
+
+    const int64_t ntiles64 = (batch + kTile - 1) / kTile;
+    if (ntiles64 > (1 << 30)) return fail(LDPC_ERR_UNSUPPORTED, "batch too large for one call");
+    const int ntiles = (int)ntiles64;
+    const bool want_llr = d_llr != nullptr;
+
+    ldpc_status st;
+    if ((st = d->synmask.ensure(std::max<size_t>((size_t)ntiles * s, 1) * sizeof(u64))) != LDPC_OK) return st;
+    if ((st = d->nevermask.ensure((size_t)ntiles * sizeof(u64))) != LDPC_OK) return st;
+    if ((st = d->errmask.ensure(std::max<size_t>((size_t)ntiles * n, 1) * sizeof(u64))) != LDPC_OK) return st;
+    if (want_llr && (st = d->llr_t.ensure(std::max<size_t>((size_t)ntiles * n, 1) * kTile * sizeof(double))) != LDPC_OK)
+        return st;
+    const int grid = std::min(d->resident_tiles, ntiles);
+    if ((st = d->msg.ensure((size_t)grid * std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double))) != LDPC_OK)
+        return st;
+
+    HIP_TRY(hipMemsetAsync(ctrl, 0, 64, stream));
+    HIP_TRY(hipMemsetAsync(d->nevermask.p, 0, (size_t)ntiles * sizeof(u64), stream));
+    HIP_TRY(hipEventRecord(ev[0], stream));
+    if (s > 0) {
+        dim3 g((unsigned)((s + 63) / 64), (unsigned)ntiles);
+        hipLaunchKernelGGL(pack_syndromes_kernel, g, dim3(64), 0, stream, d_syn, (long long)batch, (int)s,
+                           (u64 *)d->synmask.p, (u64 *)d->nevermask.p);
+        HIP_TRY(hipGetLastError());
+    }
+    BPParams p;
+    p.s = (int)s; p.n = (int)n; p.nnz = (int)d->nnz; p.max_iters = (int)d->max_iters;
+    p.ntiles = ntiles; p.batch = batch;
+    p.r = d->per / (1 - d->per);  // belief_propagation.jl:129,153 (IEEE double division, same on host)
+    p.msg = (double *)d->msg.p;
+    p.errmask = (u64 *)d->errmask.p;
+    p.llr = want_llr ? (double *)d->llr_t.p : nullptr;
+    p.iters = d_iters;
+    p.conv = d_conv;
+    p.queue = (unsigned int *)ctrl;
+    p.sum_iters = (u64 *)(ctrl + 8);
+    bp_kernel_t kfn = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, d->threads);
+    HIP_TRY(hipEventRecord(ev[1], stream));
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3((unsigned)d->threads), 0, stream, p,
+                       (const int *)d->row_ptr.p, (const int *)d->edge_bit.p, (const int *)d->col_ptr.p,
+                       (const int *)d->csc2csr.p, (const u64 *)d->synmask.p, (const u64 *)d->nevermask.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev[2], stream));
+    if (n > 0) {
+        dim3 g((unsigned)((n + 63) / 64), (unsigned)ntiles);
+        hipLaunchKernelGGL(unpack_errors_kernel, g, dim3(64), 0, stream, (const u64 *)d->errmask.p,
+                           (long long)batch, (int)n, d_err);
+        HIP_TRY(hipGetLastError());
+        if (want_llr) {
+            hipLaunchKernelGGL(unpack_llr_kernel, g, dim3(256), 0, stream, (const double *)d->llr_t.p,
+                               (long long)batch, (int)n, d_llr);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    HIP_TRY(hipEventRecord(ev[3], stream));
+    d->timed[slot] = true;
+    return LDPC_OK;
+}
+
+ldpc_status ldpc_bp_decode_batch(ldpc_bp_decoder *d, int64_t batch, const uint8_t *syn, uint8_t *err,
+                                 uint8_t *conv, double *llr, int32_t *iters)
+{
+    if (!d) return fail(LDPC_ERR_INVALID_ARGUMENT, "decoder is NULL");
+    if (batch < 0) return fail(LDPC_ERR_INVALID_ARGUMENT, "negative batch");
+    if (batch == 0) return ldpc_bp_decode_batch_device(d, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if ((d->s > 0 && !syn) || (d->n > 0 && !err) || !conv)
+        return fail(LDPC_ERR_INVALID_ARGUMENT, "syndromes/errors/converged pointer is NULL");
+    HIP_TRY(hipSetDevice(d->device));
+    const size_t s = (size_t)d->s, n = (size_t)d->n, B = (size_t)batch;
+    ldpc_status st;
+    if ((st = d->st_syn.ensure(std::max<size_t>(B * s, 1))) != LDPC_OK) return st;
+    if ((st = d->st_err.ensure(std::max<size_t>(B * n, 1))) != LDPC_OK) return st;
+    if ((st = d->st_conv.ensure(B)) != LDPC_OK) return st;
+    if (llr && (st = d->st_llr.ensure(std::max<size_t>(B * n, 1) * sizeof(double))) != LDPC_OK) return st;
+    if (iters && (st = d->st_iters.ensure(B * sizeof(int32_t))) != LDPC_OK) return st;
+    hipStream_t stream = nullptr;
+    if (s > 0) HIP_TRY(hipMemcpyAsync(d->st_syn.p, syn, B * s, hipMemcpyHostToDevice, stream));
+    st = ldpc_bp_decode_batch_device(d, batch, (const uint8_t *)d->st_syn.p, (uint8_t *)d->st_err.p,
+                                     (uint8_t *)d->st_conv.p, llr ? (double *)d->st_llr.p : nullptr,
+                                     iters ? (int32_t *)d->st_iters.p : nullptr, stream);
+    if (st != LDPC_OK) return st;
+    if (n > 0) HIP_TRY(hipMemcpyAsync(err, d->st_err.p, B * n, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(conv, d->st_conv.p, B, hipMemcpyDeviceToHost, stream));
+    if (llr && n > 0) HIP_TRY(hipMemcpyAsync(llr, d->st_llr.p, B * n * sizeof(double), hipMemcpyDeviceToHost, stream));
+    if (iters) HIP_TRY(hipMemcpyAsync(iters, d->st_iters.p, B * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return LDPC_OK;
+}
+
+ldpc_status ldpc_bp_call_timing(ldpc_bp_decoder *d, int32_t calls_back, double *sweep_ms, double *total_ms,
+                                int64_t *sum_iters)
+{
+    if (!d) return fail(LDPC_ERR_INVALID_ARGUMENT, "decoder is NULL");
+    if (sweep_ms) *sweep_ms = 0.0;
+    if (total_ms) *total_ms = 0.0;
+    if (sum_iters) *sum_iters = 0;
+    if (calls_back < 0 || calls_back >= ldpc_bp_decoder::kRing || (uint64_t)calls_back >= d->ncalls)
+        return fail(LDPC_ERR_INVALID_ARGUMENT, "calls_back outside the timing ring");
+    const int slot = (int)((d->ncalls - 1 - (uint64_t)calls_back) % ldpc_bp_decoder::kRing);
+    if (!d->timed[slot]) return LDPC_OK;
+    HIP_TRY(hipSetDevice(d->device));
+    HIP_TRY(hipEventSynchronize(d->ev[slot][3]));
+    float a = 0.f, b = 0.f;
+    HIP_TRY(hipEventElapsedTime(&a, d->ev[slot][1], d->ev[slot][2]));
+    HIP_TRY(hipEventElapsedTime(&b, d->ev[slot][0], d->ev[slot][3]));
+    if (sweep_ms) *sweep_ms = a;
+    if (total_ms) *total_ms = b;
+    if (sum_iters) {
+        u64 v = 0;
+        HIP_TRY(hipMemcpy(&v, (char *)d->ctrl.p + 64 * slot + 8, sizeof v, hipMemcpyDeviceToHost));
+        *sum_iters = (int64_t)v;
+    }
+    return LDPC_OK;
+}
+
+ldpc_status ldpc_bp_last_timing(ldpc_bp_decoder *d, double *sweep_ms, double *total_ms, int64_t *sum_iters)
+{
+    if (d && d->ncalls == 0) {
+        if (sweep_ms) *sweep_ms = 0.0;
+        if (total_ms) *total_ms = 0.0;
+        if (sum_iters) *sum_iters = 0;
+        return LDPC_OK;
+    }
+    return ldpc_bp_call_timing(d, 0, sweep_ms, total_ms, sum_iters);
+}
+
+}  // extern "C"

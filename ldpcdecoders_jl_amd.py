@@ -1,0 +1,13 @@
+"""Loader: makes the package directory ``ldpcdecoders.jl_amd/`` (whose name holds a
+dot and therefore cannot be written in an import statement) importable as
+``ldpcdecoders_jl_amd``."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ldpcdecoders.jl_amd")
+_spec = importlib.util.spec_from_file_location(
+    __name__, os.path.join(_dir, "__init__.py"), submodule_search_locations=[_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules[__name__] = _mod
+_spec.loader.exec_module(_mod)

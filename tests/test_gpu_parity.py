@@ -1,0 +1,174 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle.
+
+Bar (BASELINE.json north_star): hard decisions and convergence flags bit-exact,
+iteration counts equal, LLRs (`scratch.log_probabs`) within 1e-5 with +-Inf
+matching exactly.  Every test here runs the kernels on a real MI355X."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import BPOracle
+
+pytestmark = pytest.mark.gpu
+
+LLR_TOL = 1e-5  # north_star: "LLRs within 1e-5"
+
+
+def assert_parity(ldpc, H, per, max_iters, syn_bs, **kw):
+    """Decode syn_bs [B][s] on the GPU and with the oracle; compare everything."""
+    dec = ldpc.BeliefPropagationDecoder(H, per, max_iters, **kw)
+    err, conv, llr, its = dec.decode_batch_host(syn_bs, want_llr=True, want_iters=True)
+    # a second call without LLRs exercises the other kernel instantiation
+    err2, conv2, _, its2 = dec.decode_batch_host(syn_bs, want_llr=False, want_iters=True)
+    M = sp.csc_matrix(H)
+    M.sort_indices()
+    oc = BPOracle(csc=(M.indptr, M.indices), shape=M.shape, per=per, max_iters=max_iters)
+    oerr, oconv, ollr, oits = oc.batchdecode(syn_bs, want_llr=True)
+    assert np.array_equal(conv, oconv), f"converged flags differ at {np.nonzero(conv != oconv)[0][:10]}"
+    assert np.array_equal(its, oits), f"iteration counts differ at {np.nonzero(its != oits)[0][:10]}"
+    assert np.array_equal(err, oerr), f"hard decisions differ in rows {np.unique(np.nonzero(err != oerr)[0])[:10]}"
+    assert np.array_equal(err2, err) and np.array_equal(conv2, conv) and np.array_equal(its2, its)
+    fin = np.isfinite(ollr)
+    assert np.array_equal(np.isfinite(llr), fin)
+    assert np.array_equal(llr[~fin], ollr[~fin])           # +-Inf must match exactly
+    if fin.any():
+        assert np.max(np.abs(llr[fin] - ollr[fin])) <= LLR_TOL
+    dec.close()
+    return err, conv, its
+
+
+def test_c2_regular_3_6_n1008_batch4096(ldpc, gpu):
+    """BASELINE configs[1]: (3,6)-regular n=1008, per=0.01, 50 iters, batch 4096, bit-exact vs CPU."""
+    H = ldpc.codes.parity_check_csc(1008, 6, 3)
+    e = ldpc.codes.random_errors(1008, 4096, 0.01, seed=11)
+    syn = ldpc.codes.syndromes_of(H, e)
+    err, conv, its = assert_parity(ldpc, H, 0.01, 50, syn)
+    assert conv.mean() > 0.9
+
+
+def test_reference_test_code_1000_10_9(ldpc, gpu):
+    """The code of test/test_bp_decoder.jl: parity_check_matrix(1000,10,9), per=0.01, 100 iters."""
+    H = ldpc.codes.parity_check_csc(1000, 10, 9)
+    e = ldpc.codes.random_errors(1000, 300, 0.01, seed=12)
+    syn = ldpc.codes.syndromes_of(H, e)
+    err, conv, its = assert_parity(ldpc, H, 0.01, 100, syn)
+    assert conv.all() and np.array_equal(err, e)            # test_bp_decoder.jl:46-51
+
+
+@pytest.mark.parametrize("B", [1, 2, 63, 64, 65, 129])
+def test_ragged_batches(ldpc, gpu, B):
+    H = ldpc.codes.parity_check_csc(504, 6, 3)
+    e = ldpc.codes.random_errors(504, B, 0.03, seed=100 + B)
+    assert_parity(ldpc, H, 0.03, 30, ldpc.codes.syndromes_of(H, e))
+
+
+@pytest.mark.parametrize("per", [0.06, 0.10, 0.2])
+def test_non_convergent_full_iterations(ldpc, gpu, per):
+    """Above threshold nothing converges: all max_iters run, messages reach Inf/NaN territory."""
+    H = ldpc.codes.parity_check_csc(1008, 6, 3)
+    e = ldpc.codes.random_errors(1008, 200, per, seed=int(per * 1000))
+    assert_parity(ldpc, H, per, 50, ldpc.codes.syndromes_of(H, e))
+
+
+@pytest.mark.parametrize("per", [0.0, 1e-12, 0.5, 0.999, 1.0])
+def test_extreme_channel_probabilities(ldpc, gpu, per):
+    """per = 0 / 1 give odds 0 / Inf; the NaN-reset (belief_propagation.jl:158-160,174-176) must match."""
+    rng = np.random.default_rng(5)
+    H = ldpc.codes.parity_check_csc(96, 6, 3)
+    syn = rng.integers(0, 2, (70, 48)).astype(np.uint8)
+    assert_parity(ldpc, H, per, 12, syn)
+
+
+@pytest.mark.parametrize("wpt", [4, 8, 16])
+def test_waves_per_tile_variants(ldpc, gpu, wpt):
+    H = ldpc.codes.parity_check_csc(1008, 6, 3)
+    e = ldpc.codes.random_errors(1008, 200, 0.04, seed=77)
+    assert_parity(ldpc, H, 0.04, 40, ldpc.codes.syndromes_of(H, e), waves_per_tile=wpt)
+
+
+def test_irregular_graphs_with_empty_and_heavy_nodes(ldpc, gpu):
+    """Degree-0 checks/bits, a degree-40 check (> widest register bucket) and a degree-20 bit."""
+    rng = np.random.default_rng(9)
+    s, n = 60, 120
+    H = (rng.random((s, n)) < 0.05).astype(np.uint8)
+    H[3, :] = 0
+    H[:, 7] = 0
+    H[5, :40] = 1          # check of degree >= 40 -> O(deg^2) path
+    H[10:30, 50] = 1       # bit of degree >= 20  -> O(deg^2) path
+    e = (rng.random((150, n)) < 0.03).astype(np.uint8)
+    syn = (e.astype(np.int64) @ H.T.astype(np.int64) % 2).astype(np.uint8)
+    syn[100:] = rng.integers(0, 2, (50, s))
+    assert_parity(ldpc, H, 0.03, 25, syn)
+
+
+def test_mid_degree_buckets(ldpc, gpu):
+    """Degrees 9..16 and 17..32 select the wider register buckets."""
+    for (n, wr, wc, per) in [(480, 12, 6, 0.01), (960, 24, 5, 0.004)]:
+        H = ldpc.codes.parity_check_csc(n, wr, wc)
+        e = ldpc.codes.random_errors(n, 130, per, seed=n)
+        assert_parity(ldpc, H, per, 30, ldpc.codes.syndromes_of(H, e))
+
+
+def test_bb72_code(ldpc, gpu):
+    """BASELINE configs[4] BP stage: [[72,12,6]] bivariate bicycle H_X, per=0.005."""
+    HX, _ = ldpc.codes.bivariate_bicycle_72_12_6()
+    e = ldpc.codes.random_errors(72, 5000, 0.005, seed=72)
+    assert_parity(ldpc, HX, 0.005, 50, ldpc.codes.syndromes_of(HX, e))
+
+
+def test_non_binary_syndrome_entries(ldpc, gpu):
+    """Entries 2/3 keep their parity for the sign and can never converge (:136,:181)."""
+    H = ldpc.codes.parity_check_csc(96, 6, 3)
+    syn = np.zeros((66, 48), dtype=np.uint8)
+    syn[1, 0] = 2
+    syn[2, 5] = 3
+    syn[65, 47] = 2
+    err, conv, its = assert_parity(ldpc, H, 0.02, 9, syn)
+    assert conv[0] and not conv[1] and not conv[2] and not conv[65]
+    assert its[1] == 9
+
+
+def test_max_iters_zero(ldpc, gpu):
+    H = ldpc.codes.parity_check_csc(96, 6, 3)
+    dec = ldpc.BeliefPropagationDecoder(H, 0.02, 0)
+    err, conv, llr, its = dec.decode_batch_host(np.zeros((5, 48), dtype=np.uint8), want_llr=True, want_iters=True)
+    assert not err.any() and not conv.any() and not llr.any() and not its.any()
+
+
+def test_c3_code_n16384_small_batch(ldpc, gpu):
+    """BASELINE configs[2] code (n=16384, m=8192, row weight 8) at oracle-sized batch:
+    realistic (per=0.02) and full-50 (per=0.10) workloads."""
+    H = ldpc.codes.parity_check_csc(16384, 8, 4)
+    for per, B in [(0.02, 96), (0.10, 70)]:
+        e = ldpc.codes.random_errors(16384, B, per, seed=int(per * 100))
+        err, conv, its = assert_parity(ldpc, H, per, 50, ldpc.codes.syndromes_of(H, e))
+        if per == 0.10:
+            assert not conv.any() and (its == 50).all()
+
+
+def test_device_resident_entry(ldpc, gpu):
+    """ldpc_bp_decode_batch_device with HBM-resident tensors on a non-default stream."""
+    import torch
+
+    H = ldpc.codes.parity_check_csc(1008, 6, 3)
+    e = ldpc.codes.random_errors(1008, 700, 0.02, seed=3)
+    syn = ldpc.codes.syndromes_of(H, e)
+    dec = ldpc.BeliefPropagationDecoder(H, 0.02, 50)
+    dev = torch.device("cuda:0")
+    st = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(st):
+        d_syn = torch.from_numpy(syn).to(dev)
+        d_err = torch.empty((700, 1008), dtype=torch.uint8, device=dev)
+        d_conv = torch.empty(700, dtype=torch.uint8, device=dev)
+        d_llr = torch.empty((700, 1008), dtype=torch.float64, device=dev)
+        d_it = torch.empty(700, dtype=torch.int32, device=dev)
+        dec.decode_batch_device(d_syn, d_err, d_conv, d_llr, d_it)
+    st.synchronize()
+    oc = BPOracle(csc=(H.indptr, H.indices), shape=H.shape, per=0.02, max_iters=50)
+    oerr, oconv, ollr, oits = oc.batchdecode(syn)
+    assert np.array_equal(d_err.cpu().numpy(), oerr)
+    assert np.array_equal(d_conv.cpu().numpy(), oconv)
+    assert np.array_equal(d_it.cpu().numpy(), oits)
+    assert np.max(np.abs(d_llr.cpu().numpy() - ollr)) <= LLR_TOL
+    sweep_ms, total_ms, sum_iters = dec.last_timing()
+    assert sum_iters == int(oits.sum()) and 0 < sweep_ms <= total_ms

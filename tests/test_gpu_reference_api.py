@@ -1,0 +1,142 @@
+"""The reference's own tests for the BP path, re-run against the MI355X decoder
+through the host mirror of its API (``!`` spelled ``_``):
+
+    test/test_bp_decoder.jl:1-52      exact recovery, batch LER, sequential LER
+    src/decoders/belief_propagation.jl doctests (:76-82, :104-119, :204-218)
+    test/test_bpots.jl:155-167        any AbstractVector is accepted (BitVector there)
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _H(ldpc):
+    return ldpc.parity_check_matrix(1000, 10, 9)   # test_bp_decoder.jl:7
+
+
+def test_bp_decoder_single(ldpc, gpu):
+    """test_bp_decoder.jl:6-16 -- guess == err."""
+    rng = np.random.default_rng(1)
+    H = _H(ldpc)
+    per = 0.01
+    err = rng.random(1000) < per
+    syn = (H.astype(np.int64) @ err.astype(np.int64)) % 2      # Vector{Int}
+    bpd = ldpc.BeliefPropagationDecoder(H, per, 100)
+    guess, success = ldpc.decode_(bpd, syn)
+    assert success is True
+    assert guess is bpd.scratch.err and guess.dtype == np.float64   # alias of the scratch (:187)
+    assert np.array_equal(guess, err.astype(np.float64))
+
+
+def test_bp_decoder_batch(ldpc, gpu):
+    """test_bp_decoder.jl:19-30 -- batchdecode! into zero(errors) (a BitMatrix), LER < 0.005."""
+    rng = np.random.default_rng(2)
+    H = _H(ldpc)
+    per, num_trials = 0.01, 100
+    errors = np.asfortranarray(rng.random((1000, num_trials)) < per)
+    syndromes = (H.astype(np.int64) @ errors.astype(np.int64)) % 2   # Matrix{Int}, n x B
+    bpd = ldpc.BeliefPropagationDecoder(H, per, 100)
+    out = np.zeros_like(errors)
+    guesses, successes = ldpc.batchdecode_(bpd, syndromes, out)
+    assert guesses is out and successes.dtype == np.bool_ and successes.shape == (num_trials,)
+    actual = [np.array_equal(guesses[:, i], errors[:, i]) for i in range(num_trials)]
+    ler = (num_trials - sum(actual)) / num_trials
+    assert ler < 0.005
+    assert successes.all()
+
+
+def test_ldpcdecoder_sequential(ldpc, gpu):
+    """test_bp_decoder.jl:32-43 -- many decode! calls on one decoder (200 here), LER < 0.001."""
+    rng = np.random.default_rng(3)
+    H = _H(ldpc)
+    dec = ldpc.BeliefPropagationDecoder(H, 0.01, 100)
+    count = 0
+    trials = 200
+    for _ in range(trials):
+        error = rng.random(1000) < 0.01
+        syndrome = (H.astype(np.int64) @ error.astype(np.int64)) % 2
+        guess, success = ldpc.decode_(dec, syndrome)
+        count += np.array_equal(error, guess.astype(bool))
+    assert 1 - count / trials < 0.001
+
+
+def test_reset_and_doctests(ldpc, gpu):
+    """belief_propagation.jl:76-82 (reset! callable, returns the decoder), :204-218 (10 samples)."""
+    rng = np.random.default_rng(42)
+    H = _H(ldpc)
+    decoder = ldpc.BeliefPropagationDecoder(H, 0.01, 100)
+    assert ldpc.reset_(decoder) is decoder
+    errors = rng.random((1000, 10)) < 0.01
+    syndromes = (H.astype(np.int64) @ errors.astype(np.int64)) % 2
+    guesses, successes = ldpc.batchdecode_(decoder, syndromes, np.zeros_like(errors))
+    assert guesses.shape == (1000, 10) and len(successes) == 10
+    # the scratch is left holding the last column (the reference decodes columns in order)
+    assert np.array_equal(decoder.scratch.err.astype(bool), guesses[:, -1])
+    assert np.all(np.isfinite(decoder.scratch.log_probabs))
+
+
+@pytest.mark.parametrize("kind", ["bool", "int64", "float64", "uint8", "view"])
+def test_syndrome_element_types(ldpc, gpu, kind):
+    """decode! takes any AbstractVector (Bool, Int, Float 0.0/1.0, views)."""
+    rng = np.random.default_rng(4)
+    H = ldpc.parity_check_matrix(504, 6, 3)
+    dec = ldpc.BeliefPropagationDecoder(H, 0.02, 50)
+    e = rng.random(504) < 0.02
+    syn = (H.astype(np.int64) @ e.astype(np.int64)) % 2
+    ref, ok_ref = ldpc.decode_(dec, syn)
+    ref = ref.copy()
+    if kind == "view":
+        big = np.zeros((2, syn.size * 2), dtype=np.int64)
+        big[1, ::2] = syn
+        arg = big[1, ::2]
+    else:
+        arg = syn.astype(kind)
+    got, ok = ldpc.decode_(dec, arg)
+    assert ok == ok_ref and np.array_equal(got, ref)
+
+
+def test_errors_eltype_and_success_vector(ldpc, gpu):
+    """errors may be Bool or Int (test_bpots.jl:145 uses Matrix{Int}); a supplied success vector is filled."""
+    rng = np.random.default_rng(5)
+    H = ldpc.parity_check_matrix(504, 6, 3)
+    dec = ldpc.BeliefPropagationDecoder(H, 0.02, 50)
+    E = rng.random((504, 33)) < 0.02
+    S = (H.astype(np.int64) @ E.astype(np.int64)) % 2
+    out_i = np.zeros((504, 33), dtype=np.int64)
+    succ = np.zeros(33, dtype=np.bool_)
+    g, sc = ldpc.batchdecode_(dec, S, out_i, succ)
+    assert g is out_i and sc is succ and succ.all()
+    assert np.array_equal(out_i.astype(bool), E)
+    out_f = np.zeros((504, 33), dtype=np.float64)
+    ldpc.batchdecode_(dec, S.astype(bool), out_f)
+    assert np.array_equal(out_f, out_i.astype(np.float64))
+
+
+def test_batch_size_mismatch_is_an_assertion(ldpc, gpu):
+    """@assert at belief_propagation.jl:221-222."""
+    H = ldpc.parity_check_matrix(96, 6, 3)
+    dec = ldpc.BeliefPropagationDecoder(H, 0.02, 5)
+    with pytest.raises(AssertionError):
+        ldpc.batchdecode_(dec, np.zeros((48, 4), dtype=np.int64), np.zeros((96, 5), dtype=bool))
+    with pytest.raises(AssertionError):
+        ldpc.batchdecode_(dec, np.zeros((48, 4), dtype=np.int64), np.zeros((96, 4), dtype=bool),
+                          np.zeros(3, dtype=bool))
+
+
+def test_empty_batch(ldpc, gpu):
+    H = ldpc.parity_check_matrix(96, 6, 3)
+    dec = ldpc.BeliefPropagationDecoder(H, 0.02, 5)
+    g, s = ldpc.batchdecode_(dec, np.zeros((48, 0), dtype=np.int64), np.zeros((96, 0), dtype=bool))
+    assert g.shape == (96, 0) and s.shape == (0,)
+
+
+def test_invalid_csc_is_rejected(ldpc, gpu):
+    import ctypes
+
+    L = ldpc._capi.lib()
+    colptr = np.array([0, 2, 2], dtype=np.int64)
+    rowval = np.array([1, 0], dtype=np.int64)   # not ascending inside the column
+    h = ctypes.c_void_p()
+    st = L.ldpc_bp_create(2, 2, 2, colptr.ctypes.data, rowval.ctypes.data, 0.1, 5, None, ctypes.byref(h))
+    assert st == 1 and b"ascending" in L.ldpc_last_error()
