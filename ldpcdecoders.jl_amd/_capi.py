@@ -79,6 +79,20 @@ def build(force: bool = False) -> str:
 _LIB = None
 
 
+def _one_hip_runtime() -> None:
+    """Keep ONE HIP runtime in the process.  PyTorch-ROCm bundles its own libamdhip64.so.7;
+    the library links against the same SONAME, so whichever copy is mapped first serves both.
+    When torch is installed it must be that copy, or torch tensors / streams handed to
+    ldpc_bp_decode_batch_device would belong to a different runtime instance.  Without torch
+    (plain ctypes or the Julia shim) the system ROCm runtime is used."""
+    if os.environ.get("LDPC_MI355X_NO_TORCH_PRELOAD"):
+        return
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
 def lib() -> ctypes.CDLL:
     """Load the HIP library; raises (never falls back) if it is not built."""
     global _LIB
@@ -87,6 +101,7 @@ def lib() -> ctypes.CDLL:
     if not os.path.exists(LIB_PATH):
         raise LdpcError(2, f"{LIB_PATH} is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "or `make -C ldpcdecoders.jl_amd/csrc`. There is no CPU fallback.")
+    _one_hip_runtime()
     L = ctypes.CDLL(LIB_PATH)
     vp, i64, i32, f64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_double
     L.ldpc_abi_version.restype = i32
