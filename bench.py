@@ -182,6 +182,7 @@ def main():
                 "alg_bytes_per_launch": alg_bytes,
                 "kernel_ms": sweep_ms,
                 "pack_sweep_unpack_ms": total_ms,
+                "phase_share_check_var_conv": [round(t / max(sum(dec.phase_ticks(0)), 1), 4) for t in dec.phase_ticks(0)],
             },
         }
         if not args.no_cpu_baseline and world == 1:

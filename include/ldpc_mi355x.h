@@ -146,6 +146,10 @@ ldpc_status ldpc_bp_last_timing(ldpc_bp_decoder *dec, double *sweep_ms, double *
 ldpc_status ldpc_bp_call_timing(ldpc_bp_decoder *dec, int32_t calls_back, double *sweep_ms,
                                 double *total_ms, int64_t *sum_iters);
 
+/* Diagnostics: 100 MHz ticks spent in {check sweep, variable sweep, convergence test}
+ * of that call, summed over workgroups (one sampling wave each). */
+ldpc_status ldpc_bp_call_phase_ticks(ldpc_bp_decoder *dec, int32_t calls_back, uint64_t ticks[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = (
     "ldpc_bp_decode_batch_device",
     "ldpc_bp_last_timing",
     "ldpc_bp_call_timing",
+    "ldpc_bp_call_phase_ticks",
 )
 
 
@@ -122,6 +123,8 @@ def lib() -> ctypes.CDLL:
     L.ldpc_bp_last_timing.argtypes = [vp, ctypes.POINTER(f64), ctypes.POINTER(f64), ctypes.POINTER(i64)]
     L.ldpc_bp_call_timing.restype = i32
     L.ldpc_bp_call_timing.argtypes = [vp, i32, ctypes.POINTER(f64), ctypes.POINTER(f64), ctypes.POINTER(i64)]
+    L.ldpc_bp_call_phase_ticks.restype = i32
+    L.ldpc_bp_call_phase_ticks.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_uint64 * 3)]
     _LIB = L
     return L
 

@@ -50,6 +50,8 @@ struct BPParams {
     unsigned char *conv;  // [batch]
     unsigned int *queue;  // tile queue head
     u64 *sum_iters;       // accumulated iterations executed
+    u64 *phase_ticks;     // [3] 100 MHz ticks spent in check sweep / variable sweep / convergence test,
+                          //     summed over workgroups (wave 0 of each; diagnostics for DESIGN.md)
 };
 
 __device__ __forceinline__ u64 wave_or(u64 v)
@@ -206,10 +208,12 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
         int my_iters = 0;
         int my_conv = 0;
         int it = 0;
+        u64 tk_check = 0, tk_var = 0, tk_conv = 0;
 
         while (active != 0 && it < p.max_iters) {
             ++it;
             const bool first = (it == 1);
+            const u64 t0 = wall_clock64();
             // ---- check-node sweep  (:135-150)
             for (int i = w; i < s; i += W) {
                 const int e0 = row_ptr[i];
@@ -218,6 +222,7 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
                 check_update<DC>(Mt + (size_t)e0 * kTile, deg, sigma, first, r);
             }
             __syncthreads();
+            const u64 t1 = wall_clock64();
             // ---- variable-node sweep  (:152-178)
             for (int j = w; j < n; j += W) {
                 const int c0 = col_ptr[j];
@@ -235,6 +240,7 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
                 }
             }
             __syncthreads();
+            const u64 t2 = wall_clock64();
             // ---- convergence test (:180-184): lane = check, words = 64 syndromes
             u64 mism = 0;
             for (int i = w * 64 + lane; i < s; i += W * 64) {
@@ -252,6 +258,8 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
             const u64 newly = active & ~U;
             if ((newly >> lane) & 1ull) { my_iters = it; my_conv = 1; }
             active &= U;
+            const u64 t3 = wall_clock64();
+            tk_check += t1 - t0; tk_var += t2 - t1; tk_conv += t3 - t2;
         }
         if ((active >> lane) & 1ull) { my_iters = it; my_conv = 0; }
         if (w == 0) {
@@ -265,7 +273,12 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
             int tot = my_iters;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
-            if (lane == 0) atomicAdd(p.sum_iters, (u64)tot);
+            if (lane == 0) {
+                atomicAdd(p.sum_iters, (u64)tot);
+                atomicAdd(&p.phase_ticks[0], tk_check);
+                atomicAdd(&p.phase_ticks[1], tk_var);
+                atomicAdd(&p.phase_ticks[2], tk_conv);
+            }
         }
         __syncthreads();
     }

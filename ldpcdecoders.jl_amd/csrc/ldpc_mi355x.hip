@@ -366,6 +366,7 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
     p.conv = d_conv;
     p.queue = (unsigned int *)ctrl;
     p.sum_iters = (u64 *)(ctrl + 8);
+    p.phase_ticks = (u64 *)(ctrl + 16);
     bp_kernel_t kfn = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, d->threads);
     HIP_TRY(hipEventRecord(ev[1], stream));
     hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3((unsigned)d->threads), 0, stream, p,
@@ -442,6 +443,20 @@ ldpc_status ldpc_bp_call_timing(ldpc_bp_decoder *d, int32_t calls_back, double *
         HIP_TRY(hipMemcpy(&v, (char *)d->ctrl.p + 64 * slot + 8, sizeof v, hipMemcpyDeviceToHost));
         *sum_iters = (int64_t)v;
     }
+    return LDPC_OK;
+}
+
+ldpc_status ldpc_bp_call_phase_ticks(ldpc_bp_decoder *d, int32_t calls_back, uint64_t ticks[3])
+{
+    if (!d || !ticks) return fail(LDPC_ERR_INVALID_ARGUMENT, "NULL argument");
+    ticks[0] = ticks[1] = ticks[2] = 0;
+    if (calls_back < 0 || calls_back >= ldpc_bp_decoder::kRing || (uint64_t)calls_back >= d->ncalls)
+        return fail(LDPC_ERR_INVALID_ARGUMENT, "calls_back outside the timing ring");
+    const int slot = (int)((d->ncalls - 1 - (uint64_t)calls_back) % ldpc_bp_decoder::kRing);
+    if (!d->timed[slot]) return LDPC_OK;
+    HIP_TRY(hipSetDevice(d->device));
+    HIP_TRY(hipEventSynchronize(d->ev[slot][3]));
+    HIP_TRY(hipMemcpy(ticks, (char *)d->ctrl.p + 64 * slot + 16, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return LDPC_OK;
 }
 

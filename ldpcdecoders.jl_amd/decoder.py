@@ -146,6 +146,12 @@ class BeliefPropagationDecoder(AbstractDecoder):
                                                     ctypes.byref(c)))
         return a.value, b.value, c.value
 
+    def phase_ticks(self, calls_back: int = 0) -> Tuple[int, int, int]:
+        """Diagnostics: 100 MHz ticks in (check sweep, variable sweep, convergence test), summed over workgroups."""
+        t = (ctypes.c_uint64 * 3)()
+        _capi.check(_capi.lib().ldpc_bp_call_phase_ticks(self._h, calls_back, ctypes.byref(t)))
+        return int(t[0]), int(t[1]), int(t[2])
+
     # -- raw ABI calls ------------------------------------------------------
     def decode_batch_host(self, syn_bs: np.ndarray, want_llr: bool = False, want_iters: bool = False):
         """syn_bs: [B][s] uint8 C-contiguous.  Returns (errors [B][n] u8, converged [B] u8, llr|None, iters|None)."""
