@@ -68,47 +68,76 @@ __device__ __forceinline__ u64 wave_or(u64 v)
 // ---------------------------------------------------------------------------
 // check-node update for one check and 64 syndromes (one wave).
 // belief_propagation.jl:136-149.  `M` points at the check's first row + lane.
+// D is the EXACT degree: straight-line code, all D row loads issued back to back.
 // ---------------------------------------------------------------------------
-template <int DC>
-__device__ __forceinline__ void check_update(double *M, int deg, double sigma, bool first, double r)
+template <int D, bool FIRST>
+__device__ __forceinline__ void check_update_exact(double *M, double sigma, double r)
 {
-    if (deg <= DC) {
-        double a[DC], pre[DC];
+    double a[D], pre[D];
+    if (FIRST) {
+        const double a0 = 2.0 / (1.0 + r) - 1.0;          // every bit->check message is still r (:129)
 #pragma unroll
-        for (int k = 0; k < DC; ++k)
-            if (k < deg) {
-                double m = first ? r : M[(size_t)k * kTile];
-                a[k] = 2.0 / (1.0 + m) - 1.0;            // :140 / :148 (same value both times)
-            }
-        double P = sigma;                                 // :136
-#pragma unroll
-        for (int k = 0; k < DC; ++k)
-            if (k < deg) { pre[k] = P; P = P * a[k]; }    // :139-140
-        double S = 1.0;                                   // :143
-#pragma unroll
-        for (int k = DC - 1; k >= 0; --k)
-            if (k < deg) {
-                double t = pre[k] * S;                    // :146
-                M[(size_t)k * kTile] = (1.0 - t) / (1.0 + t);  // :147
-                S = S * a[k];                             // :148
-            }
+        for (int k = 0; k < D; ++k) a[k] = a0;
     } else {
-        // Rare high-degree row: O(deg^2) recomputation of the prefix, still in place
-        // (position k is overwritten only after every prefix that needs it was formed).
-        double S = 1.0;
-        for (int k = deg - 1; k >= 0; --k) {
-            double P = sigma;
-            for (int q = 0; q < k; ++q) {
-                double m = first ? r : M[(size_t)q * kTile];
-                P = P * (2.0 / (1.0 + m) - 1.0);
-            }
-            double mk = first ? r : M[(size_t)k * kTile];
-            double ak = 2.0 / (1.0 + mk) - 1.0;
-            double t = P * S;
-            M[(size_t)k * kTile] = (1.0 - t) / (1.0 + t);
-            S = S * ak;
-        }
+        double m[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) m[k] = M[(size_t)k * kTile];
+#pragma unroll
+        for (int k = 0; k < D; ++k) a[k] = 2.0 / (1.0 + m[k]) - 1.0;   // :140 / :148 (same value both times)
     }
+    double P = sigma;                                     // :136
+#pragma unroll
+    for (int k = 0; k < D; ++k) { pre[k] = P; P = P * a[k]; }          // :139-140
+    double S = 1.0;                                       // :143
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) {
+        const double t = pre[k] * S;                      // :146
+        M[(size_t)k * kTile] = (1.0 - t) / (1.0 + t);     // :147
+        S = S * a[k];                                     // :148
+    }
+}
+
+// Any degree, O(deg^2) recomputation of the prefix, still in place (position k is
+// overwritten only after every prefix that needs it was formed).  Used above the widest
+// straight-line variant.
+template <bool FIRST>
+__device__ __noinline__ void check_update_any(double *M, int deg, double sigma, double r)
+{
+    double S = 1.0;
+    for (int k = deg - 1; k >= 0; --k) {
+        double P = sigma;
+        for (int q = 0; q < k; ++q) {
+            const double m = FIRST ? r : M[(size_t)q * kTile];
+            P = P * (2.0 / (1.0 + m) - 1.0);
+        }
+        const double mk = FIRST ? r : M[(size_t)k * kTile];
+        const double ak = 2.0 / (1.0 + mk) - 1.0;
+        const double t = P * S;
+        M[(size_t)k * kTile] = (1.0 - t) / (1.0 + t);
+        S = S * ak;
+    }
+}
+
+// wave-uniform dispatch on the degree: deg in [LO, HI] -> check_update_exact<deg>
+template <int LO, int HI, bool FIRST>
+__device__ __forceinline__ void check_dispatch(double *M, int deg, double sigma, double r)
+{
+    if constexpr (LO == HI) {
+        check_update_exact<LO, FIRST>(M, sigma, r);
+    } else {
+        constexpr int MID = (LO + HI) / 2;
+        if (deg <= MID) check_dispatch<LO, MID, FIRST>(M, deg, sigma, r);
+        else check_dispatch<MID + 1, HI, FIRST>(M, deg, sigma, r);
+    }
+}
+
+template <int DC, bool FIRST>
+__device__ __forceinline__ void check_update(double *M, int deg, double sigma, double r)
+{
+    if (deg == DC) check_update_exact<DC, FIRST>(M, sigma, r);   // the regular-code case first
+    else if (deg == 0) return;
+    else if (deg < DC) check_dispatch<1, DC - 1, FIRST>(M, deg, sigma, r);
+    else check_update_any<FIRST>(M, deg, sigma, r);
 }
 
 // ---------------------------------------------------------------------------
@@ -116,54 +145,74 @@ __device__ __forceinline__ void check_update(double *M, int deg, double sigma, b
 // belief_propagation.jl:153-177.  Returns the posterior odds T.
 // `Mt` = tile message base + lane; pos = CSR positions of the bit's edges.
 // ---------------------------------------------------------------------------
-template <int DV>
-__device__ __forceinline__ double bit_update(double *Mt, const int *pos, int deg, double r)
+template <int D>
+__device__ __forceinline__ double bit_update_exact(double *Mt, const int *__restrict__ pos, double r)
 {
+    double c[D], pre[D];
+    size_t at[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) at[k] = (size_t)pos[k] * kTile;
+#pragma unroll
+    for (int k = 0; k < D; ++k) c[k] = Mt[at[k]];
     double F = r;                                         // :153
-    if (deg <= DV) {
-        double c[DV], pre[DV];
-        size_t at[DV];
 #pragma unroll
-        for (int k = 0; k < DV; ++k)
-            if (k < deg) {
-                at[k] = (size_t)pos[k] * kTile;
-                c[k] = Mt[at[k]];
-            }
+    for (int k = 0; k < D; ++k) {
+        pre[k] = F;                                       // :156
+        F = F * c[k];                                     // :157
+        if (F != F) F = 1.0;                              // :158-160
+    }
+    double G = 1.0;                                       // :170
 #pragma unroll
-        for (int k = 0; k < DV; ++k)
-            if (k < deg) {
-                pre[k] = F;                               // :156
-                F = F * c[k];                             // :157
-                if (F != F) F = 1.0;                      // :158-160
-            }
-        double G = 1.0;                                   // :170
-#pragma unroll
-        for (int k = DV - 1; k >= 0; --k)
-            if (k < deg) {
-                Mt[at[k]] = pre[k] * G;                   // :172 (unguarded, may be NaN)
-                G = G * c[k];                             // :173
-                if (G != G) G = 1.0;                      // :174-176
-            }
-    } else {
-        for (int k = 0; k < deg; ++k) {
-            F = F * Mt[(size_t)pos[k] * kTile];
-            if (F != F) F = 1.0;
-        }
-        double G = 1.0;
-        for (int k = deg - 1; k >= 0; --k) {
-            double Pk = r;
-            for (int q = 0; q < k; ++q) {
-                Pk = Pk * Mt[(size_t)pos[q] * kTile];
-                if (Pk != Pk) Pk = 1.0;
-            }
-            size_t a = (size_t)pos[k] * kTile;
-            double ck = Mt[a];
-            Mt[a] = Pk * G;
-            G = G * ck;
-            if (G != G) G = 1.0;
-        }
+    for (int k = D - 1; k >= 0; --k) {
+        Mt[at[k]] = pre[k] * G;                           // :172 (unguarded, may be NaN)
+        G = G * c[k];                                     // :173
+        if (G != G) G = 1.0;                              // :174-176
     }
     return F;
+}
+
+__device__ __noinline__ double bit_update_any(double *Mt, const int *__restrict__ pos, int deg, double r)
+{
+    double F = r;
+    for (int k = 0; k < deg; ++k) {
+        F = F * Mt[(size_t)pos[k] * kTile];
+        if (F != F) F = 1.0;
+    }
+    double G = 1.0;
+    for (int k = deg - 1; k >= 0; --k) {
+        double Pk = r;
+        for (int q = 0; q < k; ++q) {
+            Pk = Pk * Mt[(size_t)pos[q] * kTile];
+            if (Pk != Pk) Pk = 1.0;
+        }
+        const size_t a = (size_t)pos[k] * kTile;
+        const double ck = Mt[a];
+        Mt[a] = Pk * G;
+        G = G * ck;
+        if (G != G) G = 1.0;
+    }
+    return F;
+}
+
+template <int LO, int HI>
+__device__ __forceinline__ double bit_dispatch(double *Mt, const int *__restrict__ pos, int deg, double r)
+{
+    if constexpr (LO == HI) {
+        return bit_update_exact<LO>(Mt, pos, r);
+    } else {
+        constexpr int MID = (LO + HI) / 2;
+        if (deg <= MID) return bit_dispatch<LO, MID>(Mt, pos, deg, r);
+        return bit_dispatch<MID + 1, HI>(Mt, pos, deg, r);
+    }
+}
+
+template <int DV>
+__device__ __forceinline__ double bit_update(double *Mt, const int *__restrict__ pos, int deg, double r)
+{
+    if (deg == DV) return bit_update_exact<DV>(Mt, pos, r);
+    if (deg == 0) return r;
+    if (deg < DV) return bit_dispatch<1, DV - 1>(Mt, pos, deg, r);
+    return bit_update_any(Mt, pos, deg, r);
 }
 
 // ---------------------------------------------------------------------------
@@ -186,7 +235,9 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
     __shared__ int sh_tile;
     __shared__ u64 sh_mism[THREADS / 64];
     const int lane = threadIdx.x & 63;
-    const int w = threadIdx.x >> 6;
+    // the wave index is wave-uniform; telling the compiler so turns every per-node index read
+    // into a scalar load and every degree test into a scalar branch
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int W = THREADS / 64;
     const int s = p.s, n = p.n;
     const double r = p.r;
@@ -219,7 +270,8 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
                 const int e0 = row_ptr[i];
                 const int deg = row_ptr[i + 1] - e0;
                 const double sigma = ((syn[i] >> lane) & 1ull) ? -1.0 : 1.0;  // (-1)^syndrome[i] :136
-                check_update<DC>(Mt + (size_t)e0 * kTile, deg, sigma, first, r);
+                if (first) check_update<DC, true>(Mt + (size_t)e0 * kTile, deg, sigma, r);
+                else check_update<DC, false>(Mt + (size_t)e0 * kTile, deg, sigma, r);
             }
             __syncthreads();
             const u64 t1 = wall_clock64();
