@@ -1,0 +1,141 @@
+# LDPCDecodersMI355X.jl -- Julia shim over libldpc_mi355x.so (include/ldpc_mi355x.h).
+#
+# NOT EXECUTED in this repository's pipeline: no Julia runtime exists in the build image
+# or on the GPU box.  The same C ABI is exercised from Python ctypes
+# (ldpcdecoders.jl_amd/_capi.py, decoder.py) and by the test-suite; this file is the
+# binding a maintainer of QuantumSavory/LDPCDecoders.jl would add.  It mirrors
+#
+#   BeliefPropagationDecoder(H, per, max_iters)   src/decoders/belief_propagation.jl:61-67
+#   reset!(decoder)                               :83-91
+#   decode!(decoder, syndrome)                    :121-188
+#   batchdecode!(decoder, syndromes, errors[, success])   :220-231, abstract_decoder.jl:44-48
+#
+# so that `MI355XBeliefPropagationDecoder <: LDPCDecoders.AbstractDecoder` is a drop-in
+# wherever a BeliefPropagationDecoder is used, including inside BeliefPropagationOSDDecoder
+# (which reads `decoder.scratch.log_probabs`, belief_propagation_osd.jl:52).
+module LDPCDecodersMI355X
+
+using SparseArrays
+import LDPCDecoders
+import LDPCDecoders: AbstractDecoder, decode!, batchdecode!, reset!
+
+export MI355XBeliefPropagationDecoder
+
+const libldpc = get(ENV, "LDPC_MI355X_LIB", "libldpc_mi355x.so")
+
+const LDPC_OK = Cint(0)
+
+struct LDPCMI355XError <: Exception
+    status::Cint
+    msg::String
+end
+
+function check(status::Cint)
+    status == LDPC_OK && return nothing
+    msg = unsafe_string(ccall((:ldpc_last_error, libldpc), Cstring, ()))
+    # shape errors are assertion failures in the reference (belief_propagation.jl:221-222)
+    status == 1 && throw(ArgumentError(msg))
+    throw(LDPCMI355XError(status, msg))
+end
+
+"Host mirrors of the two scratch fields other code reads (belief_propagation.jl:3-18)."
+struct MI355XScratch
+    log_probabs::Vector{Float64}
+    channel_probs::Vector{Float64}
+    err::Vector{Float64}
+end
+
+mutable struct MI355XBeliefPropagationDecoder <: AbstractDecoder
+    per::Float64
+    max_iters::Int
+    s::Int
+    n::Int
+    sparse_H::SparseMatrixCSC{Bool,Int}
+    sparse_HT::SparseMatrixCSC{Bool,Int}
+    scratch::MI355XScratch
+    handle::Ptr{Cvoid}
+    # reusable staging (column-major Julia matrices already have the ABI's [B][s] image)
+    syn_u8::Vector{UInt8}
+    err_u8::Vector{UInt8}
+    conv_u8::Vector{UInt8}
+end
+
+function MI355XBeliefPropagationDecoder(H, per::Float64, max_iters::Int; device::Integer=-1)
+    s, n = size(H)
+    sparse_H = SparseMatrixCSC{Bool,Int}(sparse(H))          # :63
+    sparse_HT = SparseMatrixCSC{Bool,Int}(sparse(H'))        # :64
+    colptr = Int64.(sparse_H.colptr .- 1)                    # zero-based for the ABI
+    rowval = Int64.(rowvals(sparse_H) .- 1)
+    opts = zeros(Int32, 16); opts[1] = Int32(device)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:ldpc_bp_create, libldpc), Cint,
+                (Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Float64, Int64, Ptr{Int32}, Ptr{Ptr{Cvoid}}),
+                s, n, length(rowval), colptr, rowval, per, max_iters, opts, h))
+    d = MI355XBeliefPropagationDecoder(per, max_iters, s, n, sparse_H, sparse_HT,
+            MI355XScratch(zeros(n), fill(per, n), zeros(n)), h[], UInt8[], UInt8[], UInt8[])
+    finalizer(d) do x
+        x.handle != C_NULL && ccall((:ldpc_bp_destroy, libldpc), Cint, (Ptr{Cvoid},), x.handle)
+        x.handle = C_NULL
+    end
+    return d
+end
+
+"`(-1)^x` only needs the parity; anything but 0/1 must never match the convergence `==` (:136,:181)."
+@inline function syndrome_byte(x)::UInt8
+    v = Int(x)                      # InexactError for non-integral floats, like (-1)^2.5 -> DomainError
+    (v == 0 || v == 1) ? UInt8(v) : UInt8(2 + (v & 1))
+end
+
+function reset!(d::MI355XBeliefPropagationDecoder)            # :83-91 (device scratch is reset per call)
+    d.scratch.log_probabs .= 0.0
+    d.scratch.channel_probs .= d.per
+    d.scratch.err .= 0.0
+    d
+end
+
+function decode!(d::MI355XBeliefPropagationDecoder, syndrome::AbstractVector)   # :121-188
+    length(syndrome) == d.s || throw(BoundsError(syndrome, d.s))
+    reset!(d)
+    resize!(d.syn_u8, d.s); resize!(d.err_u8, d.n); resize!(d.conv_u8, 1)
+    @inbounds for i in 1:d.s
+        d.syn_u8[i] = syndrome_byte(syndrome[i])
+    end
+    check(ccall((:ldpc_bp_decode_batch, libldpc), Cint,
+                (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{UInt8}, Ptr{UInt8}, Ptr{Float64}, Ptr{Int32}),
+                d.handle, 1, d.syn_u8, d.err_u8, d.conv_u8, d.scratch.log_probabs, C_NULL))
+    @inbounds for j in 1:d.n
+        d.scratch.err[j] = d.err_u8[j]
+    end
+    return d.scratch.err, d.conv_u8[1] != 0                   # alias of the scratch, like :187
+end
+
+function batchdecode!(d::MI355XBeliefPropagationDecoder, syndromes::AbstractMatrix,
+                      errors::AbstractMatrix, success::AbstractVector{Bool})   # :220-231
+    @assert size(syndromes, 2) == size(errors, 2)             # :221
+    @assert size(syndromes, 2) == length(success)             # :222
+    B = size(syndromes, 2)
+    size(syndromes, 1) == d.s || throw(DimensionMismatch("syndromes has $(size(syndromes,1)) rows, decoder has $(d.s) checks"))
+    size(errors, 1) == d.n || throw(DimensionMismatch("errors has $(size(errors,1)) rows, decoder has $(d.n) bits"))
+    B == 0 && return errors, success
+    resize!(d.syn_u8, d.s * B); resize!(d.err_u8, d.n * B); resize!(d.conv_u8, B)
+    # BitMatrix / Matrix{Int} / views are normalised to the ABI's byte image; column i of the
+    # s x B matrix is the i-th contiguous run of s bytes
+    @inbounds for i in 1:B, r in 1:d.s
+        d.syn_u8[(i - 1) * d.s + r] = syndrome_byte(syndromes[r, i])
+    end
+    check(ccall((:ldpc_bp_decode_batch, libldpc), Cint,
+                (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{UInt8}, Ptr{UInt8}, Ptr{Float64}, Ptr{Int32}),
+                d.handle, B, d.syn_u8, d.err_u8, d.conv_u8, C_NULL, C_NULL))
+    @inbounds for i in 1:B
+        success[i] = d.conv_u8[i] != 0                        # :226
+        for j in 1:d.n
+            errors[j, i] = d.err_u8[(i - 1) * d.n + j]        # :227 (0/1 -> eltype(errors))
+        end
+    end
+    return errors, success                                    # :230
+end
+
+# 3-argument form: the generic method at abstract_decoder.jl:44-48 allocates `success`
+# and re-dispatches to the 4-argument method above; nothing to add.
+
+end # module
