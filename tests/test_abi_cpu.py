@@ -1,0 +1,77 @@
+"""The C-ABI library loads and exports every symbol include/ldpc_mi355x.h declares.
+No compute happens here (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import ldpcdecoders_jl_amd as ldpc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    txt = open(os.path.join(ROOT, "include", "ldpc_mi355x.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ldpc_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_every_declared_symbol_is_exported():
+    lib = ldpc._capi.lib()
+    declared = _declared_functions()
+    assert len(declared) >= 10
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/ldpc_mi355x.h but not exported"
+    assert sorted(ldpc._capi.EXPORTED_SYMBOLS) == declared
+    assert lib.ldpc_abi_version() == 1 and lib.ldpc_build_target() == b"gfx950"
+
+
+def test_code_object_is_gfx950_only():
+    data = open(ldpc._capi.LIB_PATH, "rb").read()
+    assert b"gfx950" in data
+    for other in (b"gfx942", b"gfx90a", b"sm_90", b"nvptx"):
+        assert other not in data
+
+
+def test_argument_validation_happens_before_any_device_work():
+    lib = ldpc._capi.lib()
+    h = ctypes.c_void_p()
+    colptr = np.array([0, 2, 2], dtype=np.int64)
+    bad = np.array([1, 0], dtype=np.int64)
+    st = lib.ldpc_bp_create(2, 2, 2, colptr.ctypes.data, bad.ctypes.data, 0.1, 5, None, ctypes.byref(h))
+    assert st == 1 and b"ascending" in lib.ldpc_last_error() and not h.value
+    st = lib.ldpc_bp_create(2, 2, 2, colptr.ctypes.data, np.array([0, 5], dtype=np.int64).ctypes.data,
+                            0.1, 5, None, ctypes.byref(h))
+    assert st == 1 and b"outside" in lib.ldpc_last_error()
+    st = lib.ldpc_bp_create(2, 2, 3, colptr.ctypes.data, bad.ctypes.data, 0.1, 5, None, ctypes.byref(h))
+    assert st == 1
+    assert lib.ldpc_bp_decode_batch(None, 1, None, None, None, None, None) == 1
+    assert lib.ldpc_bp_destroy(None) == 0
+
+
+def test_no_cpu_fallback():
+    """Without a gfx950 device the product path must fail loudly, never compute on the CPU."""
+    lib = ldpc._capi.lib()
+    if lib.ldpc_device_count() > 0:
+        pytest.skip("a GPU is present; the no-device behaviour is checked in the build container")
+    H = ldpc.parity_check_matrix(96, 6, 3)
+    with pytest.raises(ldpc.LdpcError) as ei:
+        ldpc.BeliefPropagationDecoder(H, 0.01, 10)
+    assert ei.value.status == 2
+    # nothing in the product package reaches for the oracle
+    pkg = os.path.join(ROOT, "ldpcdecoders.jl_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".jl")):
+                src = open(os.path.join(dp, f), errors="replace").read()
+                assert "import oracle" not in src and "from oracle" not in src and "bp_oracle" not in src, f
+
+
+def test_constructor_type_checks():
+    H = ldpc.parity_check_matrix(96, 6, 3)
+    with pytest.raises(TypeError):
+        ldpc.BeliefPropagationDecoder(H, 1, 10)        # per::Float64
+    with pytest.raises(TypeError):
+        ldpc.BeliefPropagationDecoder(H, 0.1, 10.0)    # max_iters::Int
