@@ -11,7 +11,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libldpc_mi355x.so")
+# LDPC_MI355X_LIB selects another build of the same library (tuning experiments, installed copies)
+LIB_PATH = os.environ.get("LDPC_MI355X_LIB") or os.path.join(CSRC, "libldpc_mi355x.so")
 
 LDPC_OK = 0
 STATUS_NAMES = {

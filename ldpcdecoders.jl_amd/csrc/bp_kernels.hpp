@@ -36,6 +36,34 @@ typedef unsigned long long u64;
 
 constexpr int kTile = 64;  // syndromes per tile == wavefront width on gfx950
 
+// Build-time tuning knobs (defaults = the shipped configuration; DESIGN.md lists what was measured)
+#ifndef LDPC_MIN_WAVES   // 2nd __launch_bounds__ argument (waves per SIMD); 0 = leave it to the compiler
+#define LDPC_MIN_WAVES 0
+#endif
+#ifndef LDPC_NT          // 1 = non-temporal loads/stores for the streamed edge messages
+#define LDPC_NT 0
+#endif
+#ifndef LDPC_NBV         // bits handled per wave per step of the variable sweep (1 or 2)
+#define LDPC_NBV 1
+#endif
+
+__device__ __forceinline__ double ldm(const double *p)
+{
+#if LDPC_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void stm(double *p, double v)
+{
+#if LDPC_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 struct BPParams {
     int s, n, nnz;
     int max_iters;
@@ -81,7 +109,7 @@ __device__ __forceinline__ void check_update_exact(double *M, double sigma, doub
     } else {
         double m[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) m[k] = M[(size_t)k * kTile];
+        for (int k = 0; k < D; ++k) m[k] = ldm(M + (size_t)k * kTile);
 #pragma unroll
         for (int k = 0; k < D; ++k) a[k] = 2.0 / (1.0 + m[k]) - 1.0;   // :140 / :148 (same value both times)
     }
@@ -92,7 +120,7 @@ __device__ __forceinline__ void check_update_exact(double *M, double sigma, doub
 #pragma unroll
     for (int k = D - 1; k >= 0; --k) {
         const double t = pre[k] * S;                      // :146
-        M[(size_t)k * kTile] = (1.0 - t) / (1.0 + t);     // :147
+        stm(M + (size_t)k * kTile, (1.0 - t) / (1.0 + t));  // :147
         S = S * a[k];                                     // :148
     }
 }
@@ -153,7 +181,7 @@ __device__ __forceinline__ double bit_update_exact(double *Mt, const int *__rest
 #pragma unroll
     for (int k = 0; k < D; ++k) at[k] = (size_t)pos[k] * kTile;
 #pragma unroll
-    for (int k = 0; k < D; ++k) c[k] = Mt[at[k]];
+    for (int k = 0; k < D; ++k) c[k] = ldm(Mt + at[k]);
     double F = r;                                         // :153
 #pragma unroll
     for (int k = 0; k < D; ++k) {
@@ -164,11 +192,41 @@ __device__ __forceinline__ double bit_update_exact(double *Mt, const int *__rest
     double G = 1.0;                                       // :170
 #pragma unroll
     for (int k = D - 1; k >= 0; --k) {
-        Mt[at[k]] = pre[k] * G;                           // :172 (unguarded, may be NaN)
+        stm(Mt + at[k], pre[k] * G);                      // :172 (unguarded, may be NaN)
         G = G * c[k];                                     // :173
         if (G != G) G = 1.0;                              // :174-176
     }
     return F;
+}
+
+// two bits of exact degree D at once: all 2*D row gathers are in flight together
+template <int D>
+__device__ __forceinline__ void bit_update_pair_exact(double *Mt, const int *__restrict__ posA,
+                                                      const int *__restrict__ posB, double r, double &TA,
+                                                      double &TB)
+{
+    double cA[D], cB[D], preA[D], preB[D];
+    size_t atA[D], atB[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) { atA[k] = (size_t)posA[k] * kTile; atB[k] = (size_t)posB[k] * kTile; }
+#pragma unroll
+    for (int k = 0; k < D; ++k) cA[k] = ldm(Mt + atA[k]);
+#pragma unroll
+    for (int k = 0; k < D; ++k) cB[k] = ldm(Mt + atB[k]);
+    double FA = r, FB = r;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        preA[k] = FA; FA = FA * cA[k]; if (FA != FA) FA = 1.0;
+        preB[k] = FB; FB = FB * cB[k]; if (FB != FB) FB = 1.0;
+    }
+    double GA = 1.0, GB = 1.0;
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) {
+        stm(Mt + atA[k], preA[k] * GA); GA = GA * cA[k]; if (GA != GA) GA = 1.0;
+        stm(Mt + atB[k], preB[k] * GB); GB = GB * cB[k]; if (GB != GB) GB = 1.0;
+    }
+    TA = FA;
+    TB = FB;
 }
 
 __device__ __noinline__ double bit_update_any(double *Mt, const int *__restrict__ pos, int deg, double r)
@@ -227,7 +285,12 @@ __device__ __forceinline__ double bit_update(double *Mt, const int *__restrict__
 //   csc2csr  [nnz]  CSR position of every CSC edge, checks ascending inside a bit
 //   synmask  [ntiles][s], nevermask [ntiles] (lanes holding a syndrome entry other than 0/1)
 template <int DC, int DV, bool WANT_LLR, int THREADS>
-__global__ void __launch_bounds__(THREADS)
+__global__ void
+#if LDPC_MIN_WAVES
+__launch_bounds__(THREADS, LDPC_MIN_WAVES)
+#else
+__launch_bounds__(THREADS)
+#endif
 bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restrict__ edge_bit,
                const int *__restrict__ col_ptr, const int *__restrict__ csc2csr,
                const u64 *__restrict__ synmask, const u64 *__restrict__ nevermask)
@@ -276,10 +339,7 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
             __syncthreads();
             const u64 t1 = wall_clock64();
             // ---- variable-node sweep  (:152-178)
-            for (int j = w; j < n; j += W) {
-                const int c0 = col_ptr[j];
-                const int deg = col_ptr[j + 1] - c0;
-                const double T = bit_update<DV>(Mt, csc2csr + c0, deg, r);
+            auto finish_bit = [&](int j, double T) {
                 const u64 dec = __ballot(T >= 1.0);                            // :164-168
                 if (WANT_LLR) {
                     if ((active >> lane) & 1ull)
@@ -290,6 +350,28 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
                     if (active != ~0ull) v = (em[j] & ~active) | (dec & active);  // frozen lanes keep theirs
                     em[j] = v;
                 }
+            };
+            for (int j = w; j < n; j += W * LDPC_NBV) {
+                const int c0 = col_ptr[j];
+                const int deg = col_ptr[j + 1] - c0;
+#if LDPC_NBV == 2
+                const int j2 = j + W;
+                if (j2 < n) {
+                    const int c02 = col_ptr[j2];
+                    const int deg2 = col_ptr[j2 + 1] - c02;
+                    if (deg == DV && deg2 == DV) {
+                        double TA, TB;
+                        bit_update_pair_exact<DV>(Mt, csc2csr + c0, csc2csr + c02, r, TA, TB);
+                        finish_bit(j, TA);
+                        finish_bit(j2, TB);
+                    } else {
+                        finish_bit(j, bit_update<DV>(Mt, csc2csr + c0, deg, r));
+                        finish_bit(j2, bit_update<DV>(Mt, csc2csr + c02, deg2, r));
+                    }
+                    continue;
+                }
+#endif
+                finish_bit(j, bit_update<DV>(Mt, csc2csr + c0, deg, r));
             }
             __syncthreads();
             const u64 t2 = wall_clock64();
