@@ -146,6 +146,28 @@ ldpc_status ldpc_bp_last_timing(ldpc_bp_decoder *dec, double *sweep_ms, double *
 ldpc_status ldpc_bp_call_timing(ldpc_bp_decoder *dec, int32_t calls_back, double *sweep_ms,
                                 double *total_ms, int64_t *sum_iters);
 
+/* ------------------------------------------------------------------------
+ * BP+OSD host post-processing (BASELINE config 5).  Pure host
+ * code (bit-packed GF(2) elimination, threaded over the batch): it consumes the
+ * BP outputs of ldpc_bp_decode_batch and needs no device.
+ * ------------------------------------------------------------------------ */
+typedef struct ldpc_osd ldpc_osd;
+
+/* Replaces the OSD half of `BeliefPropagationOSDDecoder(H, per, max_iters; osd_order)`
+ * (src/decoders/belief_propagation_osd.jl:17-29): keeps a bit-packed copy of H
+ * (zero-based CSC pattern as for ldpc_bp_create) and the OSD order. */
+ldpc_status ldpc_osd_create(int64_t s, int64_t n, int64_t nnz, const int64_t *colptr,
+                            const int64_t *rowval, int64_t osd_order, ldpc_osd **out);
+ldpc_status ldpc_osd_destroy(ldpc_osd *osd);
+
+/* Replaces lines :52-60 of `decode!(::BeliefPropagationOSDDecoder, syndrome)` and the
+ * `osd` methods (:63-125 order 0, :127-209 order > 0) for a batch:
+ *   syndromes [batch][s] uint8 (0/1 only), bp_errors [batch][n] uint8 and llr [batch][n]
+ *   double = the BP outputs; errors [batch][n] uint8 out.  nthreads <= 0: all host cores. */
+ldpc_status ldpc_osd_postprocess_batch(const ldpc_osd *osd, int64_t batch, const uint8_t *syndromes,
+                                       const uint8_t *bp_errors, const double *llr, uint8_t *errors,
+                                       int32_t nthreads);
+
 /* Diagnostics: 100 MHz ticks spent in {check sweep, variable sweep, convergence test}
  * of that call, summed over workgroups (one sampling wave each). */
 ldpc_status ldpc_bp_call_phase_ticks(ldpc_bp_decoder *dec, int32_t calls_back, uint64_t ticks[3]);

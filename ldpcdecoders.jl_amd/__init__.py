@@ -22,7 +22,10 @@ from .decoder import (  # noqa: F401
     syndrome_bytes,
 )
 
+from .osd import BeliefPropagationOSDDecoder, OSDPostProcessor  # noqa: F401,E402
+
 __all__ = [
+    "BeliefPropagationOSDDecoder", "OSDPostProcessor",
     "decode_", "batchdecode_", "reset_", "AbstractDecoder", "BeliefPropagationDecoder",
     "BeliefPropagationScratchSpace", "parity_check_matrix", "save_pcm", "load_pcm",
     "LdpcError", "build", "codes", "syndrome_bytes",

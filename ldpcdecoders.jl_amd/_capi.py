@@ -38,6 +38,9 @@ EXPORTED_SYMBOLS = (
     "ldpc_bp_last_timing",
     "ldpc_bp_call_timing",
     "ldpc_bp_call_phase_ticks",
+    "ldpc_osd_create",
+    "ldpc_osd_destroy",
+    "ldpc_osd_postprocess_batch",
 )
 
 
@@ -69,7 +72,7 @@ class BPOptions(ctypes.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("ldpc_mi355x.hip", "bp_kernels.hpp", "Makefile")]
+    srcs = [os.path.join(CSRC, f) for f in ("ldpc_mi355x.hip", "osd_host.cpp", "bp_kernels.hpp", "Makefile")]
     srcs.append(os.path.join(_HERE, "..", "include", "ldpc_mi355x.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(
         os.path.getmtime(f) > os.path.getmtime(LIB_PATH) for f in srcs if os.path.exists(f))
@@ -126,6 +129,12 @@ def lib() -> ctypes.CDLL:
     L.ldpc_bp_call_timing.argtypes = [vp, i32, ctypes.POINTER(f64), ctypes.POINTER(f64), ctypes.POINTER(i64)]
     L.ldpc_bp_call_phase_ticks.restype = i32
     L.ldpc_bp_call_phase_ticks.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_uint64 * 3)]
+    L.ldpc_osd_create.restype = i32
+    L.ldpc_osd_create.argtypes = [i64, i64, i64, vp, vp, i64, ctypes.POINTER(vp)]
+    L.ldpc_osd_destroy.restype = i32
+    L.ldpc_osd_destroy.argtypes = [vp]
+    L.ldpc_osd_postprocess_batch.restype = i32
+    L.ldpc_osd_postprocess_batch.argtypes = [vp, i64, vp, vp, vp, vp, i32]
     _LIB = L
     return L
 

@@ -31,6 +31,15 @@ ldpc_status fail(ldpc_status st, const std::string &msg)
     return st;
 }
 
+}  // namespace
+
+namespace ldpc_detail {
+// shared with osd_host.cpp: records the message ldpc_last_error() returns
+ldpc_status set_error(ldpc_status st, const std::string &msg) { return fail(st, msg); }
+}  // namespace ldpc_detail
+
+namespace {
+
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
         hipError_t e_ = (expr);                                                                \

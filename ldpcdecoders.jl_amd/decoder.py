@@ -238,6 +238,8 @@ def batchdecode_(decoder: AbstractDecoder, syndromes, errors, success=None):
         success = np.empty(B, dtype=np.bool_)                     # Vector{Bool}(undef, B)
     assert syndromes.shape[1] == errors.shape[1]                  # :221
     assert syndromes.shape[1] == len(success)                     # :222
+    if hasattr(decoder, "batchdecode_") and not isinstance(decoder, BeliefPropagationDecoder):
+        return decoder.batchdecode_(syndromes, errors, success)   # a decoder with its own batch strategy
     if not isinstance(decoder, BeliefPropagationDecoder):
         for i in range(B):                                        # abstract_decoder.jl:35-39
             guess, conv = decoder.decode_(syndromes[:, i])

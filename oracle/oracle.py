@@ -118,3 +118,29 @@ class BPOracle:
         _lib().bp_oracle_decode_batch(self._h, B, syn.ctypes.data, errors.ctypes.data, conv.ctypes.data,
                                       llr.ctypes.data if want_llr else None, iters.ctypes.data)
         return errors, conv, llr, iters
+
+
+_OSD_LIB = None
+
+
+def osd_oracle_postprocess(H, syndrome, bp_err, log_probabs, osd_order: int) -> np.ndarray:
+    """oracle/osd_oracle.c: belief_propagation_osd.jl:52-60 + osd (:63-125 / :127-209) for ONE syndrome.
+    H dense m x n 0/1; returns the error estimate (n bytes)."""
+    global _OSD_LIB
+    if _OSD_LIB is None:
+        so = os.path.join(_HERE, "libosd_oracle.so")
+        src = os.path.join(_HERE, "osd_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "libosd_oracle.so"])
+        _OSD_LIB = ctypes.CDLL(so)
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        _OSD_LIB.osd_oracle_postprocess.argtypes = [vp, i64, i64, vp, vp, vp, i64, vp]
+    Hd = np.ascontiguousarray(np.asarray(H) != 0, dtype=np.uint8)
+    m, n = Hd.shape
+    syn = np.ascontiguousarray(syndrome, dtype=np.uint8)
+    e = np.ascontiguousarray(bp_err, dtype=np.uint8)
+    L = np.ascontiguousarray(log_probabs, dtype=np.float64)
+    out = np.zeros(n, dtype=np.uint8)
+    _OSD_LIB.osd_oracle_postprocess(Hd.ctypes.data, m, n, syn.ctypes.data, e.ctypes.data, L.ctypes.data,
+                                    int(osd_order), out.ctypes.data)
+    return out
