@@ -37,8 +37,8 @@ typedef unsigned long long u64;
 constexpr int kTile = 64;  // syndromes per tile == wavefront width on gfx950
 
 // Build-time tuning knobs (defaults = the shipped configuration; DESIGN.md lists what was measured)
-#ifndef LDPC_MIN_WAVES   // 2nd __launch_bounds__ argument (waves per SIMD); 0 = leave it to the compiler
-#define LDPC_MIN_WAVES 0
+#ifndef LDPC_MIN_WAVES   // 2nd __launch_bounds__ argument = waves per SIMD the register budget must allow.
+#define LDPC_MIN_WAVES 6 // 6 => <=80 VGPRs => three 512-thread workgroups per CU (measured best: +9.6 % over 4)
 #endif
 #ifndef LDPC_NT          // 1 = non-temporal loads/stores for the streamed edge messages
 #define LDPC_NT 0
@@ -46,6 +46,19 @@ constexpr int kTile = 64;  // syndromes per tile == wavefront width on gfx950
 #ifndef LDPC_NBV         // bits handled per wave per step of the variable sweep (1 or 2)
 #define LDPC_NBV 1
 #endif
+
+// Register budget per kernel variant, as the waves-per-SIMD the launch bound must admit.
+// Narrow-degree variants (the regular LDPC codes of the benchmarks) run three 512-thread
+// workgroups per CU; the wide register buckets need the registers more than the occupancy.
+template <int DC, int DV, int THREADS>
+constexpr int min_waves_per_simd()
+{
+    constexpr int one_block = THREADS / 256;  // waves per SIMD of a single workgroup
+    int want = (DC <= 8 && DV <= 4) ? LDPC_MIN_WAVES : (DC <= 16 ? 4 : 2);
+    if (want < one_block) want = one_block;
+    if (THREADS >= 1024 && want > 4) want = 4;
+    return want;
+}
 
 __device__ __forceinline__ double ldm(const double *p)
 {
@@ -286,11 +299,7 @@ __device__ __forceinline__ double bit_update(double *Mt, const int *__restrict__
 //   synmask  [ntiles][s], nevermask [ntiles] (lanes holding a syndrome entry other than 0/1)
 template <int DC, int DV, bool WANT_LLR, int THREADS>
 __global__ void
-#if LDPC_MIN_WAVES
-__launch_bounds__(THREADS, LDPC_MIN_WAVES)
-#else
-__launch_bounds__(THREADS)
-#endif
+__launch_bounds__(THREADS, (min_waves_per_simd<DC, DV, THREADS>()))
 bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restrict__ edge_bit,
                const int *__restrict__ col_ptr, const int *__restrict__ csc2csr,
                const u64 *__restrict__ synmask, const u64 *__restrict__ nevermask)
@@ -380,7 +389,18 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
             for (int i = w * 64 + lane; i < s; i += W * 64) {
                 u64 par = 0;
                 const int e1 = row_ptr[i + 1];
-                for (int e = row_ptr[i]; e < e1; ++e) par ^= em[edge_bit[e]];
+                // 8 independent index loads, then 8 independent word gathers per step
+                // (a plain loop serialises 2*deg dependent L2 round trips)
+                for (int e = row_ptr[i]; e < e1; e += 8) {
+                    int jb[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) jb[q] = (e + q < e1) ? edge_bit[e + q] : -1;
+                    u64 wv[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) wv[q] = (jb[q] >= 0) ? em[jb[q]] : 0ull;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) par ^= wv[q];
+                }
                 mism |= par ^ syn[i];
             }
             mism = wave_or(mism);
