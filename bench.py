@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="syndromes per GPU (default: the workload's)")
     ap.add_argument("--waves-per-tile", type=int, default=0)
     ap.add_argument("--resident-tiles", type=int, default=0)
+    ap.add_argument("--kernel-variant", type=int, default=0, help="0 auto, 1 HBM-streaming, 2 LDS-resident")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -109,7 +110,8 @@ def main():
     H = ldpc.codes.parity_check_csc(n, wr, wc)
     nnz = int(H.nnz)
     dec = ldpc.BeliefPropagationDecoder(H, per, max_iters, device=local_rank,
-                                        waves_per_tile=args.waves_per_tile, resident_tiles=args.resident_tiles)
+                                        waves_per_tile=args.waves_per_tile, resident_tiles=args.resident_tiles,
+                                        kernel_variant=args.kernel_variant)
     syn = make_syndromes(torch, H.tocsr(), n, batch, per, seed=1234 + rank, device=device)
     err = torch.empty((batch, n), dtype=torch.uint8, device=device)
     conv = torch.empty(batch, dtype=torch.uint8, device=device)

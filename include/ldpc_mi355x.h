@@ -64,7 +64,8 @@ typedef struct ldpc_bp_options {
     int32_t device;           /* HIP device ordinal; -1 = current device */
     int32_t waves_per_tile;   /* 0 = auto */
     int32_t resident_tiles;   /* 0 = auto (fills the chip) */
-    int32_t kernel_variant;   /* 0 = auto; see DESIGN.md */
+    int32_t kernel_variant;   /* 0 = auto (LDS-resident kernel when the edge messages fit the LDS, else the
+                                 HBM-streaming tile kernel); 1 = force streaming; 2 = force LDS-resident */
     int32_t reserved[12];
 } ldpc_bp_options;
 

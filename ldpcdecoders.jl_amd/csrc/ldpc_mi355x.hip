@@ -11,6 +11,7 @@
 // usable every compute entry fails with a status code.
 #include "../../include/ldpc_mi355x.h"
 #include "bp_kernels.hpp"
+#include "bp_lds_kernels.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -107,6 +108,52 @@ bp_kernel_t pick_kernel(int dc, int dv, bool llr, int threads)
     return llr ? pick_dc<true>(dc, dv, threads) : pick_dc<false>(dc, dv, threads);
 }
 
+typedef void (*lds_kernel_t)(LdsParams, const int *, const int *, const int *, const int *);
+
+template <int DC, int DV, bool LLR>
+lds_kernel_t lds_pick_threads(int threads)
+{
+    switch (threads) {
+    case 256: return bp_lds_kernel<DC, DV, LLR, 256>;
+    case 512: return bp_lds_kernel<DC, DV, LLR, 512>;
+    default: return bp_lds_kernel<DC, DV, LLR, 1024>;
+    }
+}
+template <int DC, bool LLR>
+lds_kernel_t lds_pick_dv(int dv, int threads)
+{
+    if (dv <= 4) return lds_pick_threads<DC, 4, LLR>(threads);
+    return lds_pick_threads<DC, 16, LLR>(threads);
+}
+template <bool LLR>
+lds_kernel_t lds_pick_dc(int dc, int dv, int threads)
+{
+    if (dc <= 8) return lds_pick_dv<8, LLR>(dv, threads);
+    if (dc <= 16) return lds_pick_dv<16, LLR>(dv, threads);
+    return lds_pick_dv<32, LLR>(dv, threads);
+}
+lds_kernel_t pick_lds_kernel(int dc, int dv, bool llr, int threads)
+{
+    return llr ? lds_pick_dc<true>(dc, dv, threads) : lds_pick_dc<false>(dc, dv, threads);
+}
+
+// How many syndromes per workgroup pass the LDS kernel can hold (log2), or -1 if even one
+// syndrome's messages do not fit.  Prefers a footprint that lets two workgroups share a CU.
+int lds_logS(int64_t s, int64_t n, int64_t nnz, bool want_llr)
+{
+    constexpr size_t kMax = 160 * 1024 - 1024;   // one workgroup may own (almost) the whole LDS
+    constexpr size_t kHalf = 78 * 1024;          // two workgroups per CU
+    if (nnz > (1 << 20)) return -1;
+    int best_half = -1, best_full = -1;
+    for (int l = 0; l <= 6; ++l) {
+        const size_t b = lds_bytes_needed((int)s, (int)n, (int)nnz, 1 << l, want_llr);
+        if (b <= kHalf) best_half = l;
+        if (b <= kMax) best_full = l;
+    }
+    if (best_half >= 1) return best_half;
+    return best_full;
+}
+
 }  // namespace
 
 struct ldpc_bp_decoder {
@@ -117,6 +164,8 @@ struct ldpc_bp_decoder {
     int max_cdeg = 0, max_bdeg = 0;
     int threads = 512;        // waves_per_tile * 64
     int resident_tiles = 0;   // workspace slots
+    int variant = 0;          // 0 auto, 1 HBM-streaming tile kernel, 2 LDS-resident kernel
+    int lds_logS[2] = {-1, -1};   // [want_llr]: syndromes per workgroup pass of the LDS kernel, -1 = does not fit
     // device graph
     DevBuf row_ptr, edge_bit, col_ptr, csc2csr;
     // workspace
@@ -256,6 +305,14 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
         return fail(LDPC_ERR_INVALID_ARGUMENT, "waves_per_tile must be 0, 4, 8 or 16");
     }
     d->threads = wpt * 64;
+    d->variant = options ? options->kernel_variant : 0;
+    if (d->variant < 0 || d->variant > 2) { delete d; return fail(LDPC_ERR_INVALID_ARGUMENT, "kernel_variant must be 0, 1 or 2"); }
+    d->lds_logS[0] = lds_logS(s, n, nnz, false);
+    d->lds_logS[1] = lds_logS(s, n, nnz, true);
+    if (d->variant == 2 && (d->lds_logS[0] < 0 || d->lds_logS[1] < 0)) {
+        delete d;
+        return fail(LDPC_ERR_UNSUPPORTED, "kernel_variant 2 (LDS-resident) requested but the edge messages do not fit the LDS");
+    }
     bp_kernel_t kfn = pick_kernel(d->max_cdeg, d->max_bdeg, false, d->threads);
     int blocks_per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, (const void *)kfn, d->threads, 0) != hipSuccess ||
@@ -337,6 +394,41 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
         HIP_TRY(hipMemsetAsync(d_conv, 0, (size_t)batch, stream));
         if (d_llr && n > 0) HIP_TRY(hipMemsetAsync(d_llr, 0, (size_t)batch * n * sizeof(double), stream));
         if (d_iters) HIP_TRY(hipMemsetAsync(d_iters, 0, (size_t)batch * sizeof(int32_t), stream));
+        return LDPC_OK;
+    }
+
+    const bool want_llr_early = d_llr != nullptr;
+    if (d->variant != 1 && d->lds_logS[want_llr_early ? 1 : 0] >= 0) {
+        // ---- on-chip path: messages never leave the LDS (bp_lds_kernels.hpp)
+        const int logS = d->lds_logS[want_llr_early ? 1 : 0];
+        const int64_t ngroups64 = (batch + (1ll << logS) - 1) >> logS;
+        if (ngroups64 > (1ll << 30)) return fail(LDPC_ERR_UNSUPPORTED, "batch too large for one call");
+        LdsParams lp;
+        lp.s = (int)s; lp.n = (int)n; lp.nnz = (int)d->nnz; lp.max_iters = (int)d->max_iters;
+        lp.logS = logS; lp.ngroups = (int)ngroups64; lp.batch = batch;
+        lp.r = d->per / (1 - d->per);
+        lp.syn = d_syn; lp.err = d_err; lp.conv = d_conv; lp.iters = d_iters; lp.llr = d_llr;
+        lp.queue = (unsigned int *)ctrl;
+        lp.sum_iters = (u64 *)(ctrl + 8);
+        const size_t lds = lds_bytes_needed((int)s, (int)n, (int)d->nnz, 1 << logS, want_llr_early);
+        lds_kernel_t lk = pick_lds_kernel(d->max_cdeg, d->max_bdeg, want_llr_early, d->threads);
+        HIP_TRY(hipFuncSetAttribute((const void *)lk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)lk, d->threads, lds) != hipSuccess || per_cu <= 0) {
+            (void)hipGetLastError();
+            per_cu = 1;
+        }
+        const int lgrid = (int)std::min<int64_t>(ngroups64, (int64_t)per_cu * d->num_cus);
+        HIP_TRY(hipMemsetAsync(ctrl, 0, 64, stream));
+        HIP_TRY(hipEventRecord(ev[0], stream));
+        HIP_TRY(hipEventRecord(ev[1], stream));
+        hipLaunchKernelGGL(lk, dim3((unsigned)lgrid), dim3((unsigned)d->threads), lds, stream, lp,
+                           (const int *)d->row_ptr.p, (const int *)d->edge_bit.p, (const int *)d->col_ptr.p,
+                           (const int *)d->csc2csr.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev[2], stream));
+        HIP_TRY(hipEventRecord(ev[3], stream));
+        d->timed[slot] = true;
         return LDPC_OK;
     }
 

@@ -95,7 +95,7 @@ class BeliefPropagationDecoder(AbstractDecoder):
     """
 
     def __init__(self, H, per: float, max_iters: int, *, device: Optional[int] = None,
-                 waves_per_tile: int = 0, resident_tiles: int = 0):
+                 waves_per_tile: int = 0, resident_tiles: int = 0, kernel_variant: int = 0):
         if not isinstance(per, float):
             raise TypeError("per must be a Float64 (reference signature: per::Float64)")
         if isinstance(max_iters, bool) or not isinstance(max_iters, (int, np.integer)):
@@ -114,6 +114,7 @@ class BeliefPropagationDecoder(AbstractDecoder):
         opts.device = -1 if device is None else int(device)
         opts.waves_per_tile = int(waves_per_tile)
         opts.resident_tiles = int(resident_tiles)
+        opts.kernel_variant = int(kernel_variant)   # 0 auto, 1 HBM-streaming, 2 LDS-resident
         self._h = ctypes.c_void_p()
         L = _capi.lib()
         _capi.check(L.ldpc_bp_create(self.s, self.n, int(self._rowval.size), self._colptr.ctypes.data,

@@ -55,14 +55,15 @@ def test_oracle_reproduces_golden(path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant", [1, 0], ids=["hbm_streaming", "auto_lds"])
 @pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
-def test_hip_path_reproduces_golden(path, gpu):
+def test_hip_path_reproduces_golden(path, variant, gpu):
     import scipy.sparse as sp
 
     g = _load(path)
     s, n = (int(v) for v in g["shape"])
     H = sp.csc_matrix((np.ones(len(g["rowval"]), dtype=bool), g["rowval"], g["colptr"]), shape=(s, n))
-    dec = ldpc.BeliefPropagationDecoder(H, float(g["per"]), int(g["max_iters"]))
+    dec = ldpc.BeliefPropagationDecoder(H, float(g["per"]), int(g["max_iters"]), kernel_variant=variant)
     err, conv, llr, its = dec.decode_batch_host(g["syndromes"], want_llr=True, want_iters=True)
     assert np.array_equal(err, g["errors"])
     assert np.array_equal(conv, g["converged"])

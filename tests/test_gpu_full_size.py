@@ -1,0 +1,88 @@
+"""Parity at BASELINE.json's full sizes (configs[2]: n=16384, m=8192, row weight 8, batch 65536,
+50 iterations), where the oracle cannot decode everything in seconds:
+
+* size-independent properties on the WHOLE batch -- a converged syndrome's hard decision must
+  reproduce the syndrome (H e = s), its iteration count must be < 50 or exactly the iteration of
+  convergence, a non-converged one must have run all 50; results must not depend on the
+  waves-per-tile / workspace geometry nor on where a syndrome sits in the batch;
+* the oracle on a random subset (SURVEY.md 8d parity gate), decoded on the host cores in threads.
+"""
+import concurrent.futures as cf
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import BPOracle
+
+pytestmark = pytest.mark.gpu
+
+N, WR, WC, B, ITERS = 16384, 8, 4, 65536, 50
+
+
+def _device_syndromes(H, per, seed):
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    csr = H.tocsr()
+    cols = torch.from_numpy(csr.indices.astype(np.int64)).to(dev)
+    syn = torch.empty((B, csr.shape[0]), dtype=torch.uint8, device=dev)
+    for b0 in range(0, B, 4096):
+        e = (torch.rand((4096, N), generator=g, device=dev) < per).to(torch.uint8)
+        syn[b0:b0 + 4096] = e[:, cols].view(4096, csr.shape[0], WR).sum(dim=2, dtype=torch.int32).remainder(2).to(torch.uint8)
+    return syn, cols
+
+
+def _decode(ldpc, H, per, syn, **kw):
+    dec = ldpc.BeliefPropagationDecoder(H, per, ITERS, **kw)
+    dev = syn.device
+    err = torch.empty((syn.shape[0], N), dtype=torch.uint8, device=dev)
+    conv = torch.empty(syn.shape[0], dtype=torch.uint8, device=dev)
+    its = torch.empty(syn.shape[0], dtype=torch.int32, device=dev)
+    dec.decode_batch_device(syn, err, conv, None, its)
+    torch.cuda.synchronize()
+    dec.close()
+    return err, conv, its
+
+
+def _oracle_subset(H, per, syn_np, threads=12):
+    def work(chunk):
+        oc = BPOracle(csc=(H.indptr, H.indices), shape=H.shape, per=per, max_iters=ITERS)
+        return oc.batchdecode(chunk, want_llr=False)
+
+    chunks = np.array_split(syn_np, threads)
+    with cf.ThreadPoolExecutor(threads) as ex:   # ctypes releases the GIL inside the C oracle
+        res = list(ex.map(work, chunks))
+    return (np.concatenate([r[0] for r in res]), np.concatenate([r[1] for r in res]),
+            np.concatenate([r[3] for r in res]))
+
+
+@pytest.mark.parametrize("per,subset", [(0.02, 4096), (0.10, 384)])
+def test_c3_full_batch(ldpc, gpu, per, subset):
+    H = ldpc.codes.parity_check_csc(N, WR, WC)
+    syn, cols = _device_syndromes(H, per, seed=int(per * 1000))
+    err, conv, its = _decode(ldpc, H, per, syn)
+    conv_b = conv.bool()
+    # (1) converged  =>  H e = s, for every converged syndrome of the batch
+    for b0 in range(0, B, 4096):
+        s2 = err[b0:b0 + 4096][:, cols].view(4096, H.shape[0], WR).sum(dim=2, dtype=torch.int32).remainder(2).to(torch.uint8)
+        ok = (s2 == syn[b0:b0 + 4096]).all(dim=1)
+        assert bool((ok == conv_b[b0:b0 + 4096]).all()), "converged flag must equal 'syndrome reproduced'"
+    # (2) iteration counts: non-converged ran all 50, converged at most 50
+    assert bool((its[~conv_b] == ITERS).all()) and bool((its >= 1).all()) and bool((its <= ITERS).all())
+    if per == 0.10:
+        assert not bool(conv_b.any())              # above threshold: the full-50 roofline workload
+    else:
+        assert conv_b.float().mean().item() > 0.99
+    # (3) geometry / position independence: another waves-per-tile + fewer workspace slots, and a
+    #     permuted batch, must give identical per-syndrome results
+    perm = torch.randperm(B, device=syn.device, generator=torch.Generator(device=syn.device).manual_seed(1))[:8192]
+    e2, c2, i2 = _decode(ldpc, H, per, syn[perm].contiguous(), waves_per_tile=16, resident_tiles=100)
+    assert torch.equal(e2, err[perm]) and torch.equal(c2, conv[perm]) and torch.equal(i2, its[perm])
+    # (4) the oracle on a random subset
+    idx = np.sort(np.random.default_rng(7).choice(B, subset, replace=False))
+    tidx = torch.from_numpy(idx).to(syn.device)
+    oerr, oconv, oits = _oracle_subset(H, per, syn[tidx].cpu().numpy())
+    assert np.array_equal(conv[tidx].cpu().numpy(), oconv)
+    assert np.array_equal(its[tidx].cpu().numpy(), oits)
+    assert np.array_equal(err[tidx].cpu().numpy(), oerr)

@@ -16,24 +16,28 @@ LLR_TOL = 1e-5  # north_star: "LLRs within 1e-5"
 
 def assert_parity(ldpc, H, per, max_iters, syn_bs, **kw):
     """Decode syn_bs [B][s] on the GPU and with the oracle; compare everything."""
-    dec = ldpc.BeliefPropagationDecoder(H, per, max_iters, **kw)
-    err, conv, llr, its = dec.decode_batch_host(syn_bs, want_llr=True, want_iters=True)
-    # a second call without LLRs exercises the other kernel instantiation
-    err2, conv2, _, its2 = dec.decode_batch_host(syn_bs, want_llr=False, want_iters=True)
     M = sp.csc_matrix(H)
     M.sort_indices()
     oc = BPOracle(csc=(M.indptr, M.indices), shape=M.shape, per=per, max_iters=max_iters)
     oerr, oconv, ollr, oits = oc.batchdecode(syn_bs, want_llr=True)
-    assert np.array_equal(conv, oconv), f"converged flags differ at {np.nonzero(conv != oconv)[0][:10]}"
-    assert np.array_equal(its, oits), f"iteration counts differ at {np.nonzero(its != oits)[0][:10]}"
-    assert np.array_equal(err, oerr), f"hard decisions differ in rows {np.unique(np.nonzero(err != oerr)[0])[:10]}"
-    assert np.array_equal(err2, err) and np.array_equal(conv2, conv) and np.array_equal(its2, its)
-    fin = np.isfinite(ollr)
-    assert np.array_equal(np.isfinite(llr), fin)
-    assert np.array_equal(llr[~fin], ollr[~fin])           # +-Inf must match exactly
-    if fin.any():
-        assert np.max(np.abs(llr[fin] - ollr[fin])) <= LLR_TOL
-    dec.close()
+    # both kernels: 1 = HBM-streaming tile kernel, 0 = auto (the LDS-resident kernel whenever the
+    # edge messages fit the LDS, which is the case for every small code used here)
+    for variant in ([kw.pop("kernel_variant")] if "kernel_variant" in kw else [1, 0]):
+        dec = ldpc.BeliefPropagationDecoder(H, per, max_iters, kernel_variant=variant, **kw)
+        err, conv, llr, its = dec.decode_batch_host(syn_bs, want_llr=True, want_iters=True)
+        # a second call without LLRs exercises the other kernel instantiation
+        err2, conv2, _, its2 = dec.decode_batch_host(syn_bs, want_llr=False, want_iters=True)
+        tag = f"[kernel_variant={variant}] "
+        assert np.array_equal(conv, oconv), tag + f"converged flags differ at {np.nonzero(conv != oconv)[0][:10]}"
+        assert np.array_equal(its, oits), tag + f"iteration counts differ at {np.nonzero(its != oits)[0][:10]}"
+        assert np.array_equal(err, oerr), tag + f"hard decisions differ in rows {np.unique(np.nonzero(err != oerr)[0])[:10]}"
+        assert np.array_equal(err2, err) and np.array_equal(conv2, conv) and np.array_equal(its2, its), tag
+        fin = np.isfinite(ollr)
+        assert np.array_equal(np.isfinite(llr), fin), tag
+        assert np.array_equal(llr[~fin], ollr[~fin]), tag      # +-Inf must match exactly
+        if fin.any():
+            assert np.max(np.abs(llr[fin] - ollr[fin])) <= LLR_TOL, tag
+        dec.close()
     return err, conv, its
 
 
