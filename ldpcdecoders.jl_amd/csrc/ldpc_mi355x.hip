@@ -137,21 +137,23 @@ lds_kernel_t pick_lds_kernel(int dc, int dv, bool llr, int threads)
     return llr ? lds_pick_dc<true>(dc, dv, threads) : lds_pick_dc<false>(dc, dv, threads);
 }
 
-// How many syndromes per workgroup pass the LDS kernel can hold (log2), or -1 if even one
-// syndrome's messages do not fit.  Prefers a footprint that lets two workgroups share a CU.
+// How many syndromes per workgroup pass the LDS kernel holds (log2), or -1 if even one
+// syndrome's messages do not fit.  Maximises syndromes resident per CU (S x workgroups per CU,
+// at most 3 workgroups: the register budget), preferring more, smaller workgroups on a tie.
 int lds_logS(int64_t s, int64_t n, int64_t nnz, bool want_llr)
 {
-    constexpr size_t kMax = 160 * 1024 - 1024;   // one workgroup may own (almost) the whole LDS
-    constexpr size_t kHalf = 78 * 1024;          // two workgroups per CU
-    if (nnz > (1 << 20)) return -1;
-    int best_half = -1, best_full = -1;
+    constexpr size_t kLds = 160 * 1024;
+    if (nnz > (1 << 20) || s > (1 << 20) || n > (1 << 20)) return -1;
+    int best = -1;
+    long best_total = 0, best_wgs = 0;
     for (int l = 0; l <= 6; ++l) {
-        const size_t b = lds_bytes_needed((int)s, (int)n, (int)nnz, 1 << l, want_llr);
-        if (b <= kHalf) best_half = l;
-        if (b <= kMax) best_full = l;
+        const size_t b = lds_bytes_needed((int)s, (int)n, (int)nnz, 1 << l, want_llr) + 256;
+        if (b > kLds) break;
+        const long wgs = std::min<long>(3, (long)(kLds / b));
+        const long total = wgs << l;
+        if (total > best_total || (total == best_total && wgs > best_wgs)) { best = l; best_total = total; best_wgs = wgs; }
     }
-    if (best_half >= 1) return best_half;
-    return best_full;
+    return best;
 }
 
 }  // namespace
