@@ -30,6 +30,8 @@ WORKLOADS = {
     "c3_full50": (16384, 8, 4, 65536, 0.10, 50),
     "c3_realistic": (16384, 8, 4, 65536, 0.02, 50),
     "c2_n1008": (1008, 6, 3, 4096, 0.01, 50),
+    # BASELINE configs[4]: BB [[72,12,6]] H_X, BP on the GPU + OSD-0 on the host for what BP leaves
+    "c5_bb72_bposd": (72, 6, 3, 1048576, 0.005, 50),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -107,7 +109,13 @@ def main():
     n, wr, wc, batch, per, max_iters = WORKLOADS[args.workload]
     if args.batch:
         batch = args.batch
-    H = ldpc.codes.parity_check_csc(n, wr, wc)
+    if args.workload == "c5_bb72_bposd":
+        import scipy.sparse as sp
+
+        H = sp.csc_matrix(ldpc.codes.bivariate_bicycle_72_12_6()[0])
+        H.sort_indices()
+    else:
+        H = ldpc.codes.parity_check_csc(n, wr, wc)
     nnz = int(H.nnz)
     dec = ldpc.BeliefPropagationDecoder(H, per, max_iters, device=local_rank,
                                         waves_per_tile=args.waves_per_tile, resident_tiles=args.resident_tiles,
@@ -117,8 +125,20 @@ def main():
     conv = torch.empty(batch, dtype=torch.uint8, device=device)
     iters = torch.empty(batch, dtype=torch.int32, device=device)
 
-    def step():
-        dec.decode_batch_device(syn, err, conv, None, iters)
+    osd_sent = [0]
+    if args.workload == "c5_bb72_bposd":
+        bposd = ldpc.BeliefPropagationOSDDecoder(H, per, max_iters, osd_order=0, device=local_rank,
+                                                 waves_per_tile=args.waves_per_tile, kernel_variant=args.kernel_variant)
+        dec = bposd.bp_decoder
+
+        def step():
+            e, c, k = bposd.batchdecode_device(syn)
+            err.copy_(e)
+            conv.copy_(c)
+            osd_sent[0] = k
+    else:
+        def step():
+            dec.decode_batch_device(syn, err, conv, None, iters)
 
     def fence():
         torch.cuda.synchronize()
@@ -172,6 +192,7 @@ def main():
                 "parallelism": f"batch-sharded x{world} (independent syndromes, no data-path collective)",
                 "mean_iters": sum_iters / batch,
                 "converged_frac": float(conv.float().mean().item()),
+                "osd_postprocessed_per_step": osd_sent[0],
             },
             "roofline": {
                 "bound": "hbm",
@@ -187,7 +208,7 @@ def main():
                 "phase_share_check_var_conv": [round(t / max(sum(dec.phase_ticks(0)), 1), 4) for t in dec.phase_ticks(0)],
             },
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.workload != "c5_bb72_bposd":
             k = 64
             cps, done, ok = cpu_baseline(H, per, max_iters, syn[:k].cpu().numpy(), err[:k].cpu().numpy(),
                                          conv[:k].cpu().numpy())

@@ -42,7 +42,8 @@ __host__ __device__ inline size_t lds_bytes_needed(int s, int n, int nnz, int S,
     if (want_llr) b += (size_t)n * S * 8;       // LLRs of the active syndromes
     b += (size_t)s * 8 + (size_t)n * 8;         // syndrome masks, decision masks
     b += 64 * 8;                                // per-wave reduction words + control
-    b += 4 * ((size_t)s + 1 + (size_t)n + 1 + 2 * (size_t)nnz) + 16;   // the Tanner graph itself (int32)
+    b += 2 * ((size_t)s + 1 + (size_t)n + 1 + 2 * (size_t)nnz) + 16;   // the Tanner graph itself (uint16:
+                                                                        // nnz*8 B must fit the LDS, so every index < 65536)
     return b;
 }
 
@@ -88,7 +89,7 @@ __device__ __forceinline__ void lds_check_unit(double *M, int S, int deg, double
 }
 
 template <int DV>
-__device__ __forceinline__ double lds_bit_unit(double *Ms, int S, const int *pos, int deg, double r)
+__device__ __forceinline__ double lds_bit_unit(double *Ms, int S, const unsigned short *pos, int deg, double r)
 {
     // Ms points at msg[sigma_lane]; edge e lives at Ms[e*S]
     double F = r;                                                     // :153
@@ -97,7 +98,7 @@ __device__ __forceinline__ double lds_bit_unit(double *Ms, int S, const int *pos
         int at[DV];
 #pragma unroll
         for (int k = 0; k < DV; ++k)
-            if (k < deg) { at[k] = pos[k] * S; c[k] = Ms[at[k]]; }
+            if (k < deg) { at[k] = (int)pos[k] * S; c[k] = Ms[at[k]]; }
 #pragma unroll
         for (int k = 0; k < DV; ++k)
             if (k < deg) {
@@ -115,17 +116,17 @@ __device__ __forceinline__ double lds_bit_unit(double *Ms, int S, const int *pos
             }
     } else {
         for (int k = 0; k < deg; ++k) {
-            F = F * Ms[pos[k] * S];
+            F = F * Ms[(int)pos[k] * S];
             if (F != F) F = 1.0;
         }
         double G = 1.0;
         for (int k = deg - 1; k >= 0; --k) {
             double Pk = r;
             for (int q = 0; q < k; ++q) {
-                Pk = Pk * Ms[pos[q] * S];
+                Pk = Pk * Ms[(int)pos[q] * S];
                 if (Pk != Pk) Pk = 1.0;
             }
-            const int a = pos[k] * S;
+            const int a = (int)pos[k] * S;
             const double ck = Ms[a];
             Ms[a] = Pk * G;
             G = G * ck;
@@ -148,14 +149,15 @@ bp_lds_kernel(LdsParams p, const int *__restrict__ g_row_ptr, const int *__restr
     u64 *sbits = (u64 *)(L + (WANT_LLR ? (size_t)n * S : 0));   // [s]  bit sigma = syndrome entry parity
     u64 *ebits = sbits + s;                                     // [n]  bit sigma = hard decision
     u64 *red = ebits + n;                                       // [THREADS/64] + control words
-    int *row_ptr = (int *)(red + 64);                           // [s+1]  the graph, LDS copies
-    int *edge_bit = row_ptr + (s + 1);                          // [nnz]
-    int *col_ptr = edge_bit + nnz;                              // [n+1]
-    int *csc2csr = col_ptr + (n + 1);                           // [nnz]
+    typedef unsigned short idx_t;
+    idx_t *row_ptr = (idx_t *)(red + 64);                       // [s+1]  the graph, LDS copies
+    idx_t *edge_bit = row_ptr + (s + 1);                        // [nnz]
+    idx_t *col_ptr = edge_bit + nnz;                            // [n+1]
+    idx_t *csc2csr = col_ptr + (n + 1);                         // [nnz]
     __shared__ int sh_group;
-    for (int i = threadIdx.x; i <= s; i += THREADS) row_ptr[i] = g_row_ptr[i];
-    for (int i = threadIdx.x; i <= n; i += THREADS) col_ptr[i] = g_col_ptr[i];
-    for (int i = threadIdx.x; i < nnz; i += THREADS) { edge_bit[i] = g_edge_bit[i]; csc2csr[i] = g_csc2csr[i]; }
+    for (int i = threadIdx.x; i <= s; i += THREADS) row_ptr[i] = (idx_t)g_row_ptr[i];
+    for (int i = threadIdx.x; i <= n; i += THREADS) col_ptr[i] = (idx_t)g_col_ptr[i];
+    for (int i = threadIdx.x; i < nnz; i += THREADS) { edge_bit[i] = (idx_t)g_edge_bit[i]; csc2csr[i] = (idx_t)g_csc2csr[i]; }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     constexpr int W = THREADS / 64;
     const double r = p.r;

@@ -143,7 +143,7 @@ lds_kernel_t pick_lds_kernel(int dc, int dv, bool llr, int threads)
 int lds_logS(int64_t s, int64_t n, int64_t nnz, bool want_llr)
 {
     constexpr size_t kLds = 160 * 1024;
-    if (nnz > (1 << 20) || s > (1 << 20) || n > (1 << 20)) return -1;
+    if (nnz >= 65535 || s >= 65535 || n >= 65535) return -1;   // uint16 graph copies in LDS
     int best = -1;
     long best_total = 0, best_wgs = 0;
     for (int l = 0; l <= 6; ++l) {

@@ -95,3 +95,30 @@ class BeliefPropagationOSDDecoder(AbstractDecoder):
             bp.scratch.err[:] = err[-1]
             bp.scratch.log_probabs[:] = llr[-1]
         return errors, success
+
+    def batchdecode_device(self, syn, nthreads: int = 0):
+        """HBM-resident batch (BASELINE config 5 shape): `syn` is a [B][s] uint8 torch tensor on the
+        GPU.  BP runs on the device; only the syndromes that still need OSD travel to the host:
+        with osd_order = 0 a converged syndrome is returned unchanged by the reference's shortcut
+        (belief_propagation_osd.jl:66-74: zero residual), so its OSD call is skipped; with
+        osd_order > 0 every syndrome is post-processed, like the reference.
+        Returns (errors [B][n] uint8 tensor, converged [B] uint8 tensor, number sent to OSD)."""
+        import torch
+
+        bp = self.bp_decoder
+        B = int(syn.shape[0])
+        dev = syn.device
+        err = torch.empty((B, bp.n), dtype=torch.uint8, device=dev)
+        conv = torch.empty(B, dtype=torch.uint8, device=dev)
+        llr = torch.empty((B, bp.n), dtype=torch.float64, device=dev)
+        bp.decode_batch_device(syn, err, conv, llr, None)
+        if self.osd_order == 0:
+            idx = torch.nonzero(conv == 0, as_tuple=False).flatten()
+        else:
+            idx = torch.arange(B, device=dev)
+        k = int(idx.numel())
+        if k:
+            out = self._osd.postprocess(syn[idx].cpu().numpy(), err[idx].cpu().numpy(), llr[idx].cpu().numpy(),
+                                        nthreads=nthreads)
+            err[idx] = torch.from_numpy(out).to(dev)
+        return err, conv, k

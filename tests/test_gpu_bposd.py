@@ -84,3 +84,21 @@ def test_bposd_equals_oracle_chain_on_bb72(ldpc, gpu, order):
     # principle reorder columns -- none is expected on this workload
     assert mism == 0
     assert np.array_equal(ldpc.codes.syndromes_of(HX, guesses.T), syn)
+
+
+def test_device_resident_bposd_pipeline(ldpc, gpu):
+    """BASELINE configs[4] pipeline: HBM-resident syndromes -> BP on the GPU -> only what still needs
+    OSD goes to the host; must equal the plain host-buffer path column for column."""
+    import torch
+
+    HX, _ = ldpc.codes.bivariate_bicycle_72_12_6()
+    E = ldpc.codes.random_errors(72, 20000, 0.03, seed=5)
+    syn = ldpc.codes.syndromes_of(HX, E)
+    for order in (0, 2):
+        dec = ldpc.BeliefPropagationOSDDecoder(HX, 0.005, 50, osd_order=order)
+        ref = np.zeros((72, 20000), dtype=np.uint8)
+        ref, rconv = dec.batchdecode_(syn.T, ref)
+        err, conv, sent = dec.batchdecode_device(torch.from_numpy(syn).to("cuda:0"))
+        assert np.array_equal(err.cpu().numpy(), ref.T)
+        assert np.array_equal(conv.cpu().numpy().astype(bool), rconv)
+        assert sent == (20000 if order else int((~rconv).sum()))
