@@ -83,7 +83,9 @@ bp_kernel_t pick_threads(int threads)
 {
     switch (threads) {
     case 256: return bp_tile_kernel<DC, DV, LLR, 256>;
+    case 384: return bp_tile_kernel<DC, DV, LLR, 384>;
     case 512: return bp_tile_kernel<DC, DV, LLR, 512>;
+    case 768: return bp_tile_kernel<DC, DV, LLR, 768>;
     default: return bp_tile_kernel<DC, DV, LLR, 1024>;
     }
 }
@@ -164,8 +166,11 @@ struct ldpc_bp_decoder {
     int device = 0;
     int num_cus = 0;
     int max_cdeg = 0, max_bdeg = 0;
-    int threads = 512;        // waves_per_tile * 64
-    int resident_tiles = 0;   // workspace slots
+    int wpt_fixed = 0;        // waves per tile requested by the caller, 0 = chosen per batch
+    int resident_fixed = 0;   // workspace slots requested by the caller, 0 = fill the chip
+    int last_threads = 512, last_grid = 0;   // geometry of the most recent streaming launch (info)
+    size_t ws_budget = 0;     // bytes the message workspace may take
+    int blocks_cache[2][17];  // [want_llr][waves per tile] -> resident workgroups per CU, -1 = not queried yet
     int variant = 0;          // 0 auto, 1 HBM-streaming tile kernel, 2 LDS-resident kernel
     int lds_logS[2] = {-1, -1};   // [want_llr]: syndromes per workgroup pass of the LDS kernel, -1 = does not fit
     // device graph
@@ -299,14 +304,16 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
         return st;
     }
 
-    // geometry: waves per tile and number of workspace slots (persistent workgroups)
+    // geometry: waves per tile (fixed by the caller or chosen per batch) and the workspace budget
     int wpt = options ? options->waves_per_tile : 0;
-    if (wpt == 0) wpt = 8;
-    if (wpt != 4 && wpt != 8 && wpt != 16) {
+    if (wpt != 0 && wpt != 4 && wpt != 6 && wpt != 8 && wpt != 12 && wpt != 16) {
         delete d;
-        return fail(LDPC_ERR_INVALID_ARGUMENT, "waves_per_tile must be 0, 4, 8 or 16");
+        return fail(LDPC_ERR_INVALID_ARGUMENT, "waves_per_tile must be 0, 4, 6, 8, 12 or 16");
     }
-    d->threads = wpt * 64;
+    d->wpt_fixed = wpt;
+    d->resident_fixed = options ? std::max(options->resident_tiles, 0) : 0;
+    for (auto &row : d->blocks_cache)
+        for (int &v : row) v = -1;
     d->variant = options ? options->kernel_variant : 0;
     if (d->variant < 0 || d->variant > 2) { delete d; return fail(LDPC_ERR_INVALID_ARGUMENT, "kernel_variant must be 0, 1 or 2"); }
     d->lds_logS[0] = lds_logS(s, n, nnz, false);
@@ -315,25 +322,14 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
         delete d;
         return fail(LDPC_ERR_UNSUPPORTED, "kernel_variant 2 (LDS-resident) requested but the edge messages do not fit the LDS");
     }
-    bp_kernel_t kfn = pick_kernel(d->max_cdeg, d->max_bdeg, false, d->threads);
-    int blocks_per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, (const void *)kfn, d->threads, 0) != hipSuccess ||
-        blocks_per_cu <= 0) {
-        (void)hipGetLastError();
-        blocks_per_cu = 1;
-    }
-    int resident = options ? options->resident_tiles : 0;
-    if (resident <= 0) resident = blocks_per_cu * d->num_cus;
     // keep the workspace inside a sane share of HBM (slots are nnz*512 B each)
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-        size_t slot = (size_t)std::max<int64_t>(nnz, 1) * kTile * sizeof(double);
-        size_t budget = free_b / 2;
-        if ((size_t)resident * slot > budget) resident = (int)std::max<size_t>(budget / slot, 1);
+        d->ws_budget = free_b / 2;
     } else {
         (void)hipGetLastError();
+        d->ws_budget = (size_t)64 << 30;
     }
-    d->resident_tiles = resident;
     // the message workspace itself is allocated on first use, sized min(resident, tiles in the batch)
 
     if ((st = d->ctrl.ensure(64 * ldpc_bp_decoder::kRing)) != LDPC_OK) { delete d; return st; }
@@ -364,8 +360,8 @@ ldpc_status ldpc_bp_get_info(const ldpc_bp_decoder *d, ldpc_bp_info *info)
     std::memset(info, 0, sizeof *info);
     info->s = d->s; info->n = d->n; info->nnz = d->nnz; info->max_iters = d->max_iters; info->per = d->per;
     info->max_check_degree = d->max_cdeg; info->max_bit_degree = d->max_bdeg;
-    info->device = d->device; info->tile_syndromes = kTile; info->waves_per_tile = d->threads / 64;
-    info->resident_tiles = d->resident_tiles;
+    info->device = d->device; info->tile_syndromes = kTile; info->waves_per_tile = d->last_threads / 64;
+    info->resident_tiles = d->last_grid;
     const DevBuf *all[] = {&d->row_ptr, &d->edge_bit, &d->col_ptr, &d->csc2csr, &d->msg, &d->ctrl, &d->synmask,
                            &d->nevermask, &d->errmask, &d->llr_t, &d->st_syn, &d->st_err, &d->st_conv,
                            &d->st_llr, &d->st_iters};
@@ -413,10 +409,11 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
         lp.queue = (unsigned int *)ctrl;
         lp.sum_iters = (u64 *)(ctrl + 8);
         const size_t lds = lds_bytes_needed((int)s, (int)n, (int)d->nnz, 1 << logS, want_llr_early);
-        lds_kernel_t lk = pick_lds_kernel(d->max_cdeg, d->max_bdeg, want_llr_early, d->threads);
+        const int lthreads = (d->wpt_fixed == 4) ? 256 : (d->wpt_fixed >= 12 ? 1024 : 512);
+        lds_kernel_t lk = pick_lds_kernel(d->max_cdeg, d->max_bdeg, want_llr_early, lthreads);
         HIP_TRY(hipFuncSetAttribute((const void *)lk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)lk, d->threads, lds) != hipSuccess || per_cu <= 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)lk, lthreads, lds) != hipSuccess || per_cu <= 0) {
             (void)hipGetLastError();
             per_cu = 1;
         }
@@ -424,7 +421,7 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
         HIP_TRY(hipMemsetAsync(ctrl, 0, 64, stream));
         HIP_TRY(hipEventRecord(ev[0], stream));
         HIP_TRY(hipEventRecord(ev[1], stream));
-        hipLaunchKernelGGL(lk, dim3((unsigned)lgrid), dim3((unsigned)d->threads), lds, stream, lp,
+        hipLaunchKernelGGL(lk, dim3((unsigned)lgrid), dim3((unsigned)lthreads), lds, stream, lp,
                            (const int *)d->row_ptr.p, (const int *)d->edge_bit.p, (const int *)d->col_ptr.p,
                            (const int *)d->csc2csr.p);
         HIP_TRY(hipGetLastError());
@@ -445,7 +442,40 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
     if ((st = d->errmask.ensure(std::max<size_t>((size_t)ntiles * n, 1) * sizeof(u64))) != LDPC_OK) return st;
     if (want_llr && (st = d->llr_t.ensure(std::max<size_t>((size_t)ntiles * n, 1) * kTile * sizeof(double))) != LDPC_OK)
         return st;
-    const int grid = std::min(d->resident_tiles, ntiles);
+    // Geometry of this launch.  A tile's iterations are sequential, so the persistent grid works
+    // in ROUNDS of (workgroups per CU x CUs) tiles; a last round that is mostly empty runs the
+    // chip at a fraction of its occupancy.  Unless the caller fixed it, pick the waves-per-tile
+    // whose rounds are fullest (ties: most waves per CU, then 8 waves, the measured best).
+    int threads = 0, grid = 0;
+    {
+        const size_t slot_bytes = std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double);
+        const int max_slots = (int)std::max<size_t>(std::min<size_t>(d->ws_budget / slot_bytes, 1u << 30), 1);
+        const int cand[5] = {8, 6, 12, 4, 16};
+        double best_score = -1.0;
+        for (int c = 0; c < 5; ++c) {
+            const int wpt = cand[c];
+            if (d->wpt_fixed && wpt != d->wpt_fixed) continue;
+            int &bc = d->blocks_cache[want_llr ? 1 : 0][wpt];
+            if (bc < 0) {
+                bp_kernel_t kq = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, wpt * 64);
+                int nb = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kq, wpt * 64, 0) != hipSuccess || nb <= 0) {
+                    (void)hipGetLastError();
+                    nb = 1;
+                }
+                bc = nb;
+            }
+            int slots = d->resident_fixed ? d->resident_fixed : bc * d->num_cus;
+            slots = std::max(1, std::min(slots, max_slots));
+            const int rounds = (ntiles + slots - 1) / slots;
+            const double fill = (double)ntiles / ((double)rounds * slots);
+            const double waves_per_cu = std::min(24.0, (double)std::min(slots, ntiles) * wpt / d->num_cus);
+            const double score = fill * (0.5 + 0.5 * waves_per_cu / 24.0) - 0.001 * c;
+            if (score > best_score) { best_score = score; threads = wpt * 64; grid = std::min(slots, ntiles); }
+        }
+    }
+    d->last_threads = threads;
+    d->last_grid = grid;
     if ((st = d->msg.ensure((size_t)grid * std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double))) != LDPC_OK)
         return st;
 
@@ -470,9 +500,9 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
     p.queue = (unsigned int *)ctrl;
     p.sum_iters = (u64 *)(ctrl + 8);
     p.phase_ticks = (u64 *)(ctrl + 16);
-    bp_kernel_t kfn = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, d->threads);
+    bp_kernel_t kfn = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, threads);
     HIP_TRY(hipEventRecord(ev[1], stream));
-    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3((unsigned)d->threads), 0, stream, p,
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3((unsigned)threads), 0, stream, p,
                        (const int *)d->row_ptr.p, (const int *)d->edge_bit.p, (const int *)d->col_ptr.p,
                        (const int *)d->csc2csr.p, (const u64 *)d->synmask.p, (const u64 *)d->nevermask.p);
     HIP_TRY(hipGetLastError());
