@@ -43,6 +43,12 @@ constexpr int kTile = 64;  // syndromes per tile == wavefront width on gfx950
 #ifndef LDPC_NT          // 1 = non-temporal loads/stores for the streamed edge messages
 #define LDPC_NT 0
 #endif
+#ifndef LDPC_ROTATE      // 1 = every workgroup starts its sweeps at a different node (de-phases the workgroups)
+#define LDPC_ROTATE 0
+#endif
+#ifndef LDPC_SLOT_PAD    // bytes added to the workspace slot stride (breaks power-of-two slot strides)
+#define LDPC_SLOT_PAD 0
+#endif
 #ifndef LDPC_NBV         // bits handled per wave per step of the variable sweep (1 or 2)
 #define LDPC_NBV 1
 #endif
@@ -85,6 +91,7 @@ struct BPParams {
     double r;  // channel odds per/(1-per)   (belief_propagation.jl:129,153)
     // per-launch buffers
     double *msg;          // [slots][nnz][64]   workspace, slot = blockIdx.x
+    long long slot_stride;  // doubles between consecutive slots (>= nnz*64)
     u64 *errmask;         // [ntiles][n]
     double *llr;          // [ntiles][n][64] or nullptr
     int *iters;           // [batch] or nullptr
@@ -313,7 +320,11 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
     constexpr int W = THREADS / 64;
     const int s = p.s, n = p.n;
     const double r = p.r;
-    double *const Mt = p.msg + (size_t)blockIdx.x * (size_t)p.nnz * kTile + lane;
+    double *const Mt = p.msg + (size_t)blockIdx.x * (size_t)p.slot_stride + lane;
+#if LDPC_ROTATE
+    const int rot_c = s > 0 ? (int)((blockIdx.x * 2654435761u) % (unsigned)s) : 0;
+    const int rot_v = n > 0 ? (int)((blockIdx.x * 2246822519u) % (unsigned)n) : 0;
+#endif
 
     for (;;) {
         if (threadIdx.x == 0) sh_tile = (int)atomicAdd(p.queue, 1u);
@@ -338,7 +349,12 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
             const bool first = (it == 1);
             const u64 t0 = wall_clock64();
             // ---- check-node sweep  (:135-150)
-            for (int i = w; i < s; i += W) {
+            for (int i0 = w; i0 < s; i0 += W) {
+#if LDPC_ROTATE
+                const int i = (i0 + rot_c >= s) ? i0 + rot_c - s : i0 + rot_c;
+#else
+                const int i = i0;
+#endif
                 const int e0 = row_ptr[i];
                 const int deg = row_ptr[i + 1] - e0;
                 const double sigma = ((syn[i] >> lane) & 1ull) ? -1.0 : 1.0;  // (-1)^syndrome[i] :136
@@ -360,7 +376,12 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
                     em[j] = v;
                 }
             };
-            for (int j = w; j < n; j += W * LDPC_NBV) {
+            for (int j0 = w; j0 < n; j0 += W * LDPC_NBV) {
+#if LDPC_ROTATE
+                const int j = (j0 + rot_v >= n) ? j0 + rot_v - n : j0 + rot_v;
+#else
+                const int j = j0;
+#endif
                 const int c0 = col_ptr[j];
                 const int deg = col_ptr[j + 1] - c0;
 #if LDPC_NBV == 2

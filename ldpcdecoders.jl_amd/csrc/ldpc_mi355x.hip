@@ -442,41 +442,34 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
     if ((st = d->errmask.ensure(std::max<size_t>((size_t)ntiles * n, 1) * sizeof(u64))) != LDPC_OK) return st;
     if (want_llr && (st = d->llr_t.ensure(std::max<size_t>((size_t)ntiles * n, 1) * kTile * sizeof(double))) != LDPC_OK)
         return st;
-    // Geometry of this launch.  A tile's iterations are sequential, so the persistent grid works
-    // in ROUNDS of (workgroups per CU x CUs) tiles; a last round that is mostly empty runs the
-    // chip at a fraction of its occupancy.  Unless the caller fixed it, pick the waves-per-tile
-    // whose rounds are fullest (ties: most waves per CU, then 8 waves, the measured best).
+    // Geometry of this launch: 8 waves per tile (three workgroups per CU) is the measured best
+    // whenever there are more tiles than CUs -- also against geometries that make every tile
+    // resident at once (6 waves x 4 per CU: -10 %); with at most one tile per CU, 16 waves per
+    // tile put more of the chip to work.  The caller may fix it.
     int threads = 0, grid = 0;
     {
-        const size_t slot_bytes = std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double);
+        const size_t slot_bytes = std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double) + LDPC_SLOT_PAD;
         const int max_slots = (int)std::max<size_t>(std::min<size_t>(d->ws_budget / slot_bytes, 1u << 30), 1);
-        const int cand[5] = {8, 6, 12, 4, 16};
-        double best_score = -1.0;
-        for (int c = 0; c < 5; ++c) {
-            const int wpt = cand[c];
-            if (d->wpt_fixed && wpt != d->wpt_fixed) continue;
-            int &bc = d->blocks_cache[want_llr ? 1 : 0][wpt];
-            if (bc < 0) {
-                bp_kernel_t kq = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, wpt * 64);
-                int nb = 0;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kq, wpt * 64, 0) != hipSuccess || nb <= 0) {
-                    (void)hipGetLastError();
-                    nb = 1;
-                }
-                bc = nb;
+        const int wpt = d->wpt_fixed ? d->wpt_fixed : (ntiles <= d->num_cus ? 16 : 8);
+        int &bc = d->blocks_cache[want_llr ? 1 : 0][wpt];
+        if (bc < 0) {
+            bp_kernel_t kq = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, wpt * 64);
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kq, wpt * 64, 0) != hipSuccess || nb <= 0) {
+                (void)hipGetLastError();
+                nb = 1;
             }
-            int slots = d->resident_fixed ? d->resident_fixed : bc * d->num_cus;
-            slots = std::max(1, std::min(slots, max_slots));
-            const int rounds = (ntiles + slots - 1) / slots;
-            const double fill = (double)ntiles / ((double)rounds * slots);
-            const double waves_per_cu = std::min(24.0, (double)std::min(slots, ntiles) * wpt / d->num_cus);
-            const double score = fill * (0.5 + 0.5 * waves_per_cu / 24.0) - 0.001 * c;
-            if (score > best_score) { best_score = score; threads = wpt * 64; grid = std::min(slots, ntiles); }
+            bc = nb;
         }
+        int slots = d->resident_fixed ? d->resident_fixed : bc * d->num_cus;
+        slots = std::max(1, std::min(slots, max_slots));
+        threads = wpt * 64;
+        grid = std::min(slots, ntiles);
     }
     d->last_threads = threads;
     d->last_grid = grid;
-    if ((st = d->msg.ensure((size_t)grid * std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double))) != LDPC_OK)
+    const size_t slot_stride_bytes = std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double) + LDPC_SLOT_PAD;
+    if ((st = d->msg.ensure((size_t)grid * slot_stride_bytes)) != LDPC_OK)
         return st;
 
     HIP_TRY(hipMemsetAsync(ctrl, 0, 64, stream));
@@ -493,6 +486,7 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
     p.ntiles = ntiles; p.batch = batch;
     p.r = d->per / (1 - d->per);  // belief_propagation.jl:129,153 (IEEE double division, same on host)
     p.msg = (double *)d->msg.p;
+    p.slot_stride = (long long)(slot_stride_bytes / sizeof(double));
     p.errmask = (u64 *)d->errmask.p;
     p.llr = want_llr ? (double *)d->llr_t.p : nullptr;
     p.iters = d_iters;
