@@ -36,6 +36,23 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def pmc_traffic(workload):
+    """HBM bytes per launch of the sweep kernel from the committed rocprofv3 PMC passes
+    (profiles/*_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction applied).  bench.py
+    cannot collect counters itself; the number is only reported for the workload it was taken on."""
+    import glob
+
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+        try:
+            t = json.load(open(f))
+        except Exception:
+            continue
+        if t.get("workload") == workload:
+            best = t
+    return (best["traffic_bytes_per_launch"], os.path.basename(best["source"].split(" ")[0])) if best else (None, None)
+
+
 def make_syndromes(torch, H_csr, n, batch, per, seed, device):
     """Bernoulli(per) errors and their syndromes, generated on the device (synthetic data)."""
     g = torch.Generator(device=device)
@@ -201,7 +218,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(args.workload)[0] if (not args.batch and world == 1) else None,
+                "traffic_source": pmc_traffic(args.workload)[1],
                 "alg_bytes_per_launch": alg_bytes,
                 "kernel_ms": sweep_ms,
                 "pack_sweep_unpack_ms": total_ms,
