@@ -75,3 +75,31 @@ def test_constructor_type_checks():
         ldpc.BeliefPropagationDecoder(H, 1, 10)        # per::Float64
     with pytest.raises(TypeError):
         ldpc.BeliefPropagationDecoder(H, 0.1, 10.0)    # max_iters::Int
+
+
+def _build_driver(tmp_path):
+    import subprocess
+
+    exe = str(tmp_path / "abi_driver")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "abi_driver.c"), "-o", exe,
+                           ldpc._capi.LIB_PATH, "-Wl,-rpath," + os.path.dirname(ldpc._capi.LIB_PATH)])
+    return exe
+
+
+def test_header_is_valid_c_and_links_from_a_c_host(tmp_path):
+    """include/ldpc_mi355x.h compiles as C99 and a plain-C program links against the library."""
+    import subprocess
+
+    exe = _build_driver(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+
+
+@pytest.mark.gpu
+def test_c_host_decodes_on_the_gpu(tmp_path, gpu):
+    import subprocess
+
+    exe = _build_driver(tmp_path)
+    out = subprocess.run([exe, "gpu"], capture_output=True, text=True)
+    assert out.returncode == 0 and "gpu ok" in out.stdout, (out.returncode, out.stdout, out.stderr)
