@@ -181,7 +181,9 @@ struct ldpc_bp_decoder {
     // per-batch buffers (grow only)
     DevBuf synmask, nevermask, errmask, llr_t;
     // staging for the host-pointer entry
-    DevBuf st_syn, st_err, st_conv, st_llr, st_iters;
+    DevBuf st_syn, st_err, st_conv, st_llr, st_iters, st_all;
+    void *pin = nullptr;      // pinned host image for small batches
+    size_t pin_cap = 0;
     // timing ring: the last kRing batch calls keep their HIP events and iteration sums
     static constexpr int kRing = 16;
     hipEvent_t ev[kRing][4] = {};
@@ -191,8 +193,9 @@ struct ldpc_bp_decoder {
     ~ldpc_bp_decoder()
     {
         DevBuf *all[] = {&row_ptr, &edge_bit, &col_ptr, &csc2csr, &msg, &ctrl, &synmask, &nevermask,
-                         &errmask, &llr_t, &st_syn, &st_err, &st_conv, &st_llr, &st_iters};
+                         &errmask, &llr_t, &st_syn, &st_err, &st_conv, &st_llr, &st_iters, &st_all};
         for (DevBuf *b : all) b->release();
+        if (pin) (void)hipHostFree(pin);
         for (auto &slot : ev)
             for (hipEvent_t &e : slot)
                 if (e) (void)hipEventDestroy(e);
@@ -528,12 +531,41 @@ ldpc_status ldpc_bp_decode_batch(ldpc_bp_decoder *d, int64_t batch, const uint8_
     HIP_TRY(hipSetDevice(d->device));
     const size_t s = (size_t)d->s, n = (size_t)d->n, B = (size_t)batch;
     ldpc_status st;
+    hipStream_t stream = nullptr;
+    // Small batches (decode! is batch = 1): one pinned staging image, ONE copy in and ONE copy out
+    // instead of five pageable transfers -- the call is latency-bound, not bandwidth-bound.
+    {
+        auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        const size_t o_err = up(B * s), o_conv = o_err + up(B * n), o_it = o_conv + up(B),
+                     o_llr = o_it + up(B * sizeof(int32_t)), total = o_llr + (llr ? up(B * n * sizeof(double)) : 0);
+        if (total <= ((size_t)4 << 20)) {
+            if ((st = d->st_all.ensure(total)) != LDPC_OK) return st;
+            if (d->pin_cap < total) {
+                if (d->pin) (void)hipHostFree(d->pin);
+                d->pin = nullptr; d->pin_cap = 0;
+                HIP_TRY(hipHostMalloc(&d->pin, total, hipHostMallocDefault));
+                d->pin_cap = total;
+            }
+            char *hp = (char *)d->pin, *dp = (char *)d->st_all.p;
+            std::memcpy(hp, syn, B * s);
+            if (s > 0) HIP_TRY(hipMemcpyAsync(dp, hp, B * s, hipMemcpyHostToDevice, stream));
+            st = ldpc_bp_decode_batch_device(d, batch, (const uint8_t *)dp, (uint8_t *)(dp + o_err), (uint8_t *)(dp + o_conv),
+                                             llr ? (double *)(dp + o_llr) : nullptr, (int32_t *)(dp + o_it), stream);
+            if (st != LDPC_OK) return st;
+            HIP_TRY(hipMemcpyAsync(hp + o_err, dp + o_err, total - o_err, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            std::memcpy(err, hp + o_err, B * n);
+            std::memcpy(conv, hp + o_conv, B);
+            if (iters) std::memcpy(iters, hp + o_it, B * sizeof(int32_t));
+            if (llr) std::memcpy(llr, hp + o_llr, B * n * sizeof(double));
+            return LDPC_OK;
+        }
+    }
     if ((st = d->st_syn.ensure(std::max<size_t>(B * s, 1))) != LDPC_OK) return st;
     if ((st = d->st_err.ensure(std::max<size_t>(B * n, 1))) != LDPC_OK) return st;
     if ((st = d->st_conv.ensure(B)) != LDPC_OK) return st;
     if (llr && (st = d->st_llr.ensure(std::max<size_t>(B * n, 1) * sizeof(double))) != LDPC_OK) return st;
     if (iters && (st = d->st_iters.ensure(B * sizeof(int32_t))) != LDPC_OK) return st;
-    hipStream_t stream = nullptr;
     if (s > 0) HIP_TRY(hipMemcpyAsync(d->st_syn.p, syn, B * s, hipMemcpyHostToDevice, stream));
     st = ldpc_bp_decode_batch_device(d, batch, (const uint8_t *)d->st_syn.p, (uint8_t *)d->st_err.p,
                                      (uint8_t *)d->st_conv.p, llr ? (double *)d->st_llr.p : nullptr,
