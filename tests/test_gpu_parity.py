@@ -178,3 +178,13 @@ def test_device_resident_entry(ldpc, gpu):
     assert np.array_equal(llr[~fin], ollr[~fin]) and np.max(np.abs(llr[fin] - ollr[fin])) <= LLR_TOL
     sweep_ms, total_ms, sum_iters = dec.last_timing()
     assert sum_iters == int(oits.sum()) and 0 < sweep_ms <= total_ms
+
+
+def test_degenerate_shapes(ldpc, gpu):
+    """No checks at all, no edges at all, a single bit: the loops of decode! simply do not run."""
+    rng = np.random.default_rng(11)
+    for shape, dens in [((0, 5), 0.0), ((4, 6), 0.0), ((1, 1), 1.0), ((3, 1), 1.0)]:
+        H = sp.csc_matrix((rng.random(shape) < dens).astype(np.uint8)) if dens < 1 else sp.csc_matrix(np.ones(shape, dtype=np.uint8))
+        syn = rng.integers(0, 2, (70, shape[0])).astype(np.uint8)
+        for per in (0.1, 0.7):
+            assert_parity(ldpc, H, per, 5, syn)
