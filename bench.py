@@ -30,6 +30,12 @@ WORKLOADS = {
     "c3_full50": (16384, 8, 4, 65536, 0.10, 50),
     "c3_realistic": (16384, 8, 4, 65536, 0.02, 50),
     "c2_n1008": (1008, 6, 3, 4096, 0.01, 50),
+    # the code of the reference's own tests and benchmark suite (test/test_bp_decoder.jl:7,
+    # benchmark/benchmarks.jl:8-11): (9,10)-regular n=1000, per 0.01, 100 iterations
+    "ref_1000_10_9": (1000, 10, 9, 65536, 0.01, 100),
+    "ref_1000_10_9_hard": (1000, 10, 9, 65536, 0.06, 100),
+    # a large code with wider nodes (row weight 10, column weight 5): the 16-wide register bucket
+    "wide_16000_10_5": (16000, 10, 5, 32768, 0.10, 50),
     # BASELINE configs[4]: BB [[72,12,6]] H_X, BP on the GPU + OSD-0 on the host for what BP leaves
     "c5_bb72_bposd": (72, 6, 3, 1048576, 0.005, 50),
 }

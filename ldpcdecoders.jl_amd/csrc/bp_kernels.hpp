@@ -60,7 +60,10 @@ template <int DC, int DV, int THREADS>
 constexpr int min_waves_per_simd()
 {
     constexpr int one_block = THREADS / 256;  // waves per SIMD of a single workgroup
-    int want = (DC <= 8 && DV <= 4) ? LDPC_MIN_WAVES : (DC <= 16 ? 4 : 2);
+#ifndef LDPC_MIN_WAVES_MID
+#define LDPC_MIN_WAVES_MID 3  // 16-wide bucket: 159 VGPRs, no scratch (4 would spill 96 B/lane; same speed, HBM-bound)
+#endif
+    int want = (DC <= 8 && DV <= 4) ? LDPC_MIN_WAVES : (DC <= 16 ? LDPC_MIN_WAVES_MID : 2);
     if (want < one_block) want = one_block;
     if (THREADS >= 1024 && want > 4) want = 4;
     return want;
