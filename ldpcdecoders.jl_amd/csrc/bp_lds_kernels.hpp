@@ -17,6 +17,15 @@
 #pragma once
 #include "bp_kernels.hpp"
 
+#ifndef LDPC_LDS_STAMPS  // 1 = diagnostic build: in-kernel phase stamps (check / variable / rest)
+#define LDPC_LDS_STAMPS 0
+#endif
+#if LDPC_LDS_STAMPS
+#define LDS_CLOCK() wall_clock64()
+#else
+#define LDS_CLOCK() 0ull
+#endif
+
 namespace ldpc {
 
 struct LdsParams {
@@ -24,6 +33,8 @@ struct LdsParams {
     int max_iters;
     int logS;             // S = 1 << logS syndromes per workgroup pass
     int ngroups;          // ceil(batch / S)
+    int chunk;            // groups taken from the queue per dequeue (one same-address atomic costs ~11 ns
+                          // chip-wide: a dequeue per group would cap the kernel at ~88 groups/us)
     long long batch;
     double r;
     const unsigned char *syn;   // [batch][s]
@@ -33,6 +44,7 @@ struct LdsParams {
     double *llr;                // [batch][n] or nullptr
     unsigned int *queue;
     u64 *sum_iters;
+    u64 *phase_ticks;     // [3] 100 MHz ticks: check sweep, variable sweep, everything else (I/O, test, barriers)
 };
 
 // LDS carve-up (bytes), shared by host and device
@@ -164,11 +176,20 @@ bp_lds_kernel(LdsParams p, const int *__restrict__ g_row_ptr, const int *__restr
     const u64 maskS = (S == 64) ? ~0ull : ((1ull << S) - 1ull);
     const int sig = tid & (S - 1);                              // this lane's syndrome slot (THREADS % S == 0)
 
+    u64 acc_iters = 0, acc_check = 0, acc_var = 0, acc_rest = 0;   // per workgroup, flushed once at exit
+    int g_next = 0, g_end = 0;                                    // the chunk of groups this workgroup holds
     for (;;) {
-        if (tid == 0) sh_group = (int)atomicAdd(p.queue, 1u);
-        __syncthreads();
-        const int g = sh_group;
-        if (g >= p.ngroups) break;
+        if (g_next >= g_end) {
+            if (tid == 0) sh_group = (int)atomicAdd(p.queue, (unsigned)p.chunk);
+            __syncthreads();
+            g_next = sh_group;
+            g_end = min(g_next + p.chunk, p.ngroups);
+            __syncthreads();
+            if (g_next >= p.ngroups) break;   // every wave of every workgroup reaches this
+        }
+        const int g = g_next++;
+        const u64 tg0 = LDS_CLOCK();
+        u64 tk_check = 0, tk_var = 0;
         const long long b0 = (long long)g << logS;
         const long long left = p.batch - b0;
         const u64 valid = left >= S ? maskS : ((1ull << left) - 1ull);
@@ -200,6 +221,7 @@ bp_lds_kernel(LdsParams p, const int *__restrict__ g_row_ptr, const int *__restr
         while (active != 0 && it < p.max_iters) {
             ++it;
             const bool first = (it == 1);
+            const u64 t0 = LDS_CLOCK();
             // ---- check sweep: unit u = (check u >> logS, syndrome u & (S-1))
             for (int u = tid; u < (s << logS); u += THREADS) {
                 const int i = u >> logS;
@@ -209,6 +231,7 @@ bp_lds_kernel(LdsParams p, const int *__restrict__ g_row_ptr, const int *__restr
                 lds_check_unit<DC>(M + (size_t)e0 * S + sig, S, deg, sigma, first, r);
             }
             __syncthreads();
+            const u64 t1 = LDS_CLOCK();
             // ---- variable sweep
             for (int u0 = w * 64; u0 < (n << logS); u0 += THREADS) {
                 const int u = u0 + lane;
@@ -232,6 +255,9 @@ bp_lds_kernel(LdsParams p, const int *__restrict__ g_row_ptr, const int *__restr
                 }
             }
             __syncthreads();
+            const u64 t2 = LDS_CLOCK();
+            tk_check += t1 - t0;
+            tk_var += t2 - t1;
             // ---- convergence test (:180-184): one thread per check
             u64 mism = 0;
             for (int i = tid; i < s; i += THREADS) {
@@ -271,9 +297,23 @@ bp_lds_kernel(LdsParams p, const int *__restrict__ g_row_ptr, const int *__restr
             int tot = (tid < S && ((valid >> tid) & 1ull)) ? my_iters : 0;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
-            if (lane == 0) atomicAdd(p.sum_iters, (u64)tot);
+            if (lane == 0) {
+                const u64 tg1 = LDS_CLOCK();
+                acc_iters += (u64)tot;
+                acc_check += tk_check;
+                acc_var += tk_var;
+                acc_rest += (tg1 - tg0) - tk_check - tk_var;
+            }
         }
         __syncthreads();
+    }
+    if (tid == 0) {
+        atomicAdd(p.sum_iters, acc_iters);
+        if (LDPC_LDS_STAMPS) {
+            atomicAdd(&p.phase_ticks[0], acc_check);
+            atomicAdd(&p.phase_ticks[1], acc_var);
+            atomicAdd(&p.phase_ticks[2], acc_rest);
+        }
     }
 }
 

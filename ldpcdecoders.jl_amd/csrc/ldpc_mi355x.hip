@@ -411,6 +411,7 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
         lp.syn = d_syn; lp.err = d_err; lp.conv = d_conv; lp.iters = d_iters; lp.llr = d_llr;
         lp.queue = (unsigned int *)ctrl;
         lp.sum_iters = (u64 *)(ctrl + 8);
+        lp.phase_ticks = (u64 *)(ctrl + 16);
         const size_t lds = lds_bytes_needed((int)s, (int)n, (int)d->nnz, 1 << logS, want_llr_early);
         const int lthreads = (d->wpt_fixed == 4) ? 256 : (d->wpt_fixed >= 12 ? 1024 : 512);
         lds_kernel_t lk = pick_lds_kernel(d->max_cdeg, d->max_bdeg, want_llr_early, lthreads);
@@ -421,6 +422,8 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
             per_cu = 1;
         }
         const int lgrid = (int)std::min<int64_t>(ngroups64, (int64_t)per_cu * d->num_cus);
+        // dequeue in chunks: ~16 dequeues per workgroup keep the load balanced and the queue word quiet
+        lp.chunk = (int)std::max<int64_t>(1, std::min<int64_t>(64, ngroups64 / ((int64_t)lgrid * 16)));
         HIP_TRY(hipMemsetAsync(ctrl, 0, 64, stream));
         HIP_TRY(hipEventRecord(ev[0], stream));
         HIP_TRY(hipEventRecord(ev[1], stream));
