@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--waves-per-tile", type=int, default=0)
     ap.add_argument("--resident-tiles", type=int, default=0)
     ap.add_argument("--kernel-variant", type=int, default=0, help="0 auto, 1 HBM-streaming, 2 LDS-resident")
+    ap.add_argument("--defer-threshold", type=int, default=0, help="0 auto (16), -1 off (streaming kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -142,7 +143,7 @@ def main():
     nnz = int(H.nnz)
     dec = ldpc.BeliefPropagationDecoder(H, per, max_iters, device=local_rank,
                                         waves_per_tile=args.waves_per_tile, resident_tiles=args.resident_tiles,
-                                        kernel_variant=args.kernel_variant)
+                                        kernel_variant=args.kernel_variant, defer_threshold=args.defer_threshold)
     syn = make_syndromes(torch, H.tocsr(), n, batch, per, seed=1234 + rank, device=device)
     err = torch.empty((batch, n), dtype=torch.uint8, device=device)
     conv = torch.empty(batch, dtype=torch.uint8, device=device)

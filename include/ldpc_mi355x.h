@@ -66,7 +66,10 @@ typedef struct ldpc_bp_options {
     int32_t resident_tiles;   /* 0 = auto (fills the chip) */
     int32_t kernel_variant;   /* 0 = auto (LDS-resident kernel when the edge messages fit the LDS, else the
                                  HBM-streaming tile kernel); 1 = force streaming; 2 = force LDS-resident */
-    int32_t reserved[12];
+    int32_t defer_threshold;  /* HBM-streaming kernel: a 64-syndrome tile hands its unconverged syndromes to a
+                                 densely packed second pass once at most this many are left (same results,
+                                 fewer nearly-empty sweeps).  0 = auto (16), -1 = off, else 1..48 */
+    int32_t reserved[11];
 } ldpc_bp_options;
 
 /* Library / ABI version and build target ("gfx950"). */

@@ -66,7 +66,7 @@ class BPOptions(ctypes.Structure):
     _fields_ = [
         ("device", ctypes.c_int32), ("waves_per_tile", ctypes.c_int32),
         ("resident_tiles", ctypes.c_int32), ("kernel_variant", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 12),
+        ("defer_threshold", ctypes.c_int32), ("reserved", ctypes.c_int32 * 11),
     ]
 
 

@@ -103,6 +103,15 @@ struct BPParams {
     u64 *sum_iters;       // accumulated iterations executed
     u64 *phase_ticks;     // [3] 100 MHz ticks spent in check sweep / variable sweep / convergence test,
                           //     summed over workgroups (wave 0 of each; diagnostics for DESIGN.md)
+    // Straggler hand-off (DESIGN.md "early exit"): a tile whose active lanes have dwindled to
+    // <= defer_thresh gives those syndromes up; they are appended to defer_list and decoded again
+    // from scratch, densely packed, by a second pass (index / count_dev describe that pass).
+    int defer_thresh;           // 0 = never give up (second pass, or feature off)
+    int defer_min_iter;         // do not give up before this many iterations
+    int *defer_list;            // [<= ntiles*defer_thresh] batch positions handed to the second pass
+    unsigned int *defer_count;  // number of entries in defer_list
+    const int *index;           // second pass: batch position of compact syndrome q (nullptr in the first pass)
+    const unsigned int *count_dev;  // second pass: number of compact syndromes (device word; nullptr = p.batch)
 };
 
 __device__ __forceinline__ u64 wave_or(u64 v)
@@ -329,16 +338,20 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
     const int rot_v = n > 0 ? (int)((blockIdx.x * 2246822519u) % (unsigned)n) : 0;
 #endif
 
+    const long long batch = p.count_dev ? (long long)*p.count_dev : p.batch;
+    const int ntiles = p.count_dev ? (int)((batch + kTile - 1) / kTile) : p.ntiles;
+
     for (;;) {
         if (threadIdx.x == 0) sh_tile = (int)atomicAdd(p.queue, 1u);
         __syncthreads();
         const int tile = sh_tile;
-        if (tile >= p.ntiles) break;  // every wave of every workgroup reaches this
+        if (tile >= ntiles) break;  // every wave of every workgroup reaches this
 
         const u64 *syn = synmask + (size_t)tile * s;
         u64 *em = p.errmask + (size_t)tile * n;
         const long long b0 = (long long)tile * kTile;
-        const long long left = p.batch - b0;
+        const long long left = batch - b0;
+        u64 deferred = 0;
         const u64 valid = left >= kTile ? ~0ull : ((1ull << left) - 1ull);
         const u64 never = nevermask[tile];
         u64 active = valid;
@@ -438,12 +451,26 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
             active &= U;
             const u64 t3 = wall_clock64();
             tk_check += t1 - t0; tk_var += t2 - t1; tk_conv += t3 - t2;
+            // few stragglers left: hand them to the second pass instead of sweeping a nearly empty tile
+            if (p.defer_thresh != 0 && active != 0 && it >= p.defer_min_iter && it < p.max_iters &&
+                __popcll(active) <= p.defer_thresh) {
+                if (w == 0) {
+                    unsigned base = 0;
+                    if (lane == 0) base = atomicAdd(p.defer_count, (unsigned)__popcll(active));
+                    base = __shfl(base, 0, 64);
+                    if ((active >> lane) & 1ull)
+                        p.defer_list[base + __popcll(active & ((1ull << lane) - 1ull))] = (int)(b0 + lane);
+                }
+                deferred = active;
+                active = 0;
+            }
         }
         if ((active >> lane) & 1ull) { my_iters = it; my_conv = 0; }
         if (w == 0) {
-            if ((valid >> lane) & 1ull) {
-                p.conv[b0 + lane] = (unsigned char)my_conv;
-                if (p.iters) p.iters[b0 + lane] = my_iters;
+            if (((valid & ~deferred) >> lane) & 1ull) {
+                const long long ob = p.index ? (long long)p.index[b0 + lane] : b0 + lane;
+                p.conv[ob] = (unsigned char)my_conv;
+                if (p.iters) p.iters[ob] = my_iters;
             } else {
                 my_iters = 0;
             }
@@ -466,18 +493,23 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
 // pack: syndromes uint8 [batch][s]  ->  lane masks synmask[tile][s] (+ nevermask)
 // one wave per (tile, 64 checks); lane = check.
 // ---------------------------------------------------------------------------
+// index / count_dev (both nullptr in the first pass): compact syndrome q of the second pass is
+// syndrome index[q] of the batch, and there are *count_dev of them.
 __global__ void __launch_bounds__(64) pack_syndromes_kernel(const unsigned char *syn, long long batch,
-                                                            int s, u64 *synmask, u64 *nevermask)
+                                                            int s, u64 *synmask, u64 *nevermask,
+                                                            const int *index, const unsigned int *count_dev)
 {
+    if (count_dev) batch = (long long)*count_dev;
     const int tile = blockIdx.y;
     const int i = blockIdx.x * 64 + threadIdx.x;
     const long long b0 = (long long)tile * kTile;
+    if (b0 >= batch) return;
     const int rows = (int)((batch - b0) < kTile ? (batch - b0) : kTile);
     u64 m = 0, hi = 0;
     if (i < s) {
-        const unsigned char *p = syn + (size_t)b0 * s + i;
         for (int rr = 0; rr < rows; ++rr) {
-            unsigned v = p[(size_t)rr * s];
+            const long long b = index ? (long long)index[b0 + rr] : b0 + rr;
+            unsigned v = syn[(size_t)b * s + i];
             m |= (u64)(v & 1u) << rr;
             hi |= (u64)(v > 1u) << rr;
         }
@@ -489,33 +521,44 @@ __global__ void __launch_bounds__(64) pack_syndromes_kernel(const unsigned char 
 
 // unpack: errmask[tile][n] -> errors uint8 [batch][n]; one wave per (tile, 64 bits)
 __global__ void __launch_bounds__(64) unpack_errors_kernel(const u64 *errmask, long long batch, int n,
-                                                           unsigned char *errors)
+                                                           unsigned char *errors, const int *index,
+                                                           const unsigned int *count_dev)
 {
+    if (count_dev) batch = (long long)*count_dev;
     const int tile = blockIdx.y;
     const int j = blockIdx.x * 64 + threadIdx.x;
     const long long b0 = (long long)tile * kTile;
+    if (b0 >= batch) return;
     const int rows = (int)((batch - b0) < kTile ? (batch - b0) : kTile);
     if (j >= n) return;
     const u64 m = errmask[(size_t)tile * n + j];
-    unsigned char *o = errors + (size_t)b0 * n + j;
-    for (int rr = 0; rr < rows; ++rr) o[(size_t)rr * n] = (unsigned char)((m >> rr) & 1ull);
+    for (int rr = 0; rr < rows; ++rr) {
+        const long long b = index ? (long long)index[b0 + rr] : b0 + rr;
+        errors[(size_t)b * n + j] = (unsigned char)((m >> rr) & 1ull);
+    }
 }
 
 // llr transpose: llr_t[tile][n][64] -> llr[batch][n]; 64x64 tile through LDS
 __global__ void __launch_bounds__(256) unpack_llr_kernel(const double *llr_t, long long batch, int n,
-                                                         double *llr)
+                                                         double *llr, const int *index,
+                                                         const unsigned int *count_dev)
 {
     __shared__ double t[64][65];
+    if (count_dev) batch = (long long)*count_dev;
     const int tile = blockIdx.y;
     const int j0 = blockIdx.x * 64;
     const long long b0 = (long long)tile * kTile;
+    if (b0 >= batch) return;   // uniform for the whole workgroup
     const int rows = (int)((batch - b0) < kTile ? (batch - b0) : kTile);
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int jj = ty; jj < 64; jj += 4)
         if (j0 + jj < n) t[jj][tx] = llr_t[((size_t)tile * n + j0 + jj) * kTile + tx];
     __syncthreads();
     for (int rr = ty; rr < rows; rr += 4)
-        if (j0 + tx < n) llr[(size_t)(b0 + rr) * n + j0 + tx] = t[tx][rr];
+        if (j0 + tx < n) {
+            const long long b = index ? (long long)index[b0 + rr] : b0 + rr;
+            llr[(size_t)b * n + j0 + tx] = t[tx][rr];
+        }
 }
 
 }  // namespace ldpc

@@ -180,6 +180,9 @@ struct ldpc_bp_decoder {
     DevBuf ctrl;              // queue (u32) + sum_iters (u64), 64 B
     // per-batch buffers (grow only)
     DevBuf synmask, nevermask, errmask, llr_t;
+    // second pass of the straggler hand-off
+    DevBuf defer_list, synmask2, nevermask2, errmask2, llr_t2;
+    int defer_thresh = 0;     // 0 auto (16 lanes), -1 off, else the lane count at which a tile gives up
     // staging for the host-pointer entry
     DevBuf st_syn, st_err, st_conv, st_llr, st_iters, st_all;
     void *pin = nullptr;      // pinned host image for small batches
@@ -193,7 +196,8 @@ struct ldpc_bp_decoder {
     ~ldpc_bp_decoder()
     {
         DevBuf *all[] = {&row_ptr, &edge_bit, &col_ptr, &csc2csr, &msg, &ctrl, &synmask, &nevermask,
-                         &errmask, &llr_t, &st_syn, &st_err, &st_conv, &st_llr, &st_iters, &st_all};
+                         &errmask, &llr_t, &st_syn, &st_err, &st_conv, &st_llr, &st_iters, &st_all,
+                         &defer_list, &synmask2, &nevermask2, &errmask2, &llr_t2};
         for (DevBuf *b : all) b->release();
         if (pin) (void)hipHostFree(pin);
         for (auto &slot : ev)
@@ -315,6 +319,8 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     }
     d->wpt_fixed = wpt;
     d->resident_fixed = options ? std::max(options->resident_tiles, 0) : 0;
+    d->defer_thresh = options ? options->defer_threshold : 0;
+    if (d->defer_thresh > 48 || d->defer_thresh < -1) { delete d; return fail(LDPC_ERR_INVALID_ARGUMENT, "defer_threshold must be -1, 0 or 1..48"); }
     for (auto &row : d->blocks_cache)
         for (int &v : row) v = -1;
     d->variant = options ? options->kernel_variant : 0;
@@ -478,13 +484,32 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
     if ((st = d->msg.ensure((size_t)grid * slot_stride_bytes)) != LDPC_OK)
         return st;
 
+    // Straggler hand-off (two passes): in the first pass a tile gives up the syndromes that are
+    // still unconverged once at most `thresh` of its 64 lanes are active; the second pass decodes
+    // them again from scratch, densely packed (same arithmetic => same results), instead of
+    // sweeping nearly empty tiles for the remaining iterations.  Everything stays on the stream:
+    // the second pass reads its syndrome count from device memory.
+    const int thresh = (d->defer_thresh < 0 || d->max_iters < 4 || ntiles < 2) ? 0 : (d->defer_thresh ? d->defer_thresh : 16);
+    const int ntiles2 = thresh ? (int)(((int64_t)ntiles * thresh + kTile - 1) / kTile) + 1 : 0;
+    if (thresh) {
+        if ((st = d->defer_list.ensure((size_t)ntiles2 * kTile * sizeof(int))) != LDPC_OK) return st;
+        if ((st = d->synmask2.ensure(std::max<size_t>((size_t)ntiles2 * s, 1) * sizeof(u64))) != LDPC_OK) return st;
+        if ((st = d->nevermask2.ensure((size_t)ntiles2 * sizeof(u64))) != LDPC_OK) return st;
+        if ((st = d->errmask2.ensure(std::max<size_t>((size_t)ntiles2 * n, 1) * sizeof(u64))) != LDPC_OK) return st;
+        if (want_llr && (st = d->llr_t2.ensure(std::max<size_t>((size_t)ntiles2 * n, 1) * kTile * sizeof(double))) != LDPC_OK)
+            return st;
+        HIP_TRY(hipMemsetAsync(d->nevermask2.p, 0, (size_t)ntiles2 * sizeof(u64), stream));
+    }
+    unsigned int *defer_count = (unsigned int *)(ctrl + 4);
+
     HIP_TRY(hipMemsetAsync(ctrl, 0, 64, stream));
     HIP_TRY(hipMemsetAsync(d->nevermask.p, 0, (size_t)ntiles * sizeof(u64), stream));
     HIP_TRY(hipEventRecord(ev[0], stream));
     if (s > 0) {
         dim3 g((unsigned)((s + 63) / 64), (unsigned)ntiles);
         hipLaunchKernelGGL(pack_syndromes_kernel, g, dim3(64), 0, stream, d_syn, (long long)batch, (int)s,
-                           (u64 *)d->synmask.p, (u64 *)d->nevermask.p);
+                           (u64 *)d->synmask.p, (u64 *)d->nevermask.p, (const int *)nullptr,
+                           (const unsigned int *)nullptr);
         HIP_TRY(hipGetLastError());
     }
     BPParams p;
@@ -500,22 +525,63 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
     p.queue = (unsigned int *)ctrl;
     p.sum_iters = (u64 *)(ctrl + 8);
     p.phase_ticks = (u64 *)(ctrl + 16);
+    p.defer_thresh = thresh;
+    p.defer_min_iter = 2;
+    p.defer_list = (int *)d->defer_list.p;
+    p.defer_count = defer_count;
+    p.index = nullptr;
+    p.count_dev = nullptr;
     bp_kernel_t kfn = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, threads);
     HIP_TRY(hipEventRecord(ev[1], stream));
     hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3((unsigned)threads), 0, stream, p,
                        (const int *)d->row_ptr.p, (const int *)d->edge_bit.p, (const int *)d->col_ptr.p,
                        (const int *)d->csc2csr.p, (const u64 *)d->synmask.p, (const u64 *)d->nevermask.p);
     HIP_TRY(hipGetLastError());
+    if (thresh) {
+        // second pass over the handed-off syndromes (grids sized for the worst case, blocks past the
+        // device-side count return at once)
+        if (s > 0) {
+            dim3 g((unsigned)((s + 63) / 64), (unsigned)ntiles2);
+            hipLaunchKernelGGL(pack_syndromes_kernel, g, dim3(64), 0, stream, d_syn, (long long)0, (int)s,
+                               (u64 *)d->synmask2.p, (u64 *)d->nevermask2.p, (const int *)d->defer_list.p,
+                               (const unsigned int *)defer_count);
+            HIP_TRY(hipGetLastError());
+        }
+        BPParams p2 = p;
+        p2.errmask = (u64 *)d->errmask2.p;
+        p2.llr = want_llr ? (double *)d->llr_t2.p : nullptr;
+        p2.queue = (unsigned int *)(ctrl + 40);
+        p2.defer_thresh = 0;
+        p2.index = (const int *)d->defer_list.p;
+        p2.count_dev = defer_count;
+        hipLaunchKernelGGL(kfn, dim3((unsigned)std::min(grid, ntiles2)), dim3((unsigned)threads), 0, stream, p2,
+                           (const int *)d->row_ptr.p, (const int *)d->edge_bit.p, (const int *)d->col_ptr.p,
+                           (const int *)d->csc2csr.p, (const u64 *)d->synmask2.p, (const u64 *)d->nevermask2.p);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipEventRecord(ev[2], stream));
     if (n > 0) {
         dim3 g((unsigned)((n + 63) / 64), (unsigned)ntiles);
         hipLaunchKernelGGL(unpack_errors_kernel, g, dim3(64), 0, stream, (const u64 *)d->errmask.p,
-                           (long long)batch, (int)n, d_err);
+                           (long long)batch, (int)n, d_err, (const int *)nullptr, (const unsigned int *)nullptr);
         HIP_TRY(hipGetLastError());
         if (want_llr) {
             hipLaunchKernelGGL(unpack_llr_kernel, g, dim3(256), 0, stream, (const double *)d->llr_t.p,
-                               (long long)batch, (int)n, d_llr);
+                               (long long)batch, (int)n, d_llr, (const int *)nullptr, (const unsigned int *)nullptr);
             HIP_TRY(hipGetLastError());
+        }
+        if (thresh) {   // the second pass overwrites the rows the first pass gave up
+            dim3 g2((unsigned)((n + 63) / 64), (unsigned)ntiles2);
+            hipLaunchKernelGGL(unpack_errors_kernel, g2, dim3(64), 0, stream, (const u64 *)d->errmask2.p,
+                               (long long)0, (int)n, d_err, (const int *)d->defer_list.p,
+                               (const unsigned int *)defer_count);
+            HIP_TRY(hipGetLastError());
+            if (want_llr) {
+                hipLaunchKernelGGL(unpack_llr_kernel, g2, dim3(256), 0, stream, (const double *)d->llr_t2.p,
+                                   (long long)0, (int)n, d_llr, (const int *)d->defer_list.p,
+                                   (const unsigned int *)defer_count);
+                HIP_TRY(hipGetLastError());
+            }
         }
     }
     HIP_TRY(hipEventRecord(ev[3], stream));

@@ -95,7 +95,8 @@ class BeliefPropagationDecoder(AbstractDecoder):
     """
 
     def __init__(self, H, per: float, max_iters: int, *, device: Optional[int] = None,
-                 waves_per_tile: int = 0, resident_tiles: int = 0, kernel_variant: int = 0):
+                 waves_per_tile: int = 0, resident_tiles: int = 0, kernel_variant: int = 0,
+                 defer_threshold: int = 0):
         if not isinstance(per, float):
             raise TypeError("per must be a Float64 (reference signature: per::Float64)")
         if isinstance(max_iters, bool) or not isinstance(max_iters, (int, np.integer)):
@@ -115,6 +116,7 @@ class BeliefPropagationDecoder(AbstractDecoder):
         opts.waves_per_tile = int(waves_per_tile)
         opts.resident_tiles = int(resident_tiles)
         opts.kernel_variant = int(kernel_variant)   # 0 auto, 1 HBM-streaming, 2 LDS-resident
+        opts.defer_threshold = int(defer_threshold)  # 0 auto (16), -1 off: straggler hand-off of the streaming kernel
         self._h = ctypes.c_void_p()
         L = _capi.lib()
         _capi.check(L.ldpc_bp_create(self.s, self.n, int(self._rowval.size), self._colptr.ctypes.data,
