@@ -113,6 +113,9 @@ def main():
     ap.add_argument("--kernel-variant", type=int, default=0, help="0 auto, 1 HBM-streaming, 2 LDS-resident")
     ap.add_argument("--defer-threshold", type=int, default=0, help="0 auto (16), -1 off (streaming kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # rehearsal of the N>1 control flow on a box with fewer GPUs than ranks (never used by the driver):
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="all ranks share cuda:0 and synchronise over gloo instead of RCCL")
     args = ap.parse_args()
 
     import torch
@@ -123,10 +126,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)   # RCCL over xGMI
 
     import ldpcdecoders_jl_amd as ldpc
 
@@ -186,7 +194,7 @@ def main():
     total_ms = sum(t[1] for t in per_call) / k
     sum_iters = per_call[0][2]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
