@@ -156,16 +156,23 @@ class BeliefPropagationDecoder(AbstractDecoder):
         return int(t[0]), int(t[1]), int(t[2])
 
     # -- raw ABI calls ------------------------------------------------------
-    def decode_batch_host(self, syn_bs: np.ndarray, want_llr: bool = False, want_iters: bool = False):
-        """syn_bs: [B][s] uint8 C-contiguous.  Returns (errors [B][n] u8, converged [B] u8, llr|None, iters|None)."""
+    def decode_batch_host(self, syn_bs: np.ndarray, want_llr: bool = False, want_iters: bool = False, out=None):
+        """syn_bs: [B][s] uint8 C-contiguous.  Returns (errors [B][n] u8, converged [B] u8, llr|None, iters|None).
+        `out` = (errors, converged) preallocated C-contiguous uint8 arrays to write into (a caller that
+        reuses its buffers, like Julia's batchdecode!, avoids fresh-page faults on every call)."""
         syn_bs = np.ascontiguousarray(syn_bs, dtype=np.uint8)
         B = int(syn_bs.shape[0])
         if syn_bs.ndim != 2 or syn_bs.shape[1] != self.s:
             raise AssertionError("syndrome length does not match the number of checks")
-        err = np.zeros((B, self.n), dtype=np.uint8)
-        conv = np.zeros(B, dtype=np.uint8)
-        llr = np.zeros((B, self.n), dtype=np.float64) if want_llr else None
-        its = np.zeros(B, dtype=np.int32) if want_iters else None
+        if out is not None:
+            err, conv = out
+            assert err.dtype == np.uint8 and err.flags.c_contiguous and err.shape == (B, self.n)
+            assert conv.dtype == np.uint8 and conv.flags.c_contiguous and conv.shape == (B,)
+        else:
+            err = np.empty((B, self.n), dtype=np.uint8)   # every byte is written by the library
+            conv = np.empty(B, dtype=np.uint8)
+        llr = np.empty((B, self.n), dtype=np.float64) if want_llr else None
+        its = np.empty(B, dtype=np.int32) if want_iters else None
         _capi.check(_capi.lib().ldpc_bp_decode_batch(
             self._h, B, syn_bs.ctypes.data, err.ctypes.data, conv.ctypes.data,
             llr.ctypes.data if want_llr else None, its.ctypes.data if want_iters else None))
