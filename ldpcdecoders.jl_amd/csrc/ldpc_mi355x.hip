@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -681,7 +682,9 @@ ldpc_status ldpc_bp_decode_batch(ldpc_bp_decoder *d, int64_t batch, const uint8_
         auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
         const size_t bps = s + n + 1 + sizeof(int32_t) + (llr ? n * sizeof(double) : 0);   // bytes per syndrome
         const bool lds_path = d->variant != 1 && d->lds_logS[llr ? 1 : 0] >= 0;
-        size_t cb = ((size_t)24 << 20) / std::max<size_t>(bps, 1);
+        size_t chunk_mb = 24;
+        if (const char *e = std::getenv("LDPC_PIPE_CHUNK_MB")) chunk_mb = std::max<long>(1, std::atol(e));
+        size_t cb = (chunk_mb << 20) / std::max<size_t>(bps, 1);
         cb = std::max<size_t>(cb, lds_path ? 32768 : 65536);      // enough syndromes to fill the chip
         cb = (cb + 4095) & ~(size_t)4095;
         if (B < cb + cb / 2) cb = B;                               // no tiny trailing chunk
