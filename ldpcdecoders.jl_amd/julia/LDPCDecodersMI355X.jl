@@ -19,7 +19,7 @@ using SparseArrays
 import LDPCDecoders
 import LDPCDecoders: AbstractDecoder, decode!, batchdecode!, reset!
 
-export MI355XBeliefPropagationDecoder
+export MI355XBeliefPropagationDecoder, MI355XBeliefPropagationOSDDecoder
 
 const libldpc = get(ENV, "LDPC_MI355X_LIB", "libldpc_mi355x.so")
 
@@ -137,5 +137,74 @@ end
 
 # 3-argument form: the generic method at abstract_decoder.jl:44-48 allocates `success`
 # and re-dispatches to the 4-argument method above; nothing to add.
+
+# ---------------------------------------------------------------------------------------------
+# BP+OSD (src/decoders/belief_propagation_osd.jl).  The reference's BeliefPropagationOSDDecoder
+# holds a concretely typed `bp_decoder::BeliefPropagationDecoder` (:19), so the MI355X decoder
+# cannot be slotted into it; this type mirrors it: BP on the GPU, the ordered-statistics step in
+# the library's host code (`ldpc_osd_postprocess_batch`, bit-packed, threaded over the batch).
+# ---------------------------------------------------------------------------------------------
+mutable struct MI355XBeliefPropagationOSDDecoder <: AbstractDecoder
+    bp_decoder::MI355XBeliefPropagationDecoder
+    H::BitMatrix
+    osd_order::Int
+    osd_handle::Ptr{Cvoid}
+end
+
+function MI355XBeliefPropagationOSDDecoder(H::BitMatrix, per::Float64, max_iters::Int;
+                                           osd_order::Int=0, device::Integer=-1)     # :26-29
+    bp = MI355XBeliefPropagationDecoder(H, per, max_iters; device=device)
+    colptr = Int64.(bp.sparse_H.colptr .- 1); rowval = Int64.(rowvals(bp.sparse_H) .- 1)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:ldpc_osd_create, libldpc), Cint,
+                (Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Int64, Ptr{Ptr{Cvoid}}),
+                bp.s, bp.n, length(rowval), colptr, rowval, osd_order, h))
+    d = MI355XBeliefPropagationOSDDecoder(bp, H, osd_order, h[])
+    finalizer(d) do x
+        x.osd_handle != C_NULL && ccall((:ldpc_osd_destroy, libldpc), Cint, (Ptr{Cvoid},), x.osd_handle)
+        x.osd_handle = C_NULL
+    end
+    return d
+end
+
+function decode!(d::MI355XBeliefPropagationOSDDecoder, syndrome::AbstractVector)      # :49-61
+    bp = d.bp_decoder
+    bp_err, converged = decode!(bp, syndrome)              # fills bp.syn_u8, bp.err_u8, scratch.log_probabs
+    out = Vector{UInt8}(undef, bp.n)
+    check(ccall((:ldpc_osd_postprocess_batch, libldpc), Cint,
+                (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{UInt8}, Ptr{Float64}, Ptr{UInt8}, Int32),
+                d.osd_handle, 1, bp.syn_u8, bp.err_u8, bp.scratch.log_probabs, out, 1))
+    return Bool.(out), converged                           # a Bool vector, like :60
+end
+
+function batchdecode!(d::MI355XBeliefPropagationOSDDecoder, syndromes::AbstractMatrix,
+                      errors::AbstractMatrix, success::AbstractVector{Bool})
+    # one BP launch + one threaded OSD pass give the same columns as the reference's generic
+    # per-column loop (abstract_decoder.jl:31-42, test_bposd_decoder.jl:49-57)
+    @assert size(syndromes, 2) == size(errors, 2)
+    @assert size(syndromes, 2) == length(success)
+    bp = d.bp_decoder
+    B = size(syndromes, 2)
+    B == 0 && return errors, success
+    resize!(bp.syn_u8, bp.s * B); resize!(bp.err_u8, bp.n * B); resize!(bp.conv_u8, B)
+    @inbounds for i in 1:B, r in 1:bp.s
+        bp.syn_u8[(i - 1) * bp.s + r] = syndrome_byte(syndromes[r, i])
+    end
+    llr = Vector{Float64}(undef, bp.n * B)
+    check(ccall((:ldpc_bp_decode_batch, libldpc), Cint,
+                (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{UInt8}, Ptr{UInt8}, Ptr{Float64}, Ptr{Int32}),
+                bp.handle, B, bp.syn_u8, bp.err_u8, bp.conv_u8, llr, C_NULL))
+    out = Vector{UInt8}(undef, bp.n * B)
+    check(ccall((:ldpc_osd_postprocess_batch, libldpc), Cint,
+                (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{UInt8}, Ptr{Float64}, Ptr{UInt8}, Int32),
+                d.osd_handle, B, bp.syn_u8, bp.err_u8, llr, out, 0))
+    @inbounds for i in 1:B
+        success[i] = bp.conv_u8[i] != 0
+        for j in 1:bp.n
+            errors[j, i] = out[(i - 1) * bp.n + j]
+        end
+    end
+    return errors, success
+end
 
 end # module
