@@ -172,6 +172,33 @@ ldpc_status ldpc_osd_postprocess_batch(const ldpc_osd *osd, int64_t batch, const
                                        const uint8_t *bp_errors, const double *llr, uint8_t *errors,
                                        int32_t nthreads);
 
+/* ------------------------------------------------------------------------
+ * BP-OTS decoder: LLR-domain tanh/atanh BP with oscillation-driven prior biasing.
+ * LDS-resident kernel only: graphs whose messages fit one CU's LDS (every code of the reference's
+ * BP-OTS tests); larger ones return LDPC_ERR_UNSUPPORTED.
+ * ------------------------------------------------------------------------ */
+typedef struct ldpc_bpots_decoder ldpc_bpots_decoder;
+
+/* Replaces `BPOTSDecoder(H, per, max_iters; T=9, C=2.0)` (src/decoders/bpots_decoder.jl:39-115);
+ * H as the zero-based CSC pattern, like ldpc_bp_create.  device < 0: current device. */
+ldpc_status ldpc_bpots_create(int64_t s, int64_t n, int64_t nnz, const int64_t *colptr,
+                              const int64_t *rowval, double per, int64_t max_iters, int64_t T, double C,
+                              int32_t device, ldpc_bpots_decoder **out);
+ldpc_status ldpc_bpots_destroy(ldpc_bpots_decoder *dec);
+
+/* Replaces `decode!(decoder::BPOTSDecoder, syndrome)` (:225-340, with its `reset!` :142-154) for a
+ * batch, i.e. the generic `batchdecode!` (abstract_decoder.jl:31-48) over it.  HOST buffers.
+ *   syndromes [batch][s] uint8 : a non-zero entry flips the check's sign (:195); entries other than
+ *                                0/1 can never be matched (:273)
+ *   errors    [batch][n] uint8 : `best_decisions` (:340), converged [batch] : a zero-mismatch
+ *   estimate was found (:290), iters [batch] int32 (may be NULL): iterations executed (extension). */
+ldpc_status ldpc_bpots_decode_batch(ldpc_bpots_decoder *dec, int64_t batch, const uint8_t *syndromes,
+                                    uint8_t *errors, uint8_t *converged, int32_t *iters);
+/* Same with DEVICE pointers, asynchronous on `stream`. */
+ldpc_status ldpc_bpots_decode_batch_device(ldpc_bpots_decoder *dec, int64_t batch, const uint8_t *d_syndromes,
+                                           uint8_t *d_errors, uint8_t *d_converged, int32_t *d_iters,
+                                           void *stream);
+
 /* Diagnostics: 100 MHz ticks spent in {check sweep, variable sweep, convergence test}
  * of that call, summed over workgroups (one sampling wave each). */
 ldpc_status ldpc_bp_call_phase_ticks(ldpc_bp_decoder *dec, int32_t calls_back, uint64_t ticks[3]);

@@ -23,9 +23,10 @@ from .decoder import (  # noqa: F401
 )
 
 from .osd import BeliefPropagationOSDDecoder, OSDPostProcessor  # noqa: F401,E402
+from .bpots import BPOTSDecoder  # noqa: F401,E402
 
 __all__ = [
-    "BeliefPropagationOSDDecoder", "OSDPostProcessor",
+    "BeliefPropagationOSDDecoder", "OSDPostProcessor", "BPOTSDecoder",
     "decode_", "batchdecode_", "reset_", "AbstractDecoder", "BeliefPropagationDecoder",
     "BeliefPropagationScratchSpace", "parity_check_matrix", "save_pcm", "load_pcm",
     "LdpcError", "build", "codes", "syndrome_bytes",

@@ -41,6 +41,10 @@ EXPORTED_SYMBOLS = (
     "ldpc_osd_create",
     "ldpc_osd_destroy",
     "ldpc_osd_postprocess_batch",
+    "ldpc_bpots_create",
+    "ldpc_bpots_destroy",
+    "ldpc_bpots_decode_batch",
+    "ldpc_bpots_decode_batch_device",
 )
 
 
@@ -72,7 +76,8 @@ class BPOptions(ctypes.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("ldpc_mi355x.hip", "osd_host.cpp", "bp_kernels.hpp", "bp_lds_kernels.hpp", "Makefile")]
+    srcs = [os.path.join(CSRC, f) for f in ("ldpc_mi355x.hip", "ldpc_bpots.hip", "osd_host.cpp", "bp_kernels.hpp", "bp_lds_kernels.hpp",
+                                             "bpots_kernels.hpp", "portable_math.h", "Makefile")]
     srcs.append(os.path.join(_HERE, "..", "include", "ldpc_mi355x.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(
         os.path.getmtime(f) > os.path.getmtime(LIB_PATH) for f in srcs if os.path.exists(f))
@@ -135,6 +140,14 @@ def lib() -> ctypes.CDLL:
     L.ldpc_osd_destroy.argtypes = [vp]
     L.ldpc_osd_postprocess_batch.restype = i32
     L.ldpc_osd_postprocess_batch.argtypes = [vp, i64, vp, vp, vp, vp, i32]
+    L.ldpc_bpots_create.restype = i32
+    L.ldpc_bpots_create.argtypes = [i64, i64, i64, vp, vp, f64, i64, i64, f64, i32, ctypes.POINTER(vp)]
+    L.ldpc_bpots_destroy.restype = i32
+    L.ldpc_bpots_destroy.argtypes = [vp]
+    L.ldpc_bpots_decode_batch.restype = i32
+    L.ldpc_bpots_decode_batch.argtypes = [vp, i64, vp, vp, vp, vp]
+    L.ldpc_bpots_decode_batch_device.restype = i32
+    L.ldpc_bpots_decode_batch_device.argtypes = [vp, i64, vp, vp, vp, vp, vp]
     _LIB = L
     return L
 

@@ -1,0 +1,219 @@
+// ldpc_bpots.hip -- host side of the BP-OTS decoder: the ldpc_bpots_* entry points
+// of include/ldpc_mi355x.h.  Replaces BPOTSDecoder / decode! / batchdecode! of
+// src/decoders/bpots_decoder.jl:39-115, 225-340.  Device code: bpots_kernels.hpp.
+// LDS-resident only: the graph must be small enough for one CU's LDS (every code of the reference's
+// BP-OTS tests is); larger graphs get LDPC_ERR_UNSUPPORTED.  No CPU path.
+#include "../../include/ldpc_mi355x.h"
+#include "bpots_kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace ldpc;
+
+namespace ldpc_detail {
+ldpc_status set_error(ldpc_status st, const std::string &msg);
+}
+using ldpc_detail::set_error;
+
+#define OTS_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            (void)hipGetLastError();                                                         \
+            return set_error(e_ == hipErrorOutOfMemory ? LDPC_ERR_OUT_OF_MEMORY : LDPC_ERR_HIP, \
+                             std::string(#expr) + ": " + hipGetErrorString(e_));             \
+        }                                                                                    \
+    } while (0)
+
+struct ldpc_bpots_decoder {
+    int64_t s = 0, n = 0, nnz = 0, max_iters = 0, T = 9;
+    double per = 0.0, C = 2.0;
+    int device = 0, num_cus = 0, logS = 0, max_cdeg = 0, max_bdeg = 0;
+    int *row_ptr = nullptr, *csc_row = nullptr, *col_ptr = nullptr, *csc2csr = nullptr;
+    unsigned int *queue = nullptr;
+    void *stage = nullptr;      // device staging for the host-pointer entry
+    size_t stage_cap = 0;
+    ~ldpc_bpots_decoder()
+    {
+        void *all[] = {row_ptr, csc_row, col_ptr, csc2csr, queue, stage};
+        for (void *q : all)
+            if (q) (void)hipFree(q);
+    }
+};
+
+typedef void (*ots_kernel_t)(OtsParams, const int *, const int *, const int *, const int *);
+
+static ots_kernel_t pick_ots(int dc, int dv)
+{
+    if (dc <= 8) return dv <= 4 ? bpots_lds_kernel<8, 4> : bpots_lds_kernel<8, 16>;
+    return dv <= 4 ? bpots_lds_kernel<32, 4> : bpots_lds_kernel<32, 16>;
+}
+
+extern "C" {
+
+ldpc_status ldpc_bpots_create(int64_t s, int64_t n, int64_t nnz, const int64_t *colptr, const int64_t *rowval,
+                              double per, int64_t max_iters, int64_t T, double C, int32_t device,
+                              ldpc_bpots_decoder **out)
+{
+    if (!out) return set_error(LDPC_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    if (s < 0 || n < 0 || nnz < 0 || !colptr || (nnz > 0 && !rowval) || max_iters < 0 || max_iters > INT32_MAX)
+        return set_error(LDPC_ERR_INVALID_ARGUMENT, "bad dimensions / NULL pattern / max_iters");
+    if (T < 1) return set_error(LDPC_ERR_INVALID_ARGUMENT, "T must be >= 1 (iter % T, bpots_decoder.jl:295)");
+    if (colptr[0] != 0 || colptr[n] != nnz) return set_error(LDPC_ERR_INVALID_ARGUMENT, "colptr is not a zero-based CSC pointer array");
+    for (int64_t j = 0; j < n; ++j) {
+        if (colptr[j + 1] < colptr[j]) return set_error(LDPC_ERR_INVALID_ARGUMENT, "colptr is not non-decreasing");
+        for (int64_t k = colptr[j]; k < colptr[j + 1]; ++k) {
+            if (rowval[k] < 0 || rowval[k] >= s) return set_error(LDPC_ERR_INVALID_ARGUMENT, "rowval entry outside [0, s)");
+            if (k > colptr[j] && rowval[k] <= rowval[k - 1])
+                return set_error(LDPC_ERR_INVALID_ARGUMENT, "row indices must be strictly ascending inside each column");
+        }
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return set_error(LDPC_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    }
+    if (device < 0) OTS_TRY(hipGetDevice(&device));
+    if (device >= ndev) return set_error(LDPC_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    OTS_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    OTS_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_error(LDPC_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+
+    ldpc_bpots_decoder *d = new (std::nothrow) ldpc_bpots_decoder();
+    if (!d) return set_error(LDPC_ERR_OUT_OF_MEMORY, "host allocation failed");
+    d->s = s; d->n = n; d->nnz = nnz; d->max_iters = max_iters; d->T = T; d->per = per; d->C = C;
+    d->device = device; d->num_cus = prop.multiProcessorCount;
+    std::vector<int> row_ptr((size_t)s + 1, 0), col_ptr((size_t)n + 1), csc2csr((size_t)std::max<int64_t>(nnz, 1)),
+        csc_row((size_t)std::max<int64_t>(nnz, 1));
+    for (int64_t k = 0; k < nnz; ++k) row_ptr[(size_t)rowval[k] + 1]++;
+    for (int64_t i = 0; i < s; ++i) {
+        d->max_cdeg = std::max(d->max_cdeg, row_ptr[(size_t)i + 1]);
+        row_ptr[(size_t)i + 1] += row_ptr[(size_t)i];
+    }
+    {
+        std::vector<int> fill(row_ptr.begin(), row_ptr.end() - 1);
+        for (int64_t j = 0; j < n; ++j) {
+            col_ptr[(size_t)j] = (int)colptr[j];
+            d->max_bdeg = std::max(d->max_bdeg, (int)(colptr[j + 1] - colptr[j]));
+            for (int64_t k = colptr[j]; k < colptr[j + 1]; ++k) {
+                csc2csr[(size_t)k] = fill[(size_t)rowval[k]]++;
+                csc_row[(size_t)k] = (int)rowval[k];
+            }
+        }
+        col_ptr[(size_t)n] = (int)nnz;
+    }
+    if (d->max_cdeg > 32 || d->max_bdeg > 16 || nnz >= 65535 || s >= 65535 || n >= 65535) {
+        delete d;
+        return set_error(LDPC_ERR_UNSUPPORTED, "BP-OTS kernel: check degree <= 32, bit degree <= 16 and a graph that fits the LDS");
+    }
+    d->logS = -1;
+    for (int l = 0; l <= 6; ++l) {
+        const size_t b = ots_lds_bytes((int)s, (int)n, (int)nnz, 1 << l) + 8192;
+        if (b <= (size_t)76 * 1024 || (d->logS < 0 && b <= (size_t)156 * 1024)) d->logS = l;
+        else if (b > (size_t)156 * 1024) break;
+    }
+    if (d->logS < 0) {
+        delete d;
+        return set_error(LDPC_ERR_UNSUPPORTED, "BP-OTS kernel: the graph's messages do not fit the LDS");
+    }
+    auto up = [&](int *&dst, const std::vector<int> &v) -> bool {
+        if (hipMalloc((void **)&dst, std::max<size_t>(v.size(), 1) * sizeof(int)) != hipSuccess) return false;
+        return hipMemcpy(dst, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
+    };
+    if (!up(d->row_ptr, row_ptr) || !up(d->csc_row, csc_row) || !up(d->col_ptr, col_ptr) || !up(d->csc2csr, csc2csr) ||
+        hipMalloc((void **)&d->queue, 64) != hipSuccess) {
+        (void)hipGetLastError();
+        delete d;
+        return set_error(LDPC_ERR_OUT_OF_MEMORY, "device allocation of the Tanner graph failed");
+    }
+    *out = d;
+    return LDPC_OK;
+}
+
+ldpc_status ldpc_bpots_destroy(ldpc_bpots_decoder *d)
+{
+    if (!d) return LDPC_OK;
+    (void)hipSetDevice(d->device);
+    (void)hipDeviceSynchronize();
+    delete d;
+    return LDPC_OK;
+}
+
+ldpc_status ldpc_bpots_decode_batch_device(ldpc_bpots_decoder *d, int64_t batch, const uint8_t *d_syn, uint8_t *d_err,
+                                           uint8_t *d_conv, int32_t *d_iters, void *stream_v)
+{
+    if (!d) return set_error(LDPC_ERR_INVALID_ARGUMENT, "decoder is NULL");
+    if (batch < 0) return set_error(LDPC_ERR_INVALID_ARGUMENT, "negative batch");
+    if (batch == 0) return LDPC_OK;
+    if ((d->s > 0 && !d_syn) || (d->n > 0 && !d_err) || !d_conv) return set_error(LDPC_ERR_INVALID_ARGUMENT, "NULL batch pointer");
+    hipStream_t stream = (hipStream_t)stream_v;
+    OTS_TRY(hipSetDevice(d->device));
+    if (d->max_iters == 0) {   // the loop at :239 never runs: best_decisions = 0, converged = false
+        if (d->n > 0) OTS_TRY(hipMemsetAsync(d_err, 0, (size_t)batch * d->n, stream));
+        OTS_TRY(hipMemsetAsync(d_conv, 0, (size_t)batch, stream));
+        if (d_iters) OTS_TRY(hipMemsetAsync(d_iters, 0, (size_t)batch * sizeof(int32_t), stream));
+        return LDPC_OK;
+    }
+    const int64_t ngroups = (batch + (1ll << d->logS) - 1) >> d->logS;
+    if (ngroups > (1ll << 30)) return set_error(LDPC_ERR_UNSUPPORTED, "batch too large for one call");
+    OtsParams p;
+    p.s = (int)d->s; p.n = (int)d->n; p.nnz = (int)d->nnz; p.max_iters = (int)d->max_iters; p.T = (int)d->T;
+    p.logS = d->logS; p.ngroups = (int)ngroups; p.batch = batch;
+    p.prior = std::log((1 - (2 * d->per / 3)) / (2 * d->per / 3));   // bpots_decoder.jl:231
+    p.C = d->C;
+    p.syn = d_syn; p.err = d_err; p.conv = d_conv; p.iters = d_iters; p.queue = d->queue;
+    const size_t lds = ots_lds_bytes((int)d->s, (int)d->n, (int)d->nnz, 1 << d->logS);
+    ots_kernel_t k = pick_ots(d->max_cdeg, d->max_bdeg);
+    OTS_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k, kOtsThreads, lds) != hipSuccess || per_cu <= 0) {
+        (void)hipGetLastError();
+        per_cu = 1;
+    }
+    const int grid = (int)std::min<int64_t>(ngroups, (int64_t)per_cu * d->num_cus);
+    p.chunk = (int)std::max<int64_t>(1, std::min<int64_t>(64, ngroups / ((int64_t)grid * 16)));
+    OTS_TRY(hipMemsetAsync(d->queue, 0, 64, stream));
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kOtsThreads), lds, stream, p, (const int *)d->row_ptr,
+                       (const int *)d->csc_row, (const int *)d->col_ptr, (const int *)d->csc2csr);
+    OTS_TRY(hipGetLastError());
+    return LDPC_OK;
+}
+
+ldpc_status ldpc_bpots_decode_batch(ldpc_bpots_decoder *d, int64_t batch, const uint8_t *syn, uint8_t *err,
+                                    uint8_t *conv, int32_t *iters)
+{
+    if (!d) return set_error(LDPC_ERR_INVALID_ARGUMENT, "decoder is NULL");
+    if (batch < 0) return set_error(LDPC_ERR_INVALID_ARGUMENT, "negative batch");
+    if (batch == 0) return LDPC_OK;
+    if ((d->s > 0 && !syn) || (d->n > 0 && !err) || !conv) return set_error(LDPC_ERR_INVALID_ARGUMENT, "NULL batch pointer");
+    OTS_TRY(hipSetDevice(d->device));
+    const size_t s = (size_t)d->s, n = (size_t)d->n, B = (size_t)batch;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_err = up(B * s), o_conv = o_err + up(B * n), o_it = o_conv + up(B), total = o_it + up(B * 4);
+    if (d->stage_cap < total) {
+        if (d->stage) (void)hipFree(d->stage);
+        d->stage = nullptr; d->stage_cap = 0;
+        OTS_TRY(hipMalloc(&d->stage, total));
+        d->stage_cap = total;
+    }
+    char *dp = (char *)d->stage;
+    if (s > 0) OTS_TRY(hipMemcpyAsync(dp, syn, B * s, hipMemcpyHostToDevice, nullptr));
+    ldpc_status st = ldpc_bpots_decode_batch_device(d, batch, (const uint8_t *)dp, (uint8_t *)(dp + o_err),
+                                                    (uint8_t *)(dp + o_conv), (int32_t *)(dp + o_it), nullptr);
+    if (st != LDPC_OK) return st;
+    if (n > 0) OTS_TRY(hipMemcpyAsync(err, dp + o_err, B * n, hipMemcpyDeviceToHost, nullptr));
+    OTS_TRY(hipMemcpyAsync(conv, dp + o_conv, B, hipMemcpyDeviceToHost, nullptr));
+    if (iters) OTS_TRY(hipMemcpyAsync(iters, dp + o_it, B * 4, hipMemcpyDeviceToHost, nullptr));
+    OTS_TRY(hipStreamSynchronize(nullptr));
+    return LDPC_OK;
+}
+
+}  // extern "C"

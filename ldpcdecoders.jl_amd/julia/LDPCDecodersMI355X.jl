@@ -11,8 +11,9 @@
 #   batchdecode!(decoder, syndromes, errors[, success])   :220-231, abstract_decoder.jl:44-48
 #
 # so that `MI355XBeliefPropagationDecoder <: LDPCDecoders.AbstractDecoder` is a drop-in
-# wherever a BeliefPropagationDecoder is used, including inside BeliefPropagationOSDDecoder
-# (which reads `decoder.scratch.log_probabs`, belief_propagation_osd.jl:52).
+# wherever an AbstractDecoder is accepted (generic batchdecode!, QuantumClifford's extension).
+# BP+OSD gets its own mirror type below (the reference's OSD decoder stores a concretely typed
+# BeliefPropagationDecoder and reads `scratch.log_probabs`, belief_propagation_osd.jl:19,52).
 module LDPCDecodersMI355X
 
 using SparseArrays

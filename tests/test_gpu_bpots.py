@@ -1,0 +1,122 @@
+"""BP-OTS on the MI355X (ldpc_bpots_*, LDS-resident kernel) against the CPU oracle: estimates,
+convergence flags and iteration counts must be identical (both sides use the portable tanh/atanh),
+plus the reference's own assertions from test/test_bpots.jl through the host mirror."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import BPOTSOracle
+
+pytestmark = pytest.mark.gpu
+
+
+def cycle_matrix(n):                       # test_bpots.jl:13-24
+    H = np.zeros((n, n), dtype=np.uint8)
+    for j in range(n):
+        H[j, (j + 1) % n] = 1
+        H[j, j] = 1
+    return H
+
+
+def toric_x(d):
+    H = np.zeros((d * d, 2 * d * d), dtype=np.uint8)
+    for r in range(d):
+        for c in range(d):
+            v = r * d + c
+            H[v, r * d + c] = 1
+            H[v, r * d + (c - 1) % d] = 1
+            H[v, d * d + r * d + c] = 1
+            H[v, d * d + ((r - 1) % d) * d + c] = 1
+    return H
+
+
+def assert_same_as_oracle(ldpc, H, per, iters, T, C, syn):
+    M = sp.csc_matrix(H)
+    M.sort_indices()
+    oerr, oconv, oits = BPOTSOracle((M.indptr, M.indices), M.shape, per, iters, T, C).batchdecode(syn)
+    dec = ldpc.BPOTSDecoder(M, per, iters, T=T, C=C)
+    err, conv, its = dec.decode_batch_host(syn)
+    bad = np.nonzero((err != oerr).any(axis=1) | (conv != oconv) | (its != oits))[0]
+    assert bad.size == 0, f"{bad.size} of {syn.shape[0]} syndromes differ from the oracle, first {bad[:5]}"
+    dec.close()
+    return err, conv, its
+
+
+@pytest.mark.parametrize("n", [4, 8, 16])
+@pytest.mark.parametrize("T,C", [(3, 1.0), (5, 2.0), (9, 3.0)])
+def test_trapping_set_resistance(ldpc, gpu, n, T, C):
+    """test_bpots.jl:55-84."""
+    H = cycle_matrix(n)
+    e = np.zeros(n, dtype=np.uint8)
+    e[:2] = 1
+    syn = (H.astype(int) @ e % 2).astype(np.uint8)
+    bpots = ldpc.BPOTSDecoder(H, 0.01, 100, T=T, C=C)
+    result, converged = bpots.decode_(syn.astype(bool))
+    assert np.array_equal(H.astype(int) @ result % 2, syn)
+    rng = np.random.default_rng(n * 10 + T)
+    S = (rng.integers(0, 2, (70, n)).astype(int) @ H.T.astype(int) % 2).astype(np.uint8)
+    assert_same_as_oracle(ldpc, H, 0.01, 100, T, C, S)
+
+
+def test_parameter_sensitivity_and_batch(ldpc, gpu):
+    """test_bpots.jl:87-113, :139-153: random syndromes of the 4- and 8-cycle must be reproduced."""
+    rng = np.random.default_rng(3)
+    H = cycle_matrix(4)
+    for T, C in [(3, 3.0), (5, 3.0), (9, 3.0), (15, 3.0), (9, 1.0), (9, 2.0), (9, 5.0), (9, 10.0)]:
+        syn = (rng.integers(0, 2, 4) @ H.T.astype(int) % 2).astype(np.uint8)
+        result, converged = ldpc.BPOTSDecoder(H, 0.01, 100, T=T, C=C).decode_(syn)
+        assert np.array_equal(H.astype(int) @ result % 2, syn)
+    H = cycle_matrix(8)
+    decoder = ldpc.BPOTSDecoder(H, 0.01, 100, T=9, C=3.0)
+    syndromes = (H.astype(int) @ rng.integers(0, 2, (8, 5)) % 2)
+    errors_buf = np.zeros((8, 5), dtype=np.int64)
+    guesses, successes = ldpc.batchdecode_(decoder, syndromes, errors_buf)
+    for i in range(5):
+        assert np.array_equal(H.astype(int) @ guesses[:, i] % 2, syndromes[:, i])
+
+
+def test_toric_code(ldpc, gpu):
+    """test_bpots.jl:116-137 and equality with the oracle on every syndrome."""
+    H = toric_x(3)
+    rng = np.random.default_rng(7)
+    for noise in (0.01, 0.05, 0.1):
+        E = rng.integers(0, 2, (300, 18)).astype(np.uint8)
+        syn = (E.astype(int) @ H.T.astype(int) % 2).astype(np.uint8)
+        err, conv, _ = assert_same_as_oracle(ldpc, H, noise, 50, 9, 3.0, syn)
+        ok = np.all((err.astype(int) @ H.T.astype(int) % 2) == syn, axis=1)
+        assert ok.mean() >= 0.85
+
+
+@pytest.mark.parametrize("B", [1, 63, 257])
+def test_ldpc_code_hard_syndromes(ldpc, gpu, B):
+    """(3,6)-regular n=504 above threshold: many syndromes run into the bias step (iter % T == 0)."""
+    H = ldpc.codes.parity_check_csc(504, 6, 3)
+    E = ldpc.codes.random_errors(504, B, 0.06, seed=B)
+    syn = ldpc.codes.syndromes_of(H, E)
+    err, conv, its = assert_same_as_oracle(ldpc, H, 0.06, 60, 9, 2.0, syn)
+    if B > 100:
+        assert (its > 9).any()
+
+
+def test_bb72_and_irregular_graphs(ldpc, gpu):
+    HX, _ = ldpc.codes.bivariate_bicycle_72_12_6()
+    E = ldpc.codes.random_errors(72, 3000, 0.05, seed=2)
+    assert_same_as_oracle(ldpc, HX, 0.05, 40, 5, 2.0, ldpc.codes.syndromes_of(HX, E))
+    rng = np.random.default_rng(9)
+    for trial in range(4):
+        H = (rng.random((20, 40)) < 0.12).astype(np.uint8)
+        H[0, :] = 0
+        H[:, 1] = 0
+        syn = rng.integers(0, 2, (130, 20)).astype(np.uint8)
+        syn[3, 2] = 2
+        assert_same_as_oracle(ldpc, H, 0.03, 30, 4, 1.5, syn)
+
+
+def test_max_iters_zero_and_unsupported(ldpc, gpu):
+    H = cycle_matrix(8)
+    err, conv, its = ldpc.BPOTSDecoder(H, 0.01, 0).decode_batch_host(np.zeros((3, 8), dtype=np.uint8))
+    assert not err.any() and not conv.any() and not its.any()
+    big = ldpc.codes.parity_check_csc(16384, 8, 4)      # messages do not fit one CU's LDS
+    with pytest.raises(ldpc.LdpcError) as ei:
+        ldpc.BPOTSDecoder(big, 0.01, 10)
+    assert ei.value.status == 5
