@@ -49,9 +49,6 @@ constexpr int kTile = 64;  // syndromes per tile == wavefront width on gfx950
 #ifndef LDPC_SLOT_PAD    // bytes added to the workspace slot stride (breaks power-of-two slot strides)
 #define LDPC_SLOT_PAD 0
 #endif
-#ifndef LDPC_NBV         // bits handled per wave per step of the variable sweep (1 or 2)
-#define LDPC_NBV 1
-#endif
 
 // Register budget per kernel variant, as the waves-per-SIMD the launch bound must admit.
 // Narrow-degree variants (the regular LDPC codes of the benchmarks) run three 512-thread
@@ -231,36 +228,6 @@ __device__ __forceinline__ double bit_update_exact(double *Mt, const int *__rest
     return F;
 }
 
-// two bits of exact degree D at once: all 2*D row gathers are in flight together
-template <int D>
-__device__ __forceinline__ void bit_update_pair_exact(double *Mt, const int *__restrict__ posA,
-                                                      const int *__restrict__ posB, double r, double &TA,
-                                                      double &TB)
-{
-    double cA[D], cB[D], preA[D], preB[D];
-    size_t atA[D], atB[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) { atA[k] = (size_t)posA[k] * kTile; atB[k] = (size_t)posB[k] * kTile; }
-#pragma unroll
-    for (int k = 0; k < D; ++k) cA[k] = ldm(Mt + atA[k]);
-#pragma unroll
-    for (int k = 0; k < D; ++k) cB[k] = ldm(Mt + atB[k]);
-    double FA = r, FB = r;
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-        preA[k] = FA; FA = FA * cA[k]; if (FA != FA) FA = 1.0;
-        preB[k] = FB; FB = FB * cB[k]; if (FB != FB) FB = 1.0;
-    }
-    double GA = 1.0, GB = 1.0;
-#pragma unroll
-    for (int k = D - 1; k >= 0; --k) {
-        stm(Mt + atA[k], preA[k] * GA); GA = GA * cA[k]; if (GA != GA) GA = 1.0;
-        stm(Mt + atB[k], preB[k] * GB); GB = GB * cB[k]; if (GB != GB) GB = 1.0;
-    }
-    TA = FA;
-    TB = FB;
-}
-
 __device__ __noinline__ double bit_update_any(double *Mt, const int *__restrict__ pos, int deg, double r)
 {
     double F = r;
@@ -392,7 +359,7 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
                     em[j] = v;
                 }
             };
-            for (int j0 = w; j0 < n; j0 += W * LDPC_NBV) {
+            for (int j0 = w; j0 < n; j0 += W) {
 #if LDPC_ROTATE
                 const int j = (j0 + rot_v >= n) ? j0 + rot_v - n : j0 + rot_v;
 #else
@@ -400,23 +367,6 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
 #endif
                 const int c0 = col_ptr[j];
                 const int deg = col_ptr[j + 1] - c0;
-#if LDPC_NBV == 2
-                const int j2 = j + W;
-                if (j2 < n) {
-                    const int c02 = col_ptr[j2];
-                    const int deg2 = col_ptr[j2 + 1] - c02;
-                    if (deg == DV && deg2 == DV) {
-                        double TA, TB;
-                        bit_update_pair_exact<DV>(Mt, csc2csr + c0, csc2csr + c02, r, TA, TB);
-                        finish_bit(j, TA);
-                        finish_bit(j2, TB);
-                    } else {
-                        finish_bit(j, bit_update<DV>(Mt, csc2csr + c0, deg, r));
-                        finish_bit(j2, bit_update<DV>(Mt, csc2csr + c02, deg2, r));
-                    }
-                    continue;
-                }
-#endif
                 finish_bit(j, bit_update<DV>(Mt, csc2csr + c0, deg, r));
             }
             __syncthreads();

@@ -186,7 +186,7 @@ struct ldpc_bp_decoder {
     DevBuf defer_list, synmask2, nevermask2, errmask2, llr_t2;
     int defer_thresh = 0;     // 0 auto (16 lanes), -1 off, else the lane count at which a tile gives up
     // staging for the host-pointer entry
-    DevBuf st_syn, st_err, st_conv, st_llr, st_iters, st_all;
+    DevBuf st_all;            // device image of a small host batch
     void *pin = nullptr;      // pinned host image for small batches
     size_t pin_cap = 0;
     // host-buffer pipeline for large batches: 3 pinned + 3 device chunk images, copy / compute / copy streams
@@ -205,7 +205,7 @@ struct ldpc_bp_decoder {
     ~ldpc_bp_decoder()
     {
         DevBuf *all[] = {&row_ptr, &edge_bit, &col_ptr, &csc2csr, &msg, &ctrl, &synmask, &nevermask,
-                         &errmask, &llr_t, &st_syn, &st_err, &st_conv, &st_llr, &st_iters, &st_all,
+                         &errmask, &llr_t, &st_all,
                          &defer_list, &synmask2, &nevermask2, &errmask2, &llr_t2};
         for (DevBuf *b : all) b->release();
         if (pin) (void)hipHostFree(pin);
@@ -411,8 +411,8 @@ ldpc_status ldpc_bp_get_info(const ldpc_bp_decoder *d, ldpc_bp_info *info)
     info->device = d->device; info->tile_syndromes = kTile; info->waves_per_tile = d->last_threads / 64;
     info->resident_tiles = d->last_grid;
     const DevBuf *all[] = {&d->row_ptr, &d->edge_bit, &d->col_ptr, &d->csc2csr, &d->msg, &d->ctrl, &d->synmask,
-                           &d->nevermask, &d->errmask, &d->llr_t, &d->st_syn, &d->st_err, &d->st_conv,
-                           &d->st_llr, &d->st_iters};
+                           &d->nevermask, &d->errmask, &d->llr_t, &d->st_all, &d->defer_list, &d->synmask2,
+                           &d->nevermask2, &d->errmask2, &d->llr_t2, &d->pipe_dev[0], &d->pipe_dev[1], &d->pipe_dev[2]};
     for (const DevBuf *b : all) info->workspace_bytes += (int64_t)b->cap;
     return LDPC_OK;
 }

@@ -20,7 +20,7 @@ using SparseArrays
 import LDPCDecoders
 import LDPCDecoders: AbstractDecoder, decode!, batchdecode!, reset!
 
-export MI355XBeliefPropagationDecoder, MI355XBeliefPropagationOSDDecoder
+export MI355XBeliefPropagationDecoder, MI355XBeliefPropagationOSDDecoder, MI355XBPOTSDecoder
 
 const libldpc = get(ENV, "LDPC_MI355X_LIB", "libldpc_mi355x.so")
 
@@ -207,5 +207,45 @@ function batchdecode!(d::MI355XBeliefPropagationOSDDecoder, syndromes::AbstractM
     end
     return errors, success
 end
+
+# ---------------------------------------------------------------------------------------------
+# BP-OTS (src/decoders/bpots_decoder.jl:39-115, 225-340) over ldpc_bpots_* (LDS-resident kernel:
+# graphs whose messages fit one CU's LDS; larger ones raise LDPCMI355XError(5, ...)).
+# ---------------------------------------------------------------------------------------------
+mutable struct MI355XBPOTSDecoder <: AbstractDecoder
+    per::Float64; max_iters::Int; s::Int; n::Int; T::Int; C::Float64
+    handle::Ptr{Cvoid}
+end
+
+function MI355XBPOTSDecoder(H::Union{SparseMatrixCSC{Bool,Int},BitMatrix}, per::Float64, max_iters::Int;
+                            T::Int=9, C::Float64=2.0, device::Integer=-1)             # :90
+    s, n = size(H)
+    sp = SparseMatrixCSC{Bool,Int}(sparse(H))
+    colptr = Int64.(sp.colptr .- 1); rowval = Int64.(rowvals(sp) .- 1)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:ldpc_bpots_create, libldpc), Cint,
+                (Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Float64, Int64, Int64, Float64, Int32, Ptr{Ptr{Cvoid}}),
+                s, n, length(rowval), colptr, rowval, per, max_iters, T, C, device, h))
+    d = MI355XBPOTSDecoder(per, max_iters, s, n, T, C, h[])
+    finalizer(d) do x
+        x.handle != C_NULL && ccall((:ldpc_bpots_destroy, libldpc), Cint, (Ptr{Cvoid},), x.handle)
+        x.handle = C_NULL
+    end
+    return d
+end
+
+reset!(d::MI355XBPOTSDecoder) = d       # :142-154: the device state is reset inside every decode call
+
+function decode!(d::MI355XBPOTSDecoder, syndrome::AbstractVector)                      # :225-340
+    length(syndrome) == d.s || throw(BoundsError(syndrome, d.s))
+    syn = UInt8[syndrome_byte(x) for x in syndrome]
+    err = Vector{UInt8}(undef, d.n); conv = Vector{UInt8}(undef, 1)
+    check(ccall((:ldpc_bpots_decode_batch, libldpc), Cint,
+                (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{UInt8}, Ptr{UInt8}, Ptr{Int32}),
+                d.handle, 1, syn, err, conv, C_NULL))
+    return Int.(err), conv[1] != 0        # best_decisions::Vector{Int}, converged
+end
+# batchdecode! on it is the reference's generic per-column method (abstract_decoder.jl:31-48);
+# a batched override would call ldpc_bpots_decode_batch with B columns exactly like the BP type above.
 
 end # module
