@@ -62,7 +62,7 @@ typedef struct ldpc_bp_info {
 /* Optional knobs; pass NULL to ldpc_bp_create for defaults.  Zero = default. */
 typedef struct ldpc_bp_options {
     int32_t device;           /* HIP device ordinal; -1 = current device */
-    int32_t waves_per_tile;   /* 0 = auto (8; 16 when the batch has at most one tile per CU); else 4, 6, 8, 12, 16 */
+    int32_t waves_per_tile;   /* 0 = auto (8; 16 when the batch has at most one tile per CU); else 4, 8, 16 */
     int32_t resident_tiles;   /* 0 = auto (fills the chip) */
     int32_t kernel_variant;   /* 0 = auto (LDS-resident kernel when the edge messages fit the LDS, else the
                                  HBM-streaming tile kernel); 1 = force streaming; 2 = force LDS-resident */

@@ -283,7 +283,9 @@ __device__ __forceinline__ double bit_update(double *Mt, const int *__restrict__
 //   col_ptr  [n+1]  CSC (bit-major) edge ranges
 //   csc2csr  [nnz]  CSR position of every CSC edge, checks ascending inside a bit
 //   synmask  [ntiles][s], nevermask [ntiles] (lanes holding a syndrome entry other than 0/1)
-template <int DC, int DV, bool WANT_LLR, int THREADS>
+// SECOND = the straggler pass (same code; a distinct instantiation only so that profilers list the
+// two passes as two kernels instead of averaging a ~1 s launch with a ~5 us one).
+template <int DC, int DV, bool WANT_LLR, int THREADS, bool SECOND>
 __global__ void
 __launch_bounds__(THREADS, (min_waves_per_simd<DC, DV, THREADS>()))
 bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restrict__ edge_bit,

@@ -80,36 +80,35 @@ struct DevBuf {
 typedef void (*bp_kernel_t)(BPParams, const int *, const int *, const int *, const int *, const u64 *,
                             const u64 *);
 
-template <int DC, int DV, bool LLR>
+template <int DC, int DV, bool LLR, bool SECOND>
 bp_kernel_t pick_threads(int threads)
 {
     switch (threads) {
-    case 256: return bp_tile_kernel<DC, DV, LLR, 256>;
-    case 384: return bp_tile_kernel<DC, DV, LLR, 384>;
-    case 512: return bp_tile_kernel<DC, DV, LLR, 512>;
-    case 768: return bp_tile_kernel<DC, DV, LLR, 768>;
-    default: return bp_tile_kernel<DC, DV, LLR, 1024>;
+    case 256: return bp_tile_kernel<DC, DV, LLR, 256, SECOND>;
+    case 512: return bp_tile_kernel<DC, DV, LLR, 512, SECOND>;
+    default: return bp_tile_kernel<DC, DV, LLR, 1024, SECOND>;
     }
 }
 
-template <int DC, bool LLR>
+template <int DC, bool LLR, bool SECOND>
 bp_kernel_t pick_dv(int dv, int threads)
 {
-    if (dv <= 4) return pick_threads<DC, 4, LLR>(threads);
-    return pick_threads<DC, 16, LLR>(threads);
+    if (dv <= 4) return pick_threads<DC, 4, LLR, SECOND>(threads);
+    return pick_threads<DC, 16, LLR, SECOND>(threads);
 }
 
-template <bool LLR>
+template <bool LLR, bool SECOND>
 bp_kernel_t pick_dc(int dc, int dv, int threads)
 {
-    if (dc <= 8) return pick_dv<8, LLR>(dv, threads);
-    if (dc <= 16) return pick_dv<16, LLR>(dv, threads);
-    return pick_dv<32, LLR>(dv, threads);
+    if (dc <= 8) return pick_dv<8, LLR, SECOND>(dv, threads);
+    if (dc <= 16) return pick_dv<16, LLR, SECOND>(dv, threads);
+    return pick_dv<32, LLR, SECOND>(dv, threads);
 }
 
-bp_kernel_t pick_kernel(int dc, int dv, bool llr, int threads)
+bp_kernel_t pick_kernel(int dc, int dv, bool llr, int threads, bool second = false)
 {
-    return llr ? pick_dc<true>(dc, dv, threads) : pick_dc<false>(dc, dv, threads);
+    if (second) return llr ? pick_dc<true, true>(dc, dv, threads) : pick_dc<false, true>(dc, dv, threads);
+    return llr ? pick_dc<true, false>(dc, dv, threads) : pick_dc<false, false>(dc, dv, threads);
 }
 
 typedef void (*lds_kernel_t)(LdsParams, const int *, const int *, const int *, const int *);
@@ -352,9 +351,9 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
 
     // geometry: waves per tile (fixed by the caller or chosen per batch) and the workspace budget
     int wpt = options ? options->waves_per_tile : 0;
-    if (wpt != 0 && wpt != 4 && wpt != 6 && wpt != 8 && wpt != 12 && wpt != 16) {
+    if (wpt != 0 && wpt != 4 && wpt != 8 && wpt != 16) {
         delete d;
-        return fail(LDPC_ERR_INVALID_ARGUMENT, "waves_per_tile must be 0, 4, 6, 8, 12 or 16");
+        return fail(LDPC_ERR_INVALID_ARGUMENT, "waves_per_tile must be 0, 4, 8 or 16");
     }
     d->wpt_fixed = wpt;
     d->resident_fixed = options ? std::max(options->resident_tiles, 0) : 0;
@@ -597,7 +596,8 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
         p2.defer_thresh = 0;
         p2.index = (const int *)d->defer_list.p;
         p2.count_dev = defer_count;
-        hipLaunchKernelGGL(kfn, dim3((unsigned)std::min(grid, ntiles2)), dim3((unsigned)threads), 0, stream, p2,
+        bp_kernel_t kfn2 = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, threads, true);
+        hipLaunchKernelGGL(kfn2, dim3((unsigned)std::min(grid, ntiles2)), dim3((unsigned)threads), 0, stream, p2,
                            (const int *)d->row_ptr.p, (const int *)d->edge_bit.p, (const int *)d->col_ptr.p,
                            (const int *)d->csc2csr.p, (const u64 *)d->synmask2.p, (const u64 *)d->nevermask2.p);
         HIP_TRY(hipGetLastError());
