@@ -44,10 +44,10 @@ constexpr int kTile = 64;  // syndromes per tile == wavefront width on gfx950
 #define LDPC_NT 0
 #endif
 #ifndef LDPC_ROTATE      // 1 = every workgroup starts its sweeps at a different node (de-phases the workgroups)
-#define LDPC_ROTATE 0
+#define LDPC_ROTATE 1    // together with the pad: +1.3..1.4 % on C3 full-50 (two boxes, A/B in one process each)
 #endif
 #ifndef LDPC_SLOT_PAD    // bytes added to the workspace slot stride (breaks power-of-two slot strides)
-#define LDPC_SLOT_PAD 0
+#define LDPC_SLOT_PAD 1053184   // 1 MiB + 4.5 KiB
 #endif
 
 // Register budget per kernel variant, as the waves-per-SIMD the launch bound must admit.
