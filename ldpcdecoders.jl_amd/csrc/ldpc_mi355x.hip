@@ -141,22 +141,22 @@ lds_kernel_t pick_lds_kernel(int dc, int dv, bool llr, int threads)
 }
 
 // How many syndromes per workgroup pass the LDS kernel holds (log2), or -1 if even one
-// syndrome's messages do not fit.  Maximises syndromes resident per CU (S x workgroups per CU,
-// at most 3 workgroups: the register budget), preferring more, smaller workgroups on a tie.
+// syndrome's messages do not fit.  Workgroups per CU come first (the check sweep is VALU-bound, the
+// other phases are latency-bound: co-resident workgroups in different phases fill each other's
+// gaps), then the largest S that still admits that many: 3 workgroups of 8 waves is what the
+// register budget allows (2 when LLRs are written).  Measured on n=1008: S=1 x 3 workgroups 60.0 M
+// syndromes/s, S=2 x 2 51.6 M, S=4 x 1 31.6 M; BB-72: S=16 x 3 best.
 int lds_logS(int64_t s, int64_t n, int64_t nnz, bool want_llr)
 {
     constexpr size_t kLds = 160 * 1024;
     if (nnz >= 65535 || s >= 65535 || n >= 65535) return -1;   // uint16 graph copies in LDS
-    int best = -1;
-    long best_total = 0, best_wgs = 0;
-    for (int l = 0; l <= 6; ++l) {
-        const size_t b = lds_bytes_needed((int)s, (int)n, (int)nnz, 1 << l, want_llr) + 256;
-        if (b > kLds) break;
-        const long wgs = std::min<long>(3, (long)(kLds / b));
-        const long total = wgs << l;
-        if (total > best_total || (total == best_total && wgs > best_wgs)) { best = l; best_total = total; best_wgs = wgs; }
+    for (int wgs = want_llr ? 2 : 3; wgs >= 1; --wgs) {
+        int best = -1;
+        for (int l = 0; l <= 6; ++l)
+            if ((lds_bytes_needed((int)s, (int)n, (int)nnz, 1 << l, want_llr) + 512) * (size_t)wgs <= kLds) best = l;
+        if (best >= 0) return best;
     }
-    return best;
+    return -1;
 }
 
 }  // namespace
@@ -365,6 +365,13 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     if (d->variant < 0 || d->variant > 2) { delete d; return fail(LDPC_ERR_INVALID_ARGUMENT, "kernel_variant must be 0, 1 or 2"); }
     d->lds_logS[0] = lds_logS(s, n, nnz, false);
     d->lds_logS[1] = lds_logS(s, n, nnz, true);
+    if (const char *e = std::getenv("LDPC_LDS_LOGS")) {   // tuning experiments only
+        const int l = std::atoi(e);
+        for (int q = 0; q < 2; ++q)
+            if (d->lds_logS[q] >= 0 && l >= 0 && l <= 6 &&
+                lds_bytes_needed((int)s, (int)n, (int)nnz, 1 << l, q == 1) + 256 <= (size_t)160 * 1024)
+                d->lds_logS[q] = l;
+    }
     if (d->variant == 2 && (d->lds_logS[0] < 0 || d->lds_logS[1] < 0)) {
         delete d;
         return fail(LDPC_ERR_UNSUPPORTED, "kernel_variant 2 (LDS-resident) requested but the edge messages do not fit the LDS");
