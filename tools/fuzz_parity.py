@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Randomised parity fuzz (GPU box): random Tanner graphs, channel probabilities, iteration caps,
+batch sizes and kernel/geometry options, every result compared with the CPU oracle (hard decisions,
+flags, iteration counts bit-exact; LLRs <= 1e-5, +-Inf exact).  Usage: fuzz_parity.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.sparse as sp
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ldpcdecoders_jl_amd as ldpc  # noqa: E402
+from oracle import BPOracle, BPOTSOracle  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+t0, cases, decoded = time.time(), 0, 0
+while time.time() - t0 < budget:
+    kind = rng.integers(0, 4)
+    if kind == 0:      # Gallager regular
+        wr, wc = int(rng.choice([4, 6, 8, 10])), int(rng.choice([2, 3, 4, 5]))
+        n = wr * int(rng.integers(4, 60))
+        H = ldpc.codes.parity_check_csc(n, wr, wc, seed=int(rng.integers(1 << 30)))
+    else:              # irregular random, with empty and heavy nodes now and then
+        s, n = int(rng.integers(1, 80)), int(rng.integers(1, 160))
+        A = (rng.random((s, n)) < rng.uniform(0.02, 0.25)).astype(np.uint8)
+        if rng.random() < 0.3:
+            A[rng.integers(0, s), :] = 0
+        if rng.random() < 0.3:
+            A[:, rng.integers(0, n)] = 0
+        if rng.random() < 0.2:
+            A[rng.integers(0, s), : min(n, 40)] = 1
+        if rng.random() < 0.2 and s > 20:
+            A[:20, rng.integers(0, n)] = 1
+        H = sp.csc_matrix(A)
+    H.sort_indices()
+    s, n = H.shape
+    per = float(rng.choice([1e-6, 0.005, 0.02, 0.05, 0.1, 0.3, 0.5, 0.9]))
+    iters = int(rng.choice([1, 2, 3, 7, 20, 50]))
+    B = int(rng.choice([1, 2, 63, 64, 65, 130, 400, 1500]))
+    if rng.random() < 0.5:
+        E = (rng.random((B, n)) < min(per * rng.uniform(0.5, 3), 0.5)).astype(np.uint8)
+        syn = ldpc.codes.syndromes_of(H, E)
+    else:
+        syn = rng.integers(0, 2, (B, s)).astype(np.uint8)
+    if rng.random() < 0.1 and s > 0:
+        syn[rng.integers(0, B), rng.integers(0, s)] = rng.integers(2, 5)
+    oc = BPOracle(csc=(H.indptr, H.indices), shape=H.shape, per=per, max_iters=iters)
+    oerr, oconv, ollr, oits = oc.batchdecode(syn)
+    for variant in (0, 1):
+        kw = dict(kernel_variant=variant, waves_per_tile=int(rng.choice([0, 4, 8, 16])),
+                  defer_threshold=int(rng.choice([0, -1, 4, 40])))
+        if rng.random() < 0.3:
+            kw["resident_tiles"] = int(rng.integers(1, 5))
+        dec = ldpc.BeliefPropagationDecoder(H, per, iters, **kw)
+        want_llr = bool(rng.random() < 0.5)
+        err, conv, llr, its = dec.decode_batch_host(syn, want_llr=want_llr, want_iters=True)
+        ok = np.array_equal(err, oerr) and np.array_equal(conv, oconv) and np.array_equal(its, oits)
+        if ok and want_llr:
+            fin = np.isfinite(ollr)
+            ok = np.array_equal(llr[~fin], ollr[~fin]) and (not fin.any() or np.max(np.abs(llr[fin] - ollr[fin])) <= 1e-5)
+        if not ok:
+            np.savez("gpurun_out/fuzz_failure.npz", colptr=H.indptr, rowval=H.indices, shape=np.array(H.shape), per=per,
+                     iters=iters, syn=syn)
+            print(f"MISMATCH case {cases}: shape {H.shape} nnz {H.nnz} per {per} iters {iters} B {B} {kw} llr={want_llr}")
+            sys.exit(1)
+        dec.close()
+        decoded += B
+    if kind == 1 and H.nnz > 0 and max(np.diff(H.indptr).max(), 0) <= 16 and np.diff(H.tocsr().indptr).max() <= 32:
+        T, C = int(rng.choice([2, 3, 9])), float(rng.choice([1.0, 2.0, 3.0]))
+        pp = max(per, 1e-3) if per < 0.9 else 0.3
+        oe, ocv, oi = BPOTSOracle((H.indptr, H.indices), H.shape, pp, iters, T, C).batchdecode(syn)
+        d2 = ldpc.BPOTSDecoder(H, pp, iters, T=T, C=C)
+        e2, c2, i2 = d2.decode_batch_host(syn)
+        if not (np.array_equal(e2, oe) and np.array_equal(c2, ocv) and np.array_equal(i2, oi)):
+            print(f"BP-OTS MISMATCH case {cases}: shape {H.shape} nnz {H.nnz} per {pp} iters {iters} B {B} T {T} C {C}")
+            sys.exit(1)
+        d2.close()
+    cases += 1
+print(f"fuzz ok: {cases} random cases, {decoded} syndromes decoded on the GPU in {time.time() - t0:.0f} s, seed {seed}")
