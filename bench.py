@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--defer-threshold", type=int, default=0, help="0 auto (16), -1 off (streaming kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     # rehearsal of the N>1 control flow on a box with fewer GPUs than ranks (never used by the driver):
+    ap.add_argument("--prealloc-gib", type=float, default=0.0,
+                    help="experiment: hold this much HBM before anything else is allocated (shifts physical placement)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="all ranks share cuda:0 and synchronise over gloo instead of RCCL")
     args = ap.parse_args()
@@ -138,6 +140,7 @@ def main():
 
     import ldpcdecoders_jl_amd as ldpc
 
+    hold = torch.empty(int(args.prealloc_gib * (1 << 30)), dtype=torch.uint8, device=device) if args.prealloc_gib > 0 else None
     n, wr, wc, batch, per, max_iters = WORKLOADS[args.workload]
     if args.batch:
         batch = args.batch

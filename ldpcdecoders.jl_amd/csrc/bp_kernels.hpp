@@ -442,6 +442,26 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
 }
 
 // ---------------------------------------------------------------------------
+// placement probe: the variable sweep's access pattern on a candidate workspace -- every wave of a
+// slot's workgroup gathers 4 pseudo-random rows of the slot and writes them back.  The host times it
+// on several candidate allocations and keeps the fastest (DESIGN.md "Workspace placement").
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) placement_probe_kernel(double *base, long long slot_stride, int rows)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double *M = base + (size_t)blockIdx.x * (size_t)slot_stride + lane;
+    const unsigned r = (unsigned)rows;
+    for (unsigned j = (unsigned)w; j < r / 4u; j += 8u) {
+        const unsigned a = (j * 2654435761u + 12345u) % r, b = (j * 2246822519u + 977u) % r,
+                       c = (j * 3266489917u + 31u) % r, d = (j * 668265263u + 7u) % r;
+        const double v0 = M[(size_t)a * kTile], v1 = M[(size_t)b * kTile], v2 = M[(size_t)c * kTile],
+                     v3 = M[(size_t)d * kTile];
+        M[(size_t)a * kTile] = v1; M[(size_t)b * kTile] = v2; M[(size_t)c * kTile] = v3; M[(size_t)d * kTile] = v0;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // pack: syndromes uint8 [batch][s]  ->  lane masks synmask[tile][s] (+ nevermask)
 // one wave per (tile, 64 checks); lane = check.
 // ---------------------------------------------------------------------------
