@@ -246,6 +246,18 @@ void parallel_memcpy(void *dst, const void *src, size_t bytes)
 
 }  // namespace
 
+// bytes added to every workspace slot (LDPC_SLOT_PAD at build time; LDPC_SLOT_PAD_BYTES overrides it
+// at run time for experiments; kept a multiple of 512 so that rows stay aligned)
+static size_t slot_pad_bytes()
+{
+    static const size_t v = [] {
+        size_t p = LDPC_SLOT_PAD;
+        if (const char *e = std::getenv("LDPC_SLOT_PAD_BYTES")) p = (size_t)std::atoll(e);
+        return p & ~(size_t)511;
+    }();
+    return v;
+}
+
 // Workspace placement: where in HBM the message workspace lands changes what the sweeps can
 // stream by up to 15 % (tools/placement_probe.hip: the same kernels on eight simultaneously held
 // 24.8 GiB allocations ran 4.88 ... 5.62 TB/s, reproducibly per allocation; across processes the same
@@ -260,45 +272,85 @@ static ldpc_status ensure_workspace(ldpc_bp_decoder *d, size_t bytes, int grid, 
     d->msg.release();
     int want = 12;
     if (const char *e = std::getenv("LDPC_PLACEMENT_CANDIDATES")) want = std::max(1, std::atoi(e));
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
-    const int fit = (int)(free_b / 10 * 8 / std::max<size_t>(bytes, 1));
-    const int K = std::min(want, fit);
-    if (K < 2 || bytes < ((size_t)1 << 30) || d->nnz < 4) return d->msg.ensure(bytes);
-    std::vector<void *> cand;
-    for (int k = 0; k < K; ++k) {
-        void *q = nullptr;
-        if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
-        cand.push_back(q);
+    const bool verbose = std::getenv("LDPC_PLACEMENT_VERBOSE") != nullptr;
+    if (want < 2 || bytes < ((size_t)1 << 30) || d->nnz < 4) return d->msg.ensure(bytes);
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess) {
+        (void)hipGetLastError();
+        if (ea) (void)hipEventDestroy(ea);
+        return d->msg.ensure(bytes);
     }
-    if (cand.empty()) return d->msg.ensure(bytes);
-    int best = 0;
-    float best_ms = 0.f;
-    hipEvent_t a = nullptr, b = nullptr;
-    bool ok = hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess;
-    for (size_t k = 0; ok && k < cand.size(); ++k) {
-        const long long stride = (long long)(slot_stride_bytes / sizeof(double));
-        hipLaunchKernelGGL(placement_probe_kernel, dim3((unsigned)grid), dim3(512), 0, stream, (double *)cand[k], stride, (int)d->nnz);
-        ok = ok && hipEventRecord(a, stream) == hipSuccess;   // first pass untimed: page first-touch
-        hipLaunchKernelGGL(placement_probe_kernel, dim3((unsigned)grid), dim3(512), 0, stream, (double *)cand[k], stride, (int)d->nnz);
-        ok = ok && hipEventRecord(b, stream) == hipSuccess && hipEventSynchronize(b) == hipSuccess;
-        float ms = 0.f;
-        ok = ok && hipEventElapsedTime(&ms, a, b) == hipSuccess;
-        if (ok && (k == 0 || ms < best_ms)) { best = (int)k; best_ms = ms; }
-        if (ok && std::getenv("LDPC_PLACEMENT_VERBOSE"))
-            std::fprintf(stderr, "[ldpc] workspace candidate %zu @%p: probe %.3f ms (%.2f TB/s)\n", k, cand[k], ms,
-                         2.0 * (double)grid * (double)d->nnz * 512.0 / (ms * 1e-3) / 1e12);
+    const long long stride = (long long)(slot_stride_bytes / sizeof(double));
+    auto probe = [&](void *q) -> float {   // ms of one timed pass (after an untimed first-touch pass); <0 on error
+        hipLaunchKernelGGL(placement_probe_kernel, dim3((unsigned)grid), dim3(512), 0, stream, (double *)q, stride, (int)d->nnz);
+        if (hipEventRecord(ea, stream) != hipSuccess) return -1.f;
+        hipLaunchKernelGGL(placement_probe_kernel, dim3((unsigned)grid), dim3(512), 0, stream, (double *)q, stride, (int)d->nnz);
+        float ms = -1.f;
+        if (hipEventRecord(eb, stream) != hipSuccess || hipEventSynchronize(eb) != hipSuccess ||
+            hipEventElapsedTime(&ms, ea, eb) != hipSuccess)
+            return -1.f;
+        return ms;
+    };
+    void *keep = nullptr;      // best allocation so far (held across rounds)
+    float keep_ms = 0.f;
+    int probed = 0;
+    // Round 0 probes as many candidates as fit.  Measured classes on C3: ~8.6 ms (fast), ~9.4 ms, ~10.1 ms
+    // per probe pass, and a round of nine often holds no fast one; so unless the best is clearly of the
+    // fast class (<= 0.875 x the slowest seen), further rounds repeat behind a shim of 1/2, then 1/4
+    // workspace so that the windows fall on other addresses.
+    float worst_ms = 0.f;
+    for (int round = 0; round < 3; ++round) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); break; }
+        void *shim = nullptr;
+        const size_t shim_bytes = round == 0 ? 0 : (round == 1 ? bytes / 2 : bytes / 4);
+        if (shim_bytes && hipMalloc(&shim, shim_bytes) != hipSuccess) { (void)hipGetLastError(); shim = nullptr; }
+        const size_t budget = free_b / 10 * 8 - shim_bytes;
+        const int K = std::min<int>(want, (int)(budget / std::max<size_t>(bytes, 1)));
+        std::vector<void *> cand;
+        std::vector<float> ms;
+        for (int k = 0; k < K; ++k) {
+            void *q = nullptr;
+            if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+            cand.push_back(q);
+        }
+        for (void *q : cand) {
+            const float t = probe(q);
+            ms.push_back(t);
+            if (verbose)
+                std::fprintf(stderr, "[ldpc] workspace round %d candidate @%p: probe %.3f ms (%.2f TB/s)\n", round, q, t,
+                             t > 0 ? 2.0 * (double)grid * (double)d->nnz * 512.0 / (t * 1e-3) / 1e12 : 0.0);
+        }
+        (void)hipStreamSynchronize(stream);
+        int best = -1;
+        for (size_t k = 0; k < cand.size(); ++k)
+            if (ms[k] > 0 && (best < 0 || ms[k] < ms[(size_t)best])) best = (int)k;
+        bool standout = true;
+        if (best >= 0) {
+            for (float t : ms) worst_ms = std::max(worst_ms, t);
+            if (!keep || ms[(size_t)best] < keep_ms) {
+                if (keep) (void)hipFree(keep);
+                keep = cand[(size_t)best];
+                keep_ms = ms[(size_t)best];
+                cand[(size_t)best] = nullptr;
+            }
+            standout = keep_ms <= 0.875f * worst_ms;
+        }
+        probed += (int)cand.size();
+        for (void *q : cand)
+            if (q) (void)hipFree(q);
+        if (shim) (void)hipFree(shim);
+        if (standout || cand.empty()) break;
     }
-    if (!ok) (void)hipGetLastError();
-    if (a) (void)hipEventDestroy(a);
-    if (b) (void)hipEventDestroy(b);
-    (void)hipStreamSynchronize(stream);
-    for (size_t k = 0; k < cand.size(); ++k)
-        if ((int)k != best) (void)hipFree(cand[k]);
-    d->msg.p = cand[(size_t)best];
+    (void)hipGetLastError();
+    (void)hipEventDestroy(ea);
+    (void)hipEventDestroy(eb);
+    if (!keep) return d->msg.ensure(bytes);
+    d->msg.p = keep;
     d->msg.cap = bytes;
-    d->placement_ms = best_ms;
-    d->placement_candidates = (int)cand.size();
+    d->placement_ms = keep_ms;
+    d->placement_candidates = probed;
+    if (verbose) std::fprintf(stderr, "[ldpc] workspace: kept @%p (%.3f ms) out of %d probed\n", keep, keep_ms, probed);
     return LDPC_OK;
 }
 
@@ -567,7 +619,7 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
     // tile put more of the chip to work.  The caller may fix it.
     int threads = 0, grid = 0;
     {
-        const size_t slot_bytes = std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double) + LDPC_SLOT_PAD;
+        const size_t slot_bytes = std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double) + slot_pad_bytes();
         const int max_slots = (int)std::max<size_t>(std::min<size_t>(d->ws_budget / slot_bytes, 1u << 30), 1);
         const int wpt = d->wpt_fixed ? d->wpt_fixed : (ntiles <= d->num_cus ? 16 : 8);
         int &bc = d->blocks_cache[want_llr ? 1 : 0][wpt];
@@ -587,7 +639,7 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
     }
     d->last_threads = threads;
     d->last_grid = grid;
-    const size_t slot_stride_bytes = std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double) + LDPC_SLOT_PAD;
+    const size_t slot_stride_bytes = std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double) + slot_pad_bytes();
     if ((st = ensure_workspace(d, (size_t)grid * slot_stride_bytes, grid, slot_stride_bytes, stream)) != LDPC_OK)
         return st;
 

@@ -49,8 +49,10 @@ int main(int argc, char **argv)
 {
     const int K = argc > 1 ? atoi(argv[1]) : 8;
     const int slots = 768, rows = 65536, iters = 6;
-    const size_t slot_stride = (size_t)rows * 64 + (1053184 / 8);
-    const size_t bytes = (size_t)slots * slot_stride * sizeof(double);
+    const size_t pad_bytes = argc > 2 ? (size_t)atoll(argv[2]) : 1053184;
+    const size_t slot_stride = (size_t)rows * 64 + (pad_bytes / 8);
+    const size_t bytes = (size_t)slots * ((size_t)rows * 64 + (20u << 20) / 8) * sizeof(double);   // room for any pad tried
+    printf("slot pad %zu bytes\n", pad_bytes);
     std::vector<int> perm(rows);
     for (int i = 0; i < rows; ++i) perm[i] = i;
     unsigned long long s = 88172645463325252ull;
