@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="syndromes per GPU (default: the workload's)")
     ap.add_argument("--waves-per-tile", type=int, default=0)
     ap.add_argument("--resident-tiles", type=int, default=0)
-    ap.add_argument("--kernel-variant", type=int, default=0, help="0 auto, 1 HBM-streaming, 2 LDS-resident")
+    ap.add_argument("--kernel-variant", type=int, default=0, help="0 auto, 1 HBM-streaming, 2 LDS-resident, 3 node-parallel")
     ap.add_argument("--defer-threshold", type=int, default=0, help="0 auto (16), -1 off (streaming kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     # rehearsal of the N>1 control flow on a box with fewer GPUs than ranks (never used by the driver):

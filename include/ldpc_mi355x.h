@@ -64,8 +64,10 @@ typedef struct ldpc_bp_options {
     int32_t device;           /* HIP device ordinal; -1 = current device */
     int32_t waves_per_tile;   /* 0 = auto (8; 16 when the batch has at most one tile per CU); else 4, 8, 16 */
     int32_t resident_tiles;   /* 0 = auto (fills the chip) */
-    int32_t kernel_variant;   /* 0 = auto (LDS-resident kernel when the edge messages fit the LDS, else the
-                                 HBM-streaming tile kernel); 1 = force streaming; 2 = force LDS-resident */
+    int32_t kernel_variant;   /* 0 = auto (LDS-resident kernel when the edge messages fit the LDS; else the
+                                 node-parallel kernel -- one workgroup per syndrome -- for batches too small to
+                                 give every CU a 64-syndrome tile, and the HBM-streaming tile kernel above that);
+                                 1 = force streaming; 2 = force LDS-resident; 3 = force node-parallel */
     int32_t defer_threshold;  /* HBM-streaming kernel: a 64-syndrome tile hands its unconverged syndromes to a
                                  densely packed second pass once at most this many are left (same results,
                                  fewer nearly-empty sweeps).  0 = auto (16), -1 = off, else 1..48 */

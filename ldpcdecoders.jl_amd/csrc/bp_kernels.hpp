@@ -109,6 +109,7 @@ struct BPParams {
     unsigned int *defer_count;  // number of entries in defer_list
     const int *index;           // second pass: batch position of compact syndrome q (nullptr in the first pass)
     const unsigned int *count_dev;  // second pass: number of compact syndromes (device word; nullptr = p.batch)
+    unsigned int count_skip;    // second pass: do nothing while *count_dev <= count_skip (bp_node_kernels.hpp takes those)
 };
 
 __device__ __forceinline__ u64 wave_or(u64 v)
@@ -307,7 +308,12 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
     const int rot_v = n > 0 ? (int)((blockIdx.x * 2246822519u) % (unsigned)n) : 0;
 #endif
 
-    const long long batch = p.count_dev ? (long long)*p.count_dev : p.batch;
+    long long batch_ = p.batch;
+    if (p.count_dev) {
+        batch_ = (long long)*p.count_dev;
+        if (batch_ <= (long long)p.count_skip) batch_ = 0;
+    }
+    const long long batch = batch_;
     const int ntiles = p.count_dev ? (int)((batch + kTile - 1) / kTile) : p.ntiles;
 
     for (;;) {
@@ -466,12 +472,15 @@ __global__ void __launch_bounds__(512) placement_probe_kernel(double *base, long
 // one wave per (tile, 64 checks); lane = check.
 // ---------------------------------------------------------------------------
 // index / count_dev (both nullptr in the first pass): compact syndrome q of the second pass is
-// syndrome index[q] of the batch, and there are *count_dev of them.
+// syndrome index[q] of the batch, and there are *count_dev of them -- unless that is at most
+// count_skip, in which case the tile-kernel second pass does not run at all (the node-parallel
+// kernel decodes those few syndromes straight from / into the caller's arrays).
 __global__ void __launch_bounds__(64) pack_syndromes_kernel(const unsigned char *syn, long long batch,
                                                             int s, u64 *synmask, u64 *nevermask,
-                                                            const int *index, const unsigned int *count_dev)
+                                                            const int *index, const unsigned int *count_dev,
+                                                            unsigned int count_skip)
 {
-    if (count_dev) batch = (long long)*count_dev;
+    if (count_dev) { batch = (long long)*count_dev; if (batch <= (long long)count_skip) return; }
     const int tile = blockIdx.y;
     const int i = blockIdx.x * 64 + threadIdx.x;
     const long long b0 = (long long)tile * kTile;
@@ -494,9 +503,9 @@ __global__ void __launch_bounds__(64) pack_syndromes_kernel(const unsigned char 
 // unpack: errmask[tile][n] -> errors uint8 [batch][n]; one wave per (tile, 64 bits)
 __global__ void __launch_bounds__(64) unpack_errors_kernel(const u64 *errmask, long long batch, int n,
                                                            unsigned char *errors, const int *index,
-                                                           const unsigned int *count_dev)
+                                                           const unsigned int *count_dev, unsigned int count_skip)
 {
-    if (count_dev) batch = (long long)*count_dev;
+    if (count_dev) { batch = (long long)*count_dev; if (batch <= (long long)count_skip) return; }
     const int tile = blockIdx.y;
     const int j = blockIdx.x * 64 + threadIdx.x;
     const long long b0 = (long long)tile * kTile;
@@ -513,10 +522,10 @@ __global__ void __launch_bounds__(64) unpack_errors_kernel(const u64 *errmask, l
 // llr transpose: llr_t[tile][n][64] -> llr[batch][n]; 64x64 tile through LDS
 __global__ void __launch_bounds__(256) unpack_llr_kernel(const double *llr_t, long long batch, int n,
                                                          double *llr, const int *index,
-                                                         const unsigned int *count_dev)
+                                                         const unsigned int *count_dev, unsigned int count_skip)
 {
     __shared__ double t[64][65];
-    if (count_dev) batch = (long long)*count_dev;
+    if (count_dev) { batch = (long long)*count_dev; if (batch <= (long long)count_skip) return; }   // uniform
     const int tile = blockIdx.y;
     const int j0 = blockIdx.x * 64;
     const long long b0 = (long long)tile * kTile;

@@ -100,8 +100,8 @@ __device__ __forceinline__ void lds_check_unit(double *M, int S, int deg, double
     }
 }
 
-template <int DV>
-__device__ __forceinline__ double lds_bit_unit(double *Ms, int S, const unsigned short *pos, int deg, double r)
+template <int DV, typename IDX>
+__device__ __forceinline__ double lds_bit_unit(double *Ms, int S, const IDX *pos, int deg, double r)
 {
     // Ms points at msg[sigma_lane]; edge e lives at Ms[e*S]
     double F = r;                                                     // :153
@@ -241,7 +241,7 @@ bp_lds_kernel(LdsParams p, const int *__restrict__ g_row_ptr, const int *__restr
                 if (in) {
                     const int c0 = col_ptr[j];
                     const int deg = col_ptr[j + 1] - c0;
-                    T = lds_bit_unit<DV>(M + sig, S, csc2csr + c0, deg, r);
+                    T = lds_bit_unit<DV, idx_t>(M + sig, S, csc2csr + c0, deg, r);
                     if (WANT_LLR) {
                         if ((active >> sig) & 1ull) L[(size_t)j * S + sig] = log(1.0 / T);   // :163
                     }

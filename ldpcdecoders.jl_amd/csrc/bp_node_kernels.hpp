@@ -1,0 +1,126 @@
+// bp_node_kernels.hpp -- small batches on Tanner graphs too large for the LDS kernel.
+//
+// The tile kernel (bp_kernels.hpp) puts one syndrome in one LANE: a batch of 1 (a plain decode!)
+// or of a few hundred on an n = 16384 code leaves the chip idle and takes 7 ... 136 ms, slower than
+// one CPU core.  Here one WORKGROUP owns one syndrome and a work item is one Tanner-graph node, as
+// in bp_lds_kernels.hpp with S = 1 -- but the edge messages live in a private slot of a global
+// workspace (nnz doubles, CSR order, updated in place), where the workgroup's own CU keeps them in
+// its L2: check i reads and writes its deg(i) contiguous messages, bit j gathers / scatters its
+// deg(j) messages through csc2csr.  Syndrome and hard-decision bytes sit in LDS; the graph is read
+// from global memory (coalesced along the node index).  Same arithmetic, same order as the other
+// two kernels and src/decoders/belief_propagation.jl:121-188 (the node updates ARE
+// lds_check_unit / lds_bit_unit).
+//
+// Throughput is poor by design: every message moves as an 8-byte access of its own, and a CU's
+// texture-address path retires about one such lane access per clock (n = 16384, nnz = 65536: ~123 us
+// per iteration, matching 2 x 65536 gathers/scatters + 65536 64-byte-strided pairs; batching several
+// nodes per thread to overlap the index -> message round trips changed nothing, so latency is not the
+// bound).  The host only picks this kernel while the tile kernel would leave most CUs without a tile.
+#pragma once
+#include "bp_lds_kernels.hpp"
+
+namespace ldpc {
+
+struct NodeParams {
+    int s, n, nnz;
+    int max_iters;
+    long long batch;
+    double r;
+    const unsigned char *syn;   // [batch][s]
+    unsigned char *err;         // [batch][n]
+    unsigned char *conv;        // [batch]
+    int *iters;                 // [batch] or nullptr
+    double *llr;                // [batch][n] or nullptr
+    double *msg;                // [gridDim.x][slot_stride] workspace
+    long long slot_stride;      // doubles per workgroup slot (>= nnz)
+    unsigned int *queue;
+    u64 *sum_iters;
+    // as the second pass of the tile kernel's straggler hand-off: syndrome q of this launch is syndrome
+    // index[q] of the batch, there are *count_dev of them, and above count_max the tile kernel takes them
+    const int *index;
+    const unsigned int *count_dev;
+    unsigned int count_max;
+};
+
+__host__ __device__ inline size_t node_lds_bytes(int s, int n) { return ((size_t)s + (size_t)n + 15) & ~(size_t)15; }
+
+template <int DC, int DV, bool WANT_LLR, int THREADS>
+__global__ void __launch_bounds__(THREADS)
+bp_node_kernel(NodeParams p, const int *__restrict__ row_ptr, const int *__restrict__ edge_bit,
+               const int *__restrict__ col_ptr, const int *__restrict__ csc2csr)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char node_lds[];
+    unsigned char *sbit = node_lds;           // [s] syndrome entry parity
+    unsigned char *ebit = node_lds + p.s;     // [n] hard decisions
+    __shared__ long long sh_b;
+    const int s = p.s, n = p.n;
+    const int tid = threadIdx.x;
+    const double r = p.r;
+    double *M = p.msg + (size_t)blockIdx.x * (size_t)p.slot_stride;
+    u64 acc_iters = 0;
+    long long batch = p.batch;
+    if (p.count_dev) {
+        batch = (long long)*p.count_dev;
+        if (batch > (long long)p.count_max) batch = 0;
+    }
+    for (;;) {
+        if (tid == 0) {
+            const long long q = (long long)atomicAdd(p.queue, 1u);
+            sh_b = q >= batch ? -1 : (p.index ? (long long)p.index[q] : q);
+        }
+        __syncthreads();
+        const long long b = sh_b;
+        if (b < 0) break;                      // every wave of every workgroup reaches this
+        // ---- syndrome in (:136: entries > 1 can never be matched by a parity bit)
+        int bad = 0;
+        for (int i = tid; i < s; i += THREADS) {
+            const unsigned v = p.syn[(size_t)b * s + i];
+            sbit[i] = (unsigned char)(v & 1u);
+            bad |= (v > 1u);
+        }
+        const int never = __syncthreads_or(bad);   // also orders sbit[] before the sweeps
+
+        int it = 0, converged = 0;
+        while (it < p.max_iters) {
+            ++it;
+            const bool first = (it == 1);
+            // ---- check sweep: one thread per check, its messages are contiguous
+            for (int i = tid; i < s; i += THREADS) {
+                const int e0 = row_ptr[i];
+                const int deg = row_ptr[i + 1] - e0;
+                const double sigma = sbit[i] ? -1.0 : 1.0;
+                lds_check_unit<DC>(M + e0, 1, deg, sigma, first, r);
+            }
+            __syncthreads();
+            // ---- variable sweep: one thread per bit
+            for (int j = tid; j < n; j += THREADS) {
+                const int c0 = col_ptr[j];
+                const int deg = col_ptr[j + 1] - c0;
+                const double T = lds_bit_unit<DV, int>(M, 1, csc2csr + c0, deg, r);
+                if (WANT_LLR) p.llr[(size_t)b * n + j] = log(1.0 / T);   // :163, final at the last iteration run
+                ebit[j] = (unsigned char)(T >= 1.0);                      // :164-168
+            }
+            __syncthreads();
+            // ---- convergence test (:180-184)
+            int mism = never;
+            for (int i = tid; i < s; i += THREADS) {
+                unsigned par = sbit[i];
+                const int e1 = row_ptr[i + 1];
+                for (int e = row_ptr[i]; e < e1; ++e) par ^= ebit[edge_bit[e]];
+                mism |= (int)par;
+            }
+            if (!__syncthreads_or(mism)) { converged = 1; break; }
+        }
+        // ---- results out
+        for (int j = tid; j < n; j += THREADS) p.err[(size_t)b * n + j] = (p.max_iters > 0) ? ebit[j] : (unsigned char)0;
+        if (tid == 0) {
+            p.conv[b] = (unsigned char)converged;
+            if (p.iters) p.iters[b] = it;
+            acc_iters += (u64)it;
+        }
+        __syncthreads();   // ebit[] / sbit[] / sh_b are rewritten by the next syndrome
+    }
+    if (tid == 0 && acc_iters) atomicAdd(p.sum_iters, acc_iters);
+}
+
+}  // namespace ldpc

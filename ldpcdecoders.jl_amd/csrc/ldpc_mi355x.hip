@@ -12,6 +12,7 @@
 #include "../../include/ldpc_mi355x.h"
 #include "bp_kernels.hpp"
 #include "bp_lds_kernels.hpp"
+#include "bp_node_kernels.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -140,6 +141,31 @@ lds_kernel_t pick_lds_kernel(int dc, int dv, bool llr, int threads)
     return llr ? lds_pick_dc<true>(dc, dv, threads) : lds_pick_dc<false>(dc, dv, threads);
 }
 
+typedef void (*node_kernel_t)(NodeParams, const int *, const int *, const int *, const int *);
+
+template <int DC, int DV, bool LLR>
+node_kernel_t node_pick_threads(int threads)
+{
+    return threads == 512 ? bp_node_kernel<DC, DV, LLR, 512> : bp_node_kernel<DC, DV, LLR, 1024>;
+}
+template <int DC, bool LLR>
+node_kernel_t node_pick_dv(int dv, int threads)
+{
+    if (dv <= 4) return node_pick_threads<DC, 4, LLR>(threads);
+    return node_pick_threads<DC, 16, LLR>(threads);
+}
+template <bool LLR>
+node_kernel_t node_pick_dc(int dc, int dv, int threads)
+{
+    if (dc <= 8) return node_pick_dv<8, LLR>(dv, threads);
+    if (dc <= 16) return node_pick_dv<16, LLR>(dv, threads);
+    return node_pick_dv<32, LLR>(dv, threads);
+}
+node_kernel_t pick_node_kernel(int dc, int dv, bool llr, int threads)
+{
+    return llr ? node_pick_dc<true>(dc, dv, threads) : node_pick_dc<false>(dc, dv, threads);
+}
+
 // How many syndromes per workgroup pass the LDS kernel holds (log2), or -1 if even one
 // syndrome's messages do not fit.  Workgroups per CU come first (the check sweep is VALU-bound, the
 // other phases are latency-bound: co-resident workgroups in different phases fill each other's
@@ -172,7 +198,10 @@ struct ldpc_bp_decoder {
     int last_threads = 512, last_grid = 0;   // geometry of the most recent streaming launch (info)
     size_t ws_budget = 0;     // bytes the message workspace may take
     int blocks_cache[2][17];  // [want_llr][waves per tile] -> resident workgroups per CU, -1 = not queried yet
-    int variant = 0;          // 0 auto, 1 HBM-streaming tile kernel, 2 LDS-resident kernel
+    int variant = 0;          // 0 auto, 1 HBM-streaming tile kernel, 2 LDS-resident kernel, 3 node-parallel kernel
+    bool node_ok = false;     // syndrome + decision bytes of one syndrome fit the LDS (bp_node_kernels.hpp)
+    int64_t node_max_batch = 0;   // auto: largest batch the node-parallel kernel takes from the tile kernel
+    DevBuf node_msg;          // [workgroups][nnz] double, the node-parallel kernel's message slots
     int lds_logS[2] = {-1, -1};   // [want_llr]: syndromes per workgroup pass of the LDS kernel, -1 = does not fit
     // device graph
     DevBuf row_ptr, edge_bit, col_ptr, csc2csr;
@@ -206,7 +235,7 @@ struct ldpc_bp_decoder {
     ~ldpc_bp_decoder()
     {
         DevBuf *all[] = {&row_ptr, &edge_bit, &col_ptr, &csc2csr, &msg, &ctrl, &synmask, &nevermask,
-                         &errmask, &llr_t, &st_all,
+                         &errmask, &llr_t, &st_all, &node_msg,
                          &defer_list, &synmask2, &nevermask2, &errmask2, &llr_t2};
         for (DevBuf *b : all) b->release();
         if (pin) (void)hipHostFree(pin);
@@ -472,7 +501,7 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     for (auto &row : d->blocks_cache)
         for (int &v : row) v = -1;
     d->variant = options ? options->kernel_variant : 0;
-    if (d->variant < 0 || d->variant > 2) { delete d; return fail(LDPC_ERR_INVALID_ARGUMENT, "kernel_variant must be 0, 1 or 2"); }
+    if (d->variant < 0 || d->variant > 3) { delete d; return fail(LDPC_ERR_INVALID_ARGUMENT, "kernel_variant must be 0, 1, 2 or 3"); }
     d->lds_logS[0] = lds_logS(s, n, nnz, false);
     d->lds_logS[1] = lds_logS(s, n, nnz, true);
     if (const char *e = std::getenv("LDPC_LDS_LOGS")) {   // tuning experiments only
@@ -486,6 +515,15 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
         delete d;
         return fail(LDPC_ERR_UNSUPPORTED, "kernel_variant 2 (LDS-resident) requested but the edge messages do not fit the LDS");
     }
+    d->node_ok = node_lds_bytes((int)s, (int)n) + 1024 <= (size_t)160 * 1024;
+    if (d->variant == 3 && !d->node_ok) {
+        delete d;
+        return fail(LDPC_ERR_UNSUPPORTED, "kernel_variant 3 (node-parallel) requested but s + n bytes do not fit the LDS");
+    }
+    // The tile kernel needs ~one 64-syndrome tile per CU before it beats one workgroup per syndrome
+    // (measured crossovers in DESIGN.md); LDPC_NODE_MAX_BATCH overrides for experiments.
+    d->node_max_batch = (int64_t)d->num_cus * 8;
+    if (const char *e = std::getenv("LDPC_NODE_MAX_BATCH")) d->node_max_batch = std::atoll(e);
     // keep the workspace inside a sane share of HBM (slots are nnz*512 B each)
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -528,7 +566,7 @@ ldpc_status ldpc_bp_get_info(const ldpc_bp_decoder *d, ldpc_bp_info *info)
     info->resident_tiles = d->last_grid;
     const DevBuf *all[] = {&d->row_ptr, &d->edge_bit, &d->col_ptr, &d->csc2csr, &d->msg, &d->ctrl, &d->synmask,
                            &d->nevermask, &d->errmask, &d->llr_t, &d->st_all, &d->defer_list, &d->synmask2,
-                           &d->nevermask2, &d->errmask2, &d->llr_t2, &d->pipe_dev[0], &d->pipe_dev[1], &d->pipe_dev[2]};
+                           &d->nevermask2, &d->errmask2, &d->llr_t2, &d->node_msg, &d->pipe_dev[0], &d->pipe_dev[1], &d->pipe_dev[2]};
     for (const DevBuf *b : all) info->workspace_bytes += (int64_t)b->cap;
     return LDPC_OK;
 }
@@ -560,7 +598,7 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
     }
 
     const bool want_llr_early = d_llr != nullptr;
-    if (d->variant != 1 && d->lds_logS[want_llr_early ? 1 : 0] >= 0) {
+    if (d->variant != 1 && d->variant != 3 && d->lds_logS[want_llr_early ? 1 : 0] >= 0) {
         // ---- on-chip path: messages never leave the LDS (bp_lds_kernels.hpp)
         const int logS = d->lds_logS[want_llr_early ? 1 : 0];
         const int64_t ngroups64 = (batch + (1ll << logS) - 1) >> logS;
@@ -599,6 +637,46 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
         HIP_TRY(hipEventRecord(ev[2], stream));
         HIP_TRY(hipEventRecord(ev[3], stream));
         d->timed[slot] = true;
+        return LDPC_OK;
+    }
+
+    if (d->node_ok && (d->variant == 3 || (d->variant == 0 && batch <= d->node_max_batch))) {
+        // ---- small batch on a large graph: one workgroup per syndrome, one thread per node (bp_node_kernels.hpp)
+        if (batch > (1ll << 30)) return fail(LDPC_ERR_UNSUPPORTED, "batch too large for one call");
+        // all 16 waves of a CU on one syndrome while there are CUs to spare, else two 8-wave workgroups per CU
+        const int nthreads = d->wpt_fixed ? (d->wpt_fixed >= 12 ? 1024 : 512) : (batch <= d->num_cus ? 1024 : 512);
+        const size_t nlds = node_lds_bytes((int)s, (int)n);
+        node_kernel_t nk = pick_node_kernel(d->max_cdeg, d->max_bdeg, want_llr_early, nthreads);
+        HIP_TRY(hipFuncSetAttribute((const void *)nk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nlds));
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)nk, nthreads, nlds) != hipSuccess || per_cu <= 0) {
+            (void)hipGetLastError();
+            per_cu = 1;
+        }
+        per_cu = std::min(per_cu, 2);
+        const int ngrid = (int)std::min<int64_t>(batch, (int64_t)per_cu * d->num_cus);
+        const size_t stride = (std::max<size_t>((size_t)d->nnz, 1) + 63) & ~(size_t)63;   // 512-byte aligned slots
+        ldpc_status nst = d->node_msg.ensure((size_t)ngrid * stride * sizeof(double));
+        if (nst != LDPC_OK) return nst;
+        NodeParams np;
+        np.s = (int)s; np.n = (int)n; np.nnz = (int)d->nnz; np.max_iters = (int)d->max_iters;
+        np.batch = batch; np.r = d->per / (1 - d->per);
+        np.syn = d_syn; np.err = d_err; np.conv = d_conv; np.iters = d_iters; np.llr = d_llr;
+        np.msg = (double *)d->node_msg.p; np.slot_stride = (long long)stride;
+        np.queue = (unsigned int *)ctrl;
+        np.sum_iters = (u64 *)(ctrl + 8);
+        np.index = nullptr; np.count_dev = nullptr; np.count_max = 0;
+        HIP_TRY(hipMemsetAsync(ctrl, 0, 64, stream));
+        HIP_TRY(hipEventRecord(ev[0], stream));
+        HIP_TRY(hipEventRecord(ev[1], stream));
+        hipLaunchKernelGGL(nk, dim3((unsigned)ngrid), dim3((unsigned)nthreads), nlds, stream, np,
+                           (const int *)d->row_ptr.p, (const int *)d->edge_bit.p, (const int *)d->col_ptr.p,
+                           (const int *)d->csc2csr.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev[2], stream));
+        HIP_TRY(hipEventRecord(ev[3], stream));
+        d->timed[slot] = true;
+        d->last_threads = nthreads; d->last_grid = ngrid;
         return LDPC_OK;
     }
 
@@ -660,6 +738,12 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
         HIP_TRY(hipMemsetAsync(d->nevermask2.p, 0, (size_t)ntiles2 * sizeof(u64), stream));
     }
     unsigned int *defer_count = (unsigned int *)(ctrl + 4);
+    // Few stragglers (the usual case): the second pass is the node-parallel kernel, one workgroup per
+    // syndrome straight from / into the caller's arrays, instead of a handful of tiles that each sweep
+    // the whole graph with one or two lanes alive.  Decided on the device: the launches of the path not
+    // taken find *defer_count on the wrong side of node_take and return at once.
+    const unsigned node_take = (thresh && d->node_ok && d->variant == 0 && d->node_max_batch > 0)
+                                   ? (unsigned)std::min<int64_t>(d->node_max_batch, (int64_t)ntiles * thresh) : 0u;
 
     HIP_TRY(hipMemsetAsync(ctrl, 0, 64, stream));
     HIP_TRY(hipMemsetAsync(d->nevermask.p, 0, (size_t)ntiles * sizeof(u64), stream));
@@ -668,7 +752,7 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
         dim3 g((unsigned)((s + 63) / 64), (unsigned)ntiles);
         hipLaunchKernelGGL(pack_syndromes_kernel, g, dim3(64), 0, stream, d_syn, (long long)batch, (int)s,
                            (u64 *)d->synmask.p, (u64 *)d->nevermask.p, (const int *)nullptr,
-                           (const unsigned int *)nullptr);
+                           (const unsigned int *)nullptr, 0u);
         HIP_TRY(hipGetLastError());
     }
     BPParams p;
@@ -690,6 +774,7 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
     p.defer_count = defer_count;
     p.index = nullptr;
     p.count_dev = nullptr;
+    p.count_skip = 0;
     bp_kernel_t kfn = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, threads);
     HIP_TRY(hipEventRecord(ev[1], stream));
     hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3((unsigned)threads), 0, stream, p,
@@ -703,7 +788,7 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
             dim3 g((unsigned)((s + 63) / 64), (unsigned)ntiles2);
             hipLaunchKernelGGL(pack_syndromes_kernel, g, dim3(64), 0, stream, d_syn, (long long)0, (int)s,
                                (u64 *)d->synmask2.p, (u64 *)d->nevermask2.p, (const int *)d->defer_list.p,
-                               (const unsigned int *)defer_count);
+                               (const unsigned int *)defer_count, node_take);
             HIP_TRY(hipGetLastError());
         }
         BPParams p2 = p;
@@ -713,6 +798,7 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
         p2.defer_thresh = 0;
         p2.index = (const int *)d->defer_list.p;
         p2.count_dev = defer_count;
+        p2.count_skip = node_take;
         bp_kernel_t kfn2 = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, threads, true);
         hipLaunchKernelGGL(kfn2, dim3((unsigned)std::min(grid, ntiles2)), dim3((unsigned)threads), 0, stream, p2,
                            (const int *)d->row_ptr.p, (const int *)d->edge_bit.p, (const int *)d->col_ptr.p,
@@ -723,26 +809,47 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
     if (n > 0) {
         dim3 g((unsigned)((n + 63) / 64), (unsigned)ntiles);
         hipLaunchKernelGGL(unpack_errors_kernel, g, dim3(64), 0, stream, (const u64 *)d->errmask.p,
-                           (long long)batch, (int)n, d_err, (const int *)nullptr, (const unsigned int *)nullptr);
+                           (long long)batch, (int)n, d_err, (const int *)nullptr, (const unsigned int *)nullptr, 0u);
         HIP_TRY(hipGetLastError());
         if (want_llr) {
             hipLaunchKernelGGL(unpack_llr_kernel, g, dim3(256), 0, stream, (const double *)d->llr_t.p,
-                               (long long)batch, (int)n, d_llr, (const int *)nullptr, (const unsigned int *)nullptr);
+                               (long long)batch, (int)n, d_llr, (const int *)nullptr, (const unsigned int *)nullptr, 0u);
             HIP_TRY(hipGetLastError());
         }
         if (thresh) {   // the second pass overwrites the rows the first pass gave up
             dim3 g2((unsigned)((n + 63) / 64), (unsigned)ntiles2);
             hipLaunchKernelGGL(unpack_errors_kernel, g2, dim3(64), 0, stream, (const u64 *)d->errmask2.p,
                                (long long)0, (int)n, d_err, (const int *)d->defer_list.p,
-                               (const unsigned int *)defer_count);
+                               (const unsigned int *)defer_count, node_take);
             HIP_TRY(hipGetLastError());
             if (want_llr) {
                 hipLaunchKernelGGL(unpack_llr_kernel, g2, dim3(256), 0, stream, (const double *)d->llr_t2.p,
                                    (long long)0, (int)n, d_llr, (const int *)d->defer_list.p,
-                                   (const unsigned int *)defer_count);
+                                   (const unsigned int *)defer_count, node_take);
                 HIP_TRY(hipGetLastError());
             }
         }
+    }
+    if (node_take) {
+        const int nthreads = 512;   // 1024 x 1 per CU measured the same
+        const size_t nlds = node_lds_bytes((int)s, (int)n);
+        node_kernel_t nk = pick_node_kernel(d->max_cdeg, d->max_bdeg, want_llr, nthreads);
+        HIP_TRY(hipFuncSetAttribute((const void *)nk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nlds));
+        const int ngrid = (int)std::min<int64_t>((int64_t)node_take, (int64_t)2 * d->num_cus);
+        const size_t stride = (std::max<size_t>((size_t)d->nnz, 1) + 63) & ~(size_t)63;
+        if ((st = d->node_msg.ensure((size_t)ngrid * stride * sizeof(double))) != LDPC_OK) return st;
+        NodeParams np;
+        np.s = (int)s; np.n = (int)n; np.nnz = (int)d->nnz; np.max_iters = (int)d->max_iters;
+        np.batch = 0; np.r = p.r;
+        np.syn = d_syn; np.err = d_err; np.conv = d_conv; np.iters = d_iters; np.llr = d_llr;
+        np.msg = (double *)d->node_msg.p; np.slot_stride = (long long)stride;
+        np.queue = (unsigned int *)(ctrl + 48);
+        np.sum_iters = (u64 *)(ctrl + 8);
+        np.index = (const int *)d->defer_list.p; np.count_dev = defer_count; np.count_max = node_take;
+        hipLaunchKernelGGL(nk, dim3((unsigned)ngrid), dim3((unsigned)nthreads), nlds, stream, np,
+                           (const int *)d->row_ptr.p, (const int *)d->edge_bit.p, (const int *)d->col_ptr.p,
+                           (const int *)d->csc2csr.p);
+        HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(ev[3], stream));
     d->timed[slot] = true;

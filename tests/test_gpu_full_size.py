@@ -79,6 +79,11 @@ def test_c3_full_batch(ldpc, gpu, per, subset):
     perm = torch.randperm(B, device=syn.device, generator=torch.Generator(device=syn.device).manual_seed(1))[:8192]
     e2, c2, i2 = _decode(ldpc, H, per, syn[perm].contiguous(), waves_per_tile=16, resident_tiles=100)
     assert torch.equal(e2, err[perm]) and torch.equal(c2, conv[perm]) and torch.equal(i2, its[perm])
+    # (3b) path independence on the WHOLE batch: auto (tile kernel, stragglers re-decoded by the
+    #      node-parallel kernel) against the forced all-tile path (stragglers re-decoded in packed tiles)
+    e3, c3, i3 = _decode(ldpc, H, per, syn, kernel_variant=1)
+    assert torch.equal(e3, err) and torch.equal(c3, conv) and torch.equal(i3, its)
+    del e3, c3, i3
     # (4) the oracle on a random subset
     idx = np.sort(np.random.default_rng(7).choice(B, subset, replace=False))
     tidx = torch.from_numpy(idx).to(syn.device)

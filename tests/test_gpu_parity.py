@@ -20,9 +20,10 @@ def assert_parity(ldpc, H, per, max_iters, syn_bs, **kw):
     M.sort_indices()
     oc = BPOracle(csc=(M.indptr, M.indices), shape=M.shape, per=per, max_iters=max_iters)
     oerr, oconv, ollr, oits = oc.batchdecode(syn_bs, want_llr=True)
-    # both kernels: 1 = HBM-streaming tile kernel, 0 = auto (the LDS-resident kernel whenever the
-    # edge messages fit the LDS, which is the case for every small code used here)
-    for variant in ([kw.pop("kernel_variant")] if "kernel_variant" in kw else [1, 0]):
+    # all three kernels: 1 = HBM-streaming tile kernel, 0 = auto (the LDS-resident kernel whenever the
+    # edge messages fit the LDS, which is the case for every small code used here; the node-parallel
+    # kernel for small batches on larger codes), 3 = node-parallel kernel (one workgroup per syndrome)
+    for variant in ([kw.pop("kernel_variant")] if "kernel_variant" in kw else [1, 0, 3]):
         dec = ldpc.BeliefPropagationDecoder(H, per, max_iters, kernel_variant=variant, **kw)
         err, conv, llr, its = dec.decode_batch_host(syn_bs, want_llr=True, want_iters=True)
         # a second call without LLRs exercises the other kernel instantiation
@@ -148,6 +149,23 @@ def test_c3_code_n16384_small_batch(ldpc, gpu):
         err, conv, its = assert_parity(ldpc, H, per, 50, ldpc.codes.syndromes_of(H, e))
         if per == 0.10:
             assert not conv.any() and (its == 50).all()
+
+
+@pytest.mark.parametrize("node_max", ["8", "256", None])
+def test_straggler_handoff_second_pass_kinds(ldpc, gpu, node_max, monkeypatch):
+    """A batch large enough for the tile kernel on a code beyond the LDS, broad iteration distribution:
+    tiles hand their stragglers to a second pass, which is the node-parallel kernel while there are at
+    most LDPC_NODE_MAX_BATCH of them (read at create) and packed tiles above that -- decided on the
+    device.  Every syndrome against the oracle, LLRs included."""
+    if node_max is not None:
+        monkeypatch.setenv("LDPC_NODE_MAX_BATCH", node_max)
+    n = 4096
+    H = ldpc.codes.parity_check_csc(n, 8, 4)
+    B = 2600 if node_max is None else 1200          # > the node-parallel kernel's own batch limit
+    e = ldpc.codes.random_errors(n, B, 0.065, seed=41)
+    syn = ldpc.codes.syndromes_of(H, e)
+    err, conv, its = assert_parity(ldpc, H, 0.065, 40, syn, kernel_variant=0)
+    assert 0.2 < conv.mean() and len(np.unique(its)) > 8   # the hand-off has something to do
 
 
 def test_device_resident_entry(ldpc, gpu):

@@ -49,7 +49,7 @@ while time.time() - t0 < budget:
         syn[rng.integers(0, B), rng.integers(0, s)] = rng.integers(2, 5)
     oc = BPOracle(csc=(H.indptr, H.indices), shape=H.shape, per=per, max_iters=iters)
     oerr, oconv, ollr, oits = oc.batchdecode(syn)
-    for variant in (0, 1):
+    for variant in (0, 1, 3):
         kw = dict(kernel_variant=variant, waves_per_tile=int(rng.choice([0, 4, 8, 16])),
                   defer_threshold=int(rng.choice([0, -1, 4, 40])))
         if rng.random() < 0.3:

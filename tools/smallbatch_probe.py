@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Small batches on codes too large for the LDS kernel: the tile kernel (kernel_variant 1, one syndrome
+per lane) against the node-parallel kernel (kernel_variant 3, one workgroup per syndrome), ms per
+call through the device-resident entry, next to the edge-list CPU oracle (one core).  Used to place
+the auto-dispatch crossover."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import ldpcdecoders_jl_amd as ldpc
+from oracle import BPOracle
+
+cases = [(4096, 0.02), (16384, 0.02), (16384, 0.10), (65536, 0.02)]
+batches = [int(x) for x in os.environ.get("BATCHES", "1,64,256,512,1024,2048,4096").split(",")]
+for n, per in cases:
+    H = ldpc.codes.parity_check_csc(n, 8, 4)
+    oc = BPOracle(csc=(H.indptr, H.indices), shape=H.shape, per=per, max_iters=50, dense=False)
+    decs = {v: ldpc.BeliefPropagationDecoder(H, per, 50, kernel_variant=v) for v in (1, 3)}
+    for batch in batches:
+        E = ldpc.codes.random_errors(n, batch, per, seed=3)
+        S = ldpc.codes.syndromes_of(H, E)
+        Sd = torch.from_numpy(np.ascontiguousarray(S)).cuda()
+        res = {}
+        outs = {}
+        for v, dec in decs.items():
+            err = torch.empty((batch, n), dtype=torch.uint8, device="cuda")
+            conv = torch.empty(batch, dtype=torch.uint8, device="cuda")
+            for _ in range(2):
+                dec.decode_batch_device(Sd, err, conv)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter(); dec.decode_batch_device(Sd, err, conv); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+            res[v] = np.median(ts) * 1e3
+            outs[v] = (err.cpu().numpy(), conv.cpu().numpy())
+        same = np.array_equal(outs[1][0], outs[3][0]) and np.array_equal(outs[1][1], outs[3][1])
+        t0 = time.perf_counter()
+        for b in range(min(batch, 4)):
+            oc.decode(S[b])
+        cpu = (time.perf_counter() - t0) / min(batch, 4)
+        print(f"n {n:6d} per {per:.2f} batch {batch:5d}: tile {res[1]:9.3f} ms  node {res[3]:9.3f} ms  identical {same}  "
+              f"CPU oracle {cpu*1e3:7.3f} ms/syndrome", flush=True)
+    for d in decs.values():
+        d.close()
