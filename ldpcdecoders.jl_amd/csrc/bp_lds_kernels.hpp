@@ -45,7 +45,28 @@ struct LdsParams {
     unsigned int *queue;
     u64 *sum_iters;
     u64 *phase_ticks;     // [3] 100 MHz ticks: check sweep, variable sweep, everything else (I/O, test, barriers)
+    // Latency mode of the host-pointer entry (a plain decode!): queue == nullptr, workgroup g decodes
+    // group g only (gridDim.x == ngroups); syn / err / ... are host-mapped, and the last workgroup to
+    // finish publishes done_ticket in the host-mapped word done_flag, on which the host spins.
+    unsigned int *done_count;   // device word, zero between launches
+    unsigned int *done_flag;    // nullptr = nobody is waiting
+    unsigned int done_ticket;
 };
+
+// every thread's stores have left for system memory before the workgroup reports; the last workgroup
+// re-arms the counter and raises the flag
+__device__ __forceinline__ void publish_done(unsigned int *done_count, unsigned int *done_flag, unsigned int ticket)
+{
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(done_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == gridDim.x - 1) {
+            __hip_atomic_store(done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(done_flag, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
 
 // LDS carve-up (bytes), shared by host and device
 __host__ __device__ inline size_t lds_bytes_needed(int s, int n, int nnz, int S, bool want_llr)
@@ -180,12 +201,19 @@ bp_lds_kernel(LdsParams p, const int *__restrict__ g_row_ptr, const int *__restr
     int g_next = 0, g_end = 0;                                    // the chunk of groups this workgroup holds
     for (;;) {
         if (g_next >= g_end) {
-            if (tid == 0) sh_group = (int)atomicAdd(p.queue, (unsigned)p.chunk);
-            __syncthreads();
-            g_next = sh_group;
-            g_end = min(g_next + p.chunk, p.ngroups);
-            __syncthreads();
-            if (g_next >= p.ngroups) break;   // every wave of every workgroup reaches this
+            if (!p.queue) {                   // latency mode: exactly one group per workgroup
+                if (g_end != 0 || (int)blockIdx.x >= p.ngroups) break;
+                g_next = (int)blockIdx.x;
+                g_end = g_next + 1;
+                __syncthreads();              // the graph copy above
+            } else {
+                if (tid == 0) sh_group = (int)atomicAdd(p.queue, (unsigned)p.chunk);
+                __syncthreads();
+                g_next = sh_group;
+                g_end = min(g_next + p.chunk, p.ngroups);
+                __syncthreads();
+                if (g_next >= p.ngroups) break;   // every wave of every workgroup reaches this
+            }
         }
         const int g = g_next++;
         const u64 tg0 = LDS_CLOCK();
@@ -307,7 +335,8 @@ bp_lds_kernel(LdsParams p, const int *__restrict__ g_row_ptr, const int *__restr
         }
         __syncthreads();
     }
-    if (tid == 0) {
+    if (p.done_flag) publish_done(p.done_count, p.done_flag, p.done_ticket);
+    if (tid == 0 && p.sum_iters) {
         atomicAdd(p.sum_iters, acc_iters);
         if (LDPC_LDS_STAMPS) {
             atomicAdd(&p.phase_ticks[0], acc_check);

@@ -40,6 +40,10 @@ struct NodeParams {
     const int *index;
     const unsigned int *count_dev;
     unsigned int count_max;
+    // latency mode (see LdsParams): queue == nullptr, workgroup g decodes syndrome g only
+    unsigned int *done_count;
+    unsigned int *done_flag;
+    unsigned int done_ticket;
 };
 
 __host__ __device__ inline size_t node_lds_bytes(int s, int n) { return ((size_t)s + (size_t)n + 15) & ~(size_t)15; }
@@ -63,13 +67,20 @@ bp_node_kernel(NodeParams p, const int *__restrict__ row_ptr, const int *__restr
         batch = (long long)*p.count_dev;
         if (batch > (long long)p.count_max) batch = 0;
     }
+    bool taken = false;
     for (;;) {
-        if (tid == 0) {
-            const long long q = (long long)atomicAdd(p.queue, 1u);
-            sh_b = q >= batch ? -1 : (p.index ? (long long)p.index[q] : q);
+        long long b;
+        if (!p.queue) {                        // latency mode: exactly one syndrome per workgroup
+            b = (taken || (long long)blockIdx.x >= batch) ? -1 : (long long)blockIdx.x;
+            taken = true;
+        } else {
+            if (tid == 0) {
+                const long long q = (long long)atomicAdd(p.queue, 1u);
+                sh_b = q >= batch ? -1 : (p.index ? (long long)p.index[q] : q);
+            }
+            __syncthreads();
+            b = sh_b;
         }
-        __syncthreads();
-        const long long b = sh_b;
         if (b < 0) break;                      // every wave of every workgroup reaches this
         // ---- syndrome in (:136: entries > 1 can never be matched by a parity bit)
         int bad = 0;
@@ -120,7 +131,8 @@ bp_node_kernel(NodeParams p, const int *__restrict__ row_ptr, const int *__restr
         }
         __syncthreads();   // ebit[] / sbit[] / sh_b are rewritten by the next syndrome
     }
-    if (tid == 0 && acc_iters) atomicAdd(p.sum_iters, acc_iters);
+    if (p.done_flag) publish_done(p.done_count, p.done_flag, p.done_ticket);
+    if (tid == 0 && acc_iters && p.sum_iters) atomicAdd(p.sum_iters, acc_iters);
 }
 
 }  // namespace ldpc

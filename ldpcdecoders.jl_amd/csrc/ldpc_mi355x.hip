@@ -21,6 +21,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 using namespace ldpc;
@@ -202,6 +203,16 @@ struct ldpc_bp_decoder {
     bool node_ok = false;     // syndrome + decision bytes of one syndrome fit the LDS (bp_node_kernels.hpp)
     int64_t node_max_batch = 0;   // auto: largest batch the node-parallel kernel takes from the tile kernel
     DevBuf node_msg;          // [workgroups][nnz] double, the node-parallel kernel's message slots
+    // latency mode of the host-pointer entry (tiny batches, a plain decode!): the kernel reads and writes a
+    // host-mapped staging image and raises a flag in it; no copies, no events, no stream synchronisation
+    DevBuf done_ctr;          // one device word, zero between launches
+    void *lat_pin = nullptr;  // [flag 256 B][syndromes][errors][converged][iters][llr], hipHostMallocMapped
+    void *lat_pin_dev = nullptr;
+    size_t lat_pin_cap = 0;
+    unsigned lat_ticket = 0;
+    // kernels whose dynamic-LDS limit is set / whose occupancy is known (both are ~us runtime calls)
+    std::vector<std::pair<const void *, int>> kernel_info;
+    ldpc_status prepare_kernel(const void *fn, int threads, size_t lds, int *per_cu);
     int lds_logS[2] = {-1, -1};   // [want_llr]: syndromes per workgroup pass of the LDS kernel, -1 = does not fit
     // device graph
     DevBuf row_ptr, edge_bit, col_ptr, csc2csr;
@@ -235,10 +246,11 @@ struct ldpc_bp_decoder {
     ~ldpc_bp_decoder()
     {
         DevBuf *all[] = {&row_ptr, &edge_bit, &col_ptr, &csc2csr, &msg, &ctrl, &synmask, &nevermask,
-                         &errmask, &llr_t, &st_all, &node_msg,
+                         &errmask, &llr_t, &st_all, &node_msg, &done_ctr,
                          &defer_list, &synmask2, &nevermask2, &errmask2, &llr_t2};
         for (DevBuf *b : all) b->release();
         if (pin) (void)hipHostFree(pin);
+        if (lat_pin) (void)hipHostFree(lat_pin);
         for (void *&q : pipe_pin)
             if (q) (void)hipHostFree(q);
         for (DevBuf &b : pipe_dev) b.release();
@@ -252,6 +264,21 @@ struct ldpc_bp_decoder {
                 if (e) (void)hipEventDestroy(e);
     }
 };
+
+ldpc_status ldpc_bp_decoder::prepare_kernel(const void *fn, int threads, size_t lds, int *per_cu)
+{
+    for (auto &ki : kernel_info)
+        if (ki.first == fn) { *per_cu = ki.second; return LDPC_OK; }
+    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, lds) != hipSuccess || nb <= 0) {
+        (void)hipGetLastError();
+        nb = 1;
+    }
+    kernel_info.emplace_back(fn, nb);
+    *per_cu = nb;
+    return LDPC_OK;
+}
 
 namespace {
 
@@ -535,6 +562,8 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     // the message workspace itself is allocated on first use, sized min(resident, tiles in the batch)
 
     if ((st = d->ctrl.ensure(64 * ldpc_bp_decoder::kRing)) != LDPC_OK) { delete d; return st; }
+    if ((st = d->done_ctr.ensure(64)) != LDPC_OK) { delete d; return st; }
+    if (hipMemset(d->done_ctr.p, 0, 64) != hipSuccess) { (void)hipGetLastError(); delete d; return fail(LDPC_ERR_HIP, "hipMemset failed"); }
     for (auto &slot : d->ev)
         for (hipEvent_t &e : slot) {
             if (hipEventCreate(&e) != hipSuccess) {
@@ -571,9 +600,27 @@ ldpc_status ldpc_bp_get_info(const ldpc_bp_decoder *d, ldpc_bp_info *info)
     return LDPC_OK;
 }
 
-ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const uint8_t *d_syn,
-                                        uint8_t *d_err, uint8_t *d_conv, double *d_llr, int32_t *d_iters,
-                                        void *stream_v)
+}  // extern "C"
+
+// Latency mode (see ldpc_bp_decoder::lat_pin): the word the last workgroup raises, and its value.
+struct LatencyCtl {
+    unsigned int *flag;
+    unsigned int ticket;
+};
+
+// Which kernel a batch goes to (shared by the device entry and the host entry's latency path).
+static bool takes_lds_kernel(const ldpc_bp_decoder *d, bool want_llr)
+{
+    return d->variant != 1 && d->variant != 3 && d->lds_logS[want_llr ? 1 : 0] >= 0;
+}
+static bool takes_node_kernel(const ldpc_bp_decoder *d, int64_t batch, bool want_llr)
+{
+    return !takes_lds_kernel(d, want_llr) && d->node_ok && (d->variant == 3 || (d->variant == 0 && batch <= d->node_max_batch));
+}
+
+static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const uint8_t *d_syn,
+                                      uint8_t *d_err, uint8_t *d_conv, double *d_llr, int32_t *d_iters,
+                                      void *stream_v, const LatencyCtl *lat)
 {
     if (!d) return fail(LDPC_ERR_INVALID_ARGUMENT, "decoder is NULL");
     if (batch < 0) return fail(LDPC_ERR_INVALID_ARGUMENT, "negative batch");
@@ -598,7 +645,7 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
     }
 
     const bool want_llr_early = d_llr != nullptr;
-    if (d->variant != 1 && d->variant != 3 && d->lds_logS[want_llr_early ? 1 : 0] >= 0) {
+    if (takes_lds_kernel(d, want_llr_early)) {
         // ---- on-chip path: messages never leave the LDS (bp_lds_kernels.hpp)
         const int logS = d->lds_logS[want_llr_early ? 1 : 0];
         const int64_t ngroups64 = (batch + (1ll << logS) - 1) >> logS;
@@ -611,6 +658,7 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
         lp.queue = (unsigned int *)ctrl;
         lp.sum_iters = (u64 *)(ctrl + 8);
         lp.phase_ticks = (u64 *)(ctrl + 16);
+        lp.done_count = (unsigned int *)d->done_ctr.p; lp.done_flag = nullptr; lp.done_ticket = 0;
         const size_t lds = lds_bytes_needed((int)s, (int)n, (int)d->nnz, 1 << logS, want_llr_early);
         // 512 threads when two or more workgroups share a CU; when the LDS footprint admits only
         // one, give that one all 16 waves (measured +21 % on the (9,10)-regular n=1000 code)
@@ -618,15 +666,21 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
         const int lthreads = d->wpt_fixed ? ((d->wpt_fixed == 4) ? 256 : (d->wpt_fixed >= 12 ? 1024 : 512))
                                           : (lone ? 1024 : 512);
         lds_kernel_t lk = pick_lds_kernel(d->max_cdeg, d->max_bdeg, want_llr_early, lthreads);
-        HIP_TRY(hipFuncSetAttribute((const void *)lk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)lk, lthreads, lds) != hipSuccess || per_cu <= 0) {
-            (void)hipGetLastError();
-            per_cu = 1;
-        }
+        ldpc_status pst = d->prepare_kernel((const void *)lk, lthreads, lds, &per_cu);
+        if (pst != LDPC_OK) return pst;
         const int lgrid = (int)std::min<int64_t>(ngroups64, (int64_t)per_cu * d->num_cus);
         // dequeue in chunks: ~16 dequeues per workgroup keep the load balanced and the queue word quiet
         lp.chunk = (int)std::max<int64_t>(1, std::min<int64_t>(64, ngroups64 / ((int64_t)lgrid * 16)));
+        if (lat) {   // one launch and nothing else: no queue, no statistics, no events
+            lp.queue = nullptr; lp.sum_iters = nullptr; lp.chunk = 1;
+            lp.done_flag = lat->flag; lp.done_ticket = lat->ticket;
+            hipLaunchKernelGGL(lk, dim3((unsigned)ngroups64), dim3((unsigned)lthreads), lds, stream, lp,
+                               (const int *)d->row_ptr.p, (const int *)d->edge_bit.p, (const int *)d->col_ptr.p,
+                               (const int *)d->csc2csr.p);
+            HIP_TRY(hipGetLastError());
+            return LDPC_OK;
+        }
         HIP_TRY(hipMemsetAsync(ctrl, 0, 64, stream));
         HIP_TRY(hipEventRecord(ev[0], stream));
         HIP_TRY(hipEventRecord(ev[1], stream));
@@ -640,21 +694,18 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
         return LDPC_OK;
     }
 
-    if (d->node_ok && (d->variant == 3 || (d->variant == 0 && batch <= d->node_max_batch))) {
+    if (takes_node_kernel(d, batch, want_llr_early)) {
         // ---- small batch on a large graph: one workgroup per syndrome, one thread per node (bp_node_kernels.hpp)
         if (batch > (1ll << 30)) return fail(LDPC_ERR_UNSUPPORTED, "batch too large for one call");
         // all 16 waves of a CU on one syndrome while there are CUs to spare, else two 8-wave workgroups per CU
         const int nthreads = d->wpt_fixed ? (d->wpt_fixed >= 12 ? 1024 : 512) : (batch <= d->num_cus ? 1024 : 512);
         const size_t nlds = node_lds_bytes((int)s, (int)n);
         node_kernel_t nk = pick_node_kernel(d->max_cdeg, d->max_bdeg, want_llr_early, nthreads);
-        HIP_TRY(hipFuncSetAttribute((const void *)nk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nlds));
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)nk, nthreads, nlds) != hipSuccess || per_cu <= 0) {
-            (void)hipGetLastError();
-            per_cu = 1;
-        }
+        ldpc_status pst = d->prepare_kernel((const void *)nk, nthreads, nlds, &per_cu);
+        if (pst != LDPC_OK) return pst;
         per_cu = std::min(per_cu, 2);
-        const int ngrid = (int)std::min<int64_t>(batch, (int64_t)per_cu * d->num_cus);
+        const int ngrid = lat ? (int)batch : (int)std::min<int64_t>(batch, (int64_t)per_cu * d->num_cus);
         const size_t stride = (std::max<size_t>((size_t)d->nnz, 1) + 63) & ~(size_t)63;   // 512-byte aligned slots
         ldpc_status nst = d->node_msg.ensure((size_t)ngrid * stride * sizeof(double));
         if (nst != LDPC_OK) return nst;
@@ -666,6 +717,16 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
         np.queue = (unsigned int *)ctrl;
         np.sum_iters = (u64 *)(ctrl + 8);
         np.index = nullptr; np.count_dev = nullptr; np.count_max = 0;
+        np.done_count = (unsigned int *)d->done_ctr.p; np.done_flag = nullptr; np.done_ticket = 0;
+        if (lat) {
+            np.queue = nullptr; np.sum_iters = nullptr;
+            np.done_flag = lat->flag; np.done_ticket = lat->ticket;
+            hipLaunchKernelGGL(nk, dim3((unsigned)ngrid), dim3((unsigned)nthreads), nlds, stream, np,
+                               (const int *)d->row_ptr.p, (const int *)d->edge_bit.p, (const int *)d->col_ptr.p,
+                               (const int *)d->csc2csr.p);
+            HIP_TRY(hipGetLastError());
+            return LDPC_OK;
+        }
         HIP_TRY(hipMemsetAsync(ctrl, 0, 64, stream));
         HIP_TRY(hipEventRecord(ev[0], stream));
         HIP_TRY(hipEventRecord(ev[1], stream));
@@ -680,6 +741,7 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
         return LDPC_OK;
     }
 
+    if (lat) return fail(LDPC_ERR_HIP, "internal: latency mode reached the tile kernel");
     const int64_t ntiles64 = (batch + kTile - 1) / kTile;
     if (ntiles64 > (1 << 30)) return fail(LDPC_ERR_UNSUPPORTED, "batch too large for one call");
     const int ntiles = (int)ntiles64;
@@ -834,7 +896,8 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
         const int nthreads = 512;   // 1024 x 1 per CU measured the same
         const size_t nlds = node_lds_bytes((int)s, (int)n);
         node_kernel_t nk = pick_node_kernel(d->max_cdeg, d->max_bdeg, want_llr, nthreads);
-        HIP_TRY(hipFuncSetAttribute((const void *)nk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nlds));
+        int per_cu_unused = 0;
+        if ((st = d->prepare_kernel((const void *)nk, nthreads, nlds, &per_cu_unused)) != LDPC_OK) return st;
         const int ngrid = (int)std::min<int64_t>((int64_t)node_take, (int64_t)2 * d->num_cus);
         const size_t stride = (std::max<size_t>((size_t)d->nnz, 1) + 63) & ~(size_t)63;
         if ((st = d->node_msg.ensure((size_t)ngrid * stride * sizeof(double))) != LDPC_OK) return st;
@@ -846,6 +909,7 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
         np.queue = (unsigned int *)(ctrl + 48);
         np.sum_iters = (u64 *)(ctrl + 8);
         np.index = (const int *)d->defer_list.p; np.count_dev = defer_count; np.count_max = node_take;
+        np.done_count = nullptr; np.done_flag = nullptr; np.done_ticket = 0;
         hipLaunchKernelGGL(nk, dim3((unsigned)ngrid), dim3((unsigned)nthreads), nlds, stream, np,
                            (const int *)d->row_ptr.p, (const int *)d->edge_bit.p, (const int *)d->col_ptr.p,
                            (const int *)d->csc2csr.p);
@@ -854,6 +918,15 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
     HIP_TRY(hipEventRecord(ev[3], stream));
     d->timed[slot] = true;
     return LDPC_OK;
+}
+
+extern "C" {
+
+ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const uint8_t *d_syn,
+                                        uint8_t *d_err, uint8_t *d_conv, double *d_llr, int32_t *d_iters,
+                                        void *stream_v)
+{
+    return decode_device_impl(d, batch, d_syn, d_err, d_conv, d_llr, d_iters, stream_v, nullptr);
 }
 
 ldpc_status ldpc_bp_decode_batch(ldpc_bp_decoder *d, int64_t batch, const uint8_t *syn, uint8_t *err,
@@ -874,6 +947,53 @@ ldpc_status ldpc_bp_decode_batch(ldpc_bp_decoder *d, int64_t batch, const uint8_
         auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
         const size_t o_err = up(B * s), o_conv = o_err + up(B * n), o_it = o_conv + up(B),
                      o_llr = o_it + up(B * sizeof(int32_t)), total = o_llr + (llr ? up(B * n * sizeof(double)) : 0);
+        // Tiny batches on the two kernels that read their input once (a plain decode! above all): the
+        // kernel works on a host-mapped image directly and raises a flag in it when the last workgroup
+        // is through -- ONE runtime call (the launch) instead of nine, no copies, no stream synchronisation.
+        static const bool lat_off = std::getenv("LDPC_NO_LATENCY_PATH") != nullptr;
+        const bool lds_k = takes_lds_kernel(d, llr != nullptr);
+        const int64_t lat_groups = lds_k ? ((batch + (1ll << d->lds_logS[llr ? 1 : 0]) - 1) >> d->lds_logS[llr ? 1 : 0]) : batch;
+        if (!lat_off && total <= ((size_t)256 << 10) && d->max_iters > 0 && lat_groups <= 2 * (int64_t)d->num_cus &&
+            (lds_k || takes_node_kernel(d, batch, llr != nullptr))) {
+            const size_t hdr = 256;
+            if (d->lat_pin_cap < hdr + total) {
+                if (d->lat_pin) (void)hipHostFree(d->lat_pin);
+                d->lat_pin = nullptr; d->lat_pin_cap = 0;
+                const size_t cap = hdr + ((size_t)256 << 10);
+                HIP_TRY(hipHostMalloc(&d->lat_pin, cap, hipHostMallocMapped | hipHostMallocCoherent));
+                std::memset(d->lat_pin, 0, hdr);
+                HIP_TRY(hipHostGetDevicePointer(&d->lat_pin_dev, d->lat_pin, 0));
+                d->lat_pin_cap = cap;
+            }
+            char *hp = (char *)d->lat_pin + hdr, *dp = (char *)d->lat_pin_dev + hdr;
+            volatile unsigned int *flag = (volatile unsigned int *)d->lat_pin;
+            if (++d->lat_ticket == 0) d->lat_ticket = 1;
+            const LatencyCtl lc{(unsigned int *)d->lat_pin_dev, d->lat_ticket};
+            std::memcpy(hp, syn, B * s);
+            st = decode_device_impl(d, batch, (const uint8_t *)dp, (uint8_t *)(dp + o_err), (uint8_t *)(dp + o_conv),
+                                    llr ? (double *)(dp + o_llr) : nullptr, (int32_t *)(dp + o_it), stream, &lc);
+            if (st != LDPC_OK) return st;
+            for (uint64_t spins = 1;; ++spins) {
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == lc.ticket) break;
+                if ((spins & 0xffff) == 0) {   // every ~65k polls: is the kernel still alive?
+                    const hipError_t q = hipStreamQuery(stream);
+                    if (q == hipSuccess) {
+                        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == lc.ticket) break;
+                        return fail(LDPC_ERR_HIP, "latency path: the kernel finished without raising its flag");
+                    }
+                    if (q != hipErrorNotReady) {
+                        (void)hipGetLastError();
+                        return fail(LDPC_ERR_HIP, std::string("latency path: ") + hipGetErrorString(q));
+                    }
+                }
+                __builtin_ia32_pause();
+            }
+            std::memcpy(err, hp + o_err, B * n);
+            std::memcpy(conv, hp + o_conv, B);
+            if (iters) std::memcpy(iters, hp + o_it, B * sizeof(int32_t));
+            if (llr) std::memcpy(llr, hp + o_llr, B * n * sizeof(double));
+            return LDPC_OK;
+        }
         if (total <= ((size_t)4 << 20)) {
             if ((st = d->st_all.ensure(total)) != LDPC_OK) return st;
             if (d->pin_cap < total) {
