@@ -16,6 +16,7 @@
 //     dependent ~1 us L2 round trip (measured: 2.9x on n=1008).
 #pragma once
 #include "bp_kernels.hpp"
+#include "latency_mode.hpp"
 
 #ifndef LDPC_LDS_STAMPS  // 1 = diagnostic build: in-kernel phase stamps (check / variable / rest)
 #define LDPC_LDS_STAMPS 0
@@ -52,21 +53,6 @@ struct LdsParams {
     unsigned int *done_flag;    // nullptr = nobody is waiting
     unsigned int done_ticket;
 };
-
-// every thread's stores have left for system memory before the workgroup reports; the last workgroup
-// re-arms the counter and raises the flag
-__device__ __forceinline__ void publish_done(unsigned int *done_count, unsigned int *done_flag, unsigned int ticket)
-{
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned prev = __hip_atomic_fetch_add(done_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev == gridDim.x - 1) {
-            __hip_atomic_store(done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(done_flag, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-}
 
 // LDS carve-up (bytes), shared by host and device
 __host__ __device__ inline size_t lds_bytes_needed(int s, int n, int nnz, int S, bool want_llr)

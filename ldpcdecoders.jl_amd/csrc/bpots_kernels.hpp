@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "portable_math.h"
+#include "latency_mode.hpp"
 
 namespace ldpc {
 
@@ -33,7 +34,10 @@ struct OtsParams {
     unsigned char *err;         // [batch][n]  best_decisions
     unsigned char *conv;        // [batch]
     int *iters;                 // [batch] or nullptr
-    unsigned int *queue;
+    unsigned int *queue;        // nullptr = latency mode: workgroup g decodes group g only (gridDim.x == ngroups)
+    unsigned int *done_count;   // latency mode: device word, zero between launches
+    unsigned int *done_flag;    // host-mapped word the last workgroup stores done_ticket into (nullptr = nobody waits)
+    unsigned int done_ticket;
 };
 
 constexpr int kOtsThreads = 512;
@@ -101,12 +105,19 @@ bpots_lds_kernel(OtsParams p, const int *__restrict__ g_row_ptr, const int *__re
     int g_next = 0, g_end = 0;
     for (;;) {
         if (g_next >= g_end) {
-            if (tid == 0) sh_group = (int)atomicAdd(p.queue, (unsigned)p.chunk);
-            __syncthreads();
-            g_next = sh_group;
-            g_end = min(g_next + p.chunk, p.ngroups);
-            __syncthreads();
-            if (g_next >= p.ngroups) break;
+            if (!p.queue) {
+                if (g_end != 0 || (int)blockIdx.x >= p.ngroups) break;
+                g_next = (int)blockIdx.x;
+                g_end = g_next + 1;
+                __syncthreads();              // the graph copy above
+            } else {
+                if (tid == 0) sh_group = (int)atomicAdd(p.queue, (unsigned)p.chunk);
+                __syncthreads();
+                g_next = sh_group;
+                g_end = min(g_next + p.chunk, p.ngroups);
+                __syncthreads();
+                if (g_next >= p.ngroups) break;
+            }
         }
         const int g = g_next++;
         const long long b0 = (long long)g << logS;
@@ -302,6 +313,7 @@ bpots_lds_kernel(OtsParams p, const int *__restrict__ g_row_ptr, const int *__re
         }
         __syncthreads();
     }
+    if (p.done_flag) publish_done(p.done_count, p.done_flag, p.done_ticket);
 }
 
 }  // namespace ldpc

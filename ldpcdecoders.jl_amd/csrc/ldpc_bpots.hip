@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -38,11 +39,19 @@ struct ldpc_bpots_decoder {
     unsigned int *queue = nullptr;
     void *stage = nullptr;      // device staging for the host-pointer entry
     size_t stage_cap = 0;
+    // latency path of the host-pointer entry (DESIGN.md "Latency path"): host-mapped I/O image with a flag word
+    unsigned int *done_ctr = nullptr;
+    void *lat_pin = nullptr, *lat_pin_dev = nullptr;
+    size_t lat_pin_cap = 0;
+    unsigned lat_ticket = 0;
+    bool kernel_ready = false;  // dynamic-LDS limit set, occupancy known
+    int per_cu = 1;
     ~ldpc_bpots_decoder()
     {
-        void *all[] = {row_ptr, csc_row, col_ptr, csc2csr, queue, stage};
+        void *all[] = {row_ptr, csc_row, col_ptr, csc2csr, queue, stage, done_ctr};
         for (void *q : all)
             if (q) (void)hipFree(q);
+        if (lat_pin) (void)hipHostFree(lat_pin);
     }
 };
 
@@ -129,7 +138,8 @@ ldpc_status ldpc_bpots_create(int64_t s, int64_t n, int64_t nnz, const int64_t *
         return hipMemcpy(dst, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
     };
     if (!up(d->row_ptr, row_ptr) || !up(d->csc_row, csc_row) || !up(d->col_ptr, col_ptr) || !up(d->csc2csr, csc2csr) ||
-        hipMalloc((void **)&d->queue, 64) != hipSuccess) {
+        hipMalloc((void **)&d->queue, 64) != hipSuccess || hipMalloc((void **)&d->done_ctr, 64) != hipSuccess ||
+        hipMemset(d->done_ctr, 0, 64) != hipSuccess) {
         (void)hipGetLastError();
         delete d;
         return set_error(LDPC_ERR_OUT_OF_MEMORY, "device allocation of the Tanner graph failed");
@@ -147,8 +157,15 @@ ldpc_status ldpc_bpots_destroy(ldpc_bpots_decoder *d)
     return LDPC_OK;
 }
 
-ldpc_status ldpc_bpots_decode_batch_device(ldpc_bpots_decoder *d, int64_t batch, const uint8_t *d_syn, uint8_t *d_err,
-                                           uint8_t *d_conv, int32_t *d_iters, void *stream_v)
+}  // extern "C"
+
+struct OtsLatencyCtl {
+    unsigned int *flag;
+    unsigned int ticket;
+};
+
+static ldpc_status bpots_decode_impl(ldpc_bpots_decoder *d, int64_t batch, const uint8_t *d_syn, uint8_t *d_err,
+                                     uint8_t *d_conv, int32_t *d_iters, void *stream_v, const OtsLatencyCtl *lat)
 {
     if (!d) return set_error(LDPC_ERR_INVALID_ARGUMENT, "decoder is NULL");
     if (batch < 0) return set_error(LDPC_ERR_INVALID_ARGUMENT, "negative batch");
@@ -172,19 +189,40 @@ ldpc_status ldpc_bpots_decode_batch_device(ldpc_bpots_decoder *d, int64_t batch,
     p.syn = d_syn; p.err = d_err; p.conv = d_conv; p.iters = d_iters; p.queue = d->queue;
     const size_t lds = ots_lds_bytes((int)d->s, (int)d->n, (int)d->nnz, 1 << d->logS);
     ots_kernel_t k = pick_ots(d->max_cdeg, d->max_bdeg);
-    OTS_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k, kOtsThreads, lds) != hipSuccess || per_cu <= 0) {
-        (void)hipGetLastError();
-        per_cu = 1;
+    if (!d->kernel_ready) {
+        OTS_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k, kOtsThreads, lds) != hipSuccess || per_cu <= 0) {
+            (void)hipGetLastError();
+            per_cu = 1;
+        }
+        d->per_cu = per_cu;
+        d->kernel_ready = true;
     }
-    const int grid = (int)std::min<int64_t>(ngroups, (int64_t)per_cu * d->num_cus);
+    p.done_count = d->done_ctr; p.done_flag = nullptr; p.done_ticket = 0;
+    if (lat) {   // one workgroup per group, no queue to reset: the launch is the only runtime call
+        p.queue = nullptr; p.chunk = 1;
+        p.done_flag = lat->flag; p.done_ticket = lat->ticket;
+        hipLaunchKernelGGL(k, dim3((unsigned)ngroups), dim3(kOtsThreads), lds, stream, p, (const int *)d->row_ptr,
+                           (const int *)d->csc_row, (const int *)d->col_ptr, (const int *)d->csc2csr);
+        OTS_TRY(hipGetLastError());
+        return LDPC_OK;
+    }
+    const int grid = (int)std::min<int64_t>(ngroups, (int64_t)d->per_cu * d->num_cus);
     p.chunk = (int)std::max<int64_t>(1, std::min<int64_t>(64, ngroups / ((int64_t)grid * 16)));
     OTS_TRY(hipMemsetAsync(d->queue, 0, 64, stream));
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kOtsThreads), lds, stream, p, (const int *)d->row_ptr,
                        (const int *)d->csc_row, (const int *)d->col_ptr, (const int *)d->csc2csr);
     OTS_TRY(hipGetLastError());
     return LDPC_OK;
+}
+
+extern "C" {
+
+ldpc_status ldpc_bpots_decode_batch_device(ldpc_bpots_decoder *d, int64_t batch, const uint8_t *d_syn, uint8_t *d_err,
+                                           uint8_t *d_conv, int32_t *d_iters, void *stream_v)
+{
+    return bpots_decode_impl(d, batch, d_syn, d_err, d_conv, d_iters, stream_v, nullptr);
 }
 
 ldpc_status ldpc_bpots_decode_batch(ldpc_bpots_decoder *d, int64_t batch, const uint8_t *syn, uint8_t *err,
@@ -198,6 +236,45 @@ ldpc_status ldpc_bpots_decode_batch(ldpc_bpots_decoder *d, int64_t batch, const 
     const size_t s = (size_t)d->s, n = (size_t)d->n, B = (size_t)batch;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o_err = up(B * s), o_conv = o_err + up(B * n), o_it = o_conv + up(B), total = o_it + up(B * 4);
+    static const bool lat_off = std::getenv("LDPC_NO_LATENCY_PATH") != nullptr;
+    const int64_t lat_groups = (batch + (1ll << d->logS) - 1) >> d->logS;
+    if (!lat_off && total <= ((size_t)256 << 10) && d->max_iters > 0 && lat_groups <= 2 * (int64_t)d->num_cus) {
+        const size_t hdr = 256;
+        if (!d->lat_pin) {
+            const size_t cap = hdr + ((size_t)256 << 10);
+            OTS_TRY(hipHostMalloc(&d->lat_pin, cap, hipHostMallocMapped | hipHostMallocCoherent));
+            std::memset(d->lat_pin, 0, hdr);
+            OTS_TRY(hipHostGetDevicePointer(&d->lat_pin_dev, d->lat_pin, 0));
+            d->lat_pin_cap = cap;
+        }
+        char *hp = (char *)d->lat_pin + hdr, *dp = (char *)d->lat_pin_dev + hdr;
+        volatile unsigned int *flag = (volatile unsigned int *)d->lat_pin;
+        if (++d->lat_ticket == 0) d->lat_ticket = 1;
+        const OtsLatencyCtl lc{(unsigned int *)d->lat_pin_dev, d->lat_ticket};
+        std::memcpy(hp, syn, B * s);
+        ldpc_status lst = bpots_decode_impl(d, batch, (const uint8_t *)dp, (uint8_t *)(dp + o_err), (uint8_t *)(dp + o_conv),
+                                            (int32_t *)(dp + o_it), nullptr, &lc);
+        if (lst != LDPC_OK) return lst;
+        for (uint64_t spins = 1;; ++spins) {
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == lc.ticket) break;
+            if ((spins & 0xffff) == 0) {   // every ~65k polls: is the kernel still alive?
+                const hipError_t q = hipStreamQuery(nullptr);
+                if (q == hipSuccess) {
+                    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == lc.ticket) break;
+                    return set_error(LDPC_ERR_HIP, "latency path: the kernel finished without raising its flag");
+                }
+                if (q != hipErrorNotReady) {
+                    (void)hipGetLastError();
+                    return set_error(LDPC_ERR_HIP, std::string("latency path: ") + hipGetErrorString(q));
+                }
+            }
+            __builtin_ia32_pause();
+        }
+        std::memcpy(err, hp + o_err, B * n);
+        std::memcpy(conv, hp + o_conv, B);
+        if (iters) std::memcpy(iters, hp + o_it, B * sizeof(int32_t));
+        return LDPC_OK;
+    }
     if (d->stage_cap < total) {
         if (d->stage) (void)hipFree(d->stage);
         d->stage = nullptr; d->stage_cap = 0;
