@@ -171,3 +171,41 @@ def test_large_host_batch_goes_through_the_chunked_pipeline(ldpc, gpu):
     oc = BPOracle(csc=(H.indptr, H.indices), shape=H.shape, per=0.02, max_iters=40)
     oerr, oconv, _, oits = oc.batchdecode(syn[idx], want_llr=False)
     assert np.array_equal(err[idx], oerr) and np.array_equal(conv[idx], oconv) and np.array_equal(its[idx], oits)
+
+
+def test_decoder_lifecycle_does_not_leak_device_memory(ldpc, gpu):
+    """Create / decode / destroy many decoders of every kind (LDS, node-parallel, tile kernels, BP-OTS,
+    BP+OSD; latency path and staged path): device memory returns to where it started, and handles of
+    different kinds can be alive at the same time."""
+    import torch
+
+    H1 = ldpc.codes.parity_check_csc(1008, 6, 3)
+    H2 = ldpc.codes.parity_check_csc(4096, 8, 4)
+    S1 = ldpc.codes.syndromes_of(H1, ldpc.codes.random_errors(1008, 300, 0.01, seed=1))
+    S2 = ldpc.codes.syndromes_of(H2, ldpc.codes.random_errors(4096, 300, 0.02, seed=2))
+
+    def round_trip():
+        a = ldpc.BeliefPropagationDecoder(H1, 0.01, 50)
+        b = ldpc.BeliefPropagationDecoder(H2, 0.02, 50)                     # node-parallel for small batches
+        c = ldpc.BeliefPropagationDecoder(H2, 0.02, 50, kernel_variant=1)    # tile kernel
+        o = ldpc.BPOTSDecoder(H1, 0.01, 30)
+        q = ldpc.BeliefPropagationOSDDecoder(H1, 0.01, 20, osd_order=2)
+        r1 = a.decode_batch_host(S1[:1])            # latency path
+        r2 = a.decode_batch_host(S1, want_llr=True)  # staged path
+        r3 = b.decode_batch_host(S2[:3])
+        r4 = c.decode_batch_host(S2[:130], want_llr=True)
+        o.decode_batch_host(S1[:2])
+        q.decode_(S1[0])
+        assert np.array_equal(r1[0][0], r2[0][0]) and np.array_equal(r3[0], r4[0][:3])
+        for d in (a, b, c, o):
+            d.close()
+        del q
+
+    round_trip()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(25):
+        round_trip()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (64 << 20), f"device memory shrank by {(free0 - free1) >> 20} MiB over 25 decoder life cycles"

@@ -90,3 +90,24 @@ def test_non_binary_syndrome_never_converges():
     py = DensePyBP(H.tolist(), 0.1, 7)
     perr, pconv = py.decode([2, 0, 0, 0])
     assert not pconv and np.array_equal(err2, np.asarray(perr))
+
+
+def test_oracles_under_sanitizers(tmp_path):
+    """The C oracles themselves under AddressSanitizer + UBSan (tests/native/oracle_sanitize.c): random
+    irregular graphs, per from 0 to 1, non-binary syndromes; edge-list and dense storage agree bit for bit."""
+    import os
+    import shutil
+    import subprocess
+
+    import pytest
+
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "oracle_sanitize")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-g", "-ffp-contract=off", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=all", "-I", os.path.join(root, "ldpcdecoders.jl_amd", "csrc"), "-o", exe,
+                           os.path.join(root, "tests", "native", "oracle_sanitize.c"), os.path.join(root, "oracle", "bp_oracle.c"),
+                           os.path.join(root, "oracle", "bpots_oracle.c"), "-lm"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr

@@ -92,3 +92,24 @@ def test_non_binary_syndrome_rejected():
     syn[0, 0] = 2
     with pytest.raises(ldpc.LdpcError):
         post.postprocess(syn, np.zeros((1, 96), np.uint8), np.zeros((1, 96)))
+
+
+def test_osd_host_under_sanitizers(tmp_path):
+    """osd_host.cpp built with AddressSanitizer + UBSan (CPU only; the GPU pool offers no sanitizers) and
+    driven by tests/native/osd_sanitize.cpp: ~8.6k syndrome x order x thread cases against the dense
+    oracle, rank-deficient matrices and reliability ties included."""
+    import os
+    import shutil
+    import subprocess
+
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    san = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all"]
+    obj = str(tmp_path / "osd_oracle.o")
+    subprocess.check_call(["gcc", "-std=c11", "-ffp-contract=off", *san, "-c", os.path.join(root, "oracle", "osd_oracle.c"), "-o", obj])
+    exe = str(tmp_path / "osd_sanitize")
+    subprocess.check_call(["g++", "-std=c++17", *san, "-o", exe, os.path.join(root, "tests", "native", "osd_sanitize.cpp"),
+                           os.path.join(root, "ldpcdecoders.jl_amd", "csrc", "osd_host.cpp"), obj, "-lpthread", "-lm"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
