@@ -49,6 +49,8 @@ struct LdsParams {
     // Latency mode of the host-pointer entry (a plain decode!): queue == nullptr, workgroup g decodes
     // group g only (gridDim.x == ngroups); syn / err / ... are host-mapped, and the last workgroup to
     // finish publishes done_ticket in the host-mapped word done_flag, on which the host spins.
+    u64 *next_ctrl;             // the NEXT call's 64-byte control slot: zeroed here, so that that call needs no memset
+                                // (calls on one handle are ordered; nullptr = leave it alone)
     unsigned int *done_count;   // device word, zero between launches
     unsigned int *done_flag;    // nullptr = nobody is waiting
     unsigned int done_ticket;
@@ -322,6 +324,7 @@ bp_lds_kernel(LdsParams p, const int *__restrict__ g_row_ptr, const int *__restr
         __syncthreads();
     }
     if (p.done_flag) publish_done(p.done_count, p.done_flag, p.done_ticket);
+    if (p.next_ctrl && blockIdx.x == 0 && tid < 8) p.next_ctrl[tid] = 0;   // (at the end: up front it cost 6 VGPRs and a workgroup per CU)
     if (tid == 0 && p.sum_iters) {
         atomicAdd(p.sum_iters, acc_iters);
         if (LDPC_LDS_STAMPS) {

@@ -40,6 +40,7 @@ struct NodeParams {
     const int *index;
     const unsigned int *count_dev;
     unsigned int count_max;
+    u64 *next_ctrl;             // see LdsParams
     // latency mode (see LdsParams): queue == nullptr, workgroup g decodes syndrome g only
     unsigned int *done_count;
     unsigned int *done_flag;
@@ -62,6 +63,7 @@ bp_node_kernel(NodeParams p, const int *__restrict__ row_ptr, const int *__restr
     const double r = p.r;
     double *M = p.msg + (size_t)blockIdx.x * (size_t)p.slot_stride;
     u64 acc_iters = 0;
+    if (p.next_ctrl && blockIdx.x == 0 && tid < 8) p.next_ctrl[tid] = 0;
     long long batch = p.batch;
     if (p.count_dev) {
         batch = (long long)*p.count_dev;

@@ -238,9 +238,14 @@ struct ldpc_bp_decoder {
     hipStream_t pipe_stream[3] = {};          // H2D, compute, D2H
     hipEvent_t pipe_ev[kPipe][3] = {};        // per slot: H2D done, compute done, D2H done
     // timing ring: the last kRing batch calls keep their HIP events and iteration sums
-    static constexpr int kRing = 16;
+    // (the API reaches 16 calls back; the ring is twice that so that a kernel may zero the control
+    // slot of the call after it -- which is the slot of the call 31 back -- without touching history)
+    static constexpr int kRing = 32;
+    static constexpr int kHistory = 16;
     hipEvent_t ev[kRing][4] = {};
     bool timed[kRing] = {};
+    bool two_events[kRing] = {};   // the call recorded ev[1] / ev[2] only (single-kernel paths)
+    bool ctrl_clean[kRing] = {};   // the slot's 64 control bytes are known to be zero
     uint64_t ncalls = 0;
 
     ~ldpc_bp_decoder()
@@ -562,6 +567,8 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     // the message workspace itself is allocated on first use, sized min(resident, tiles in the batch)
 
     if ((st = d->ctrl.ensure(64 * ldpc_bp_decoder::kRing)) != LDPC_OK) { delete d; return st; }
+    if (hipMemset(d->ctrl.p, 0, 64 * ldpc_bp_decoder::kRing) != hipSuccess) { (void)hipGetLastError(); delete d; return fail(LDPC_ERR_HIP, "hipMemset failed"); }
+    for (bool &c : d->ctrl_clean) c = true;
     if ((st = d->done_ctr.ensure(64)) != LDPC_OK) { delete d; return st; }
     if (hipMemset(d->done_ctr.p, 0, 64) != hipSuccess) { (void)hipGetLastError(); delete d; return fail(LDPC_ERR_HIP, "hipMemset failed"); }
     for (auto &slot : d->ev)
@@ -629,6 +636,12 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     hipEvent_t *ev = d->ev[slot];
     char *ctrl = (char *)d->ctrl.p + 64 * slot;
     d->timed[slot] = false;
+    d->two_events[slot] = false;
+    // single-kernel paths: the kernel zeroes the control slot of the NEXT call, so a call that finds its
+    // slot clean enqueues no memset, and only two events bracket the one kernel (measured on C2, batch
+    // 4096: fill kernel 3.5 us + ~10 us of dependency gap on either side of a 94 us decode kernel)
+    const int nslot = (slot + 1) % ldpc_bp_decoder::kRing;
+    char *next_ctrl = (char *)d->ctrl.p + 64 * nslot;
     if (batch == 0) return LDPC_OK;
     if ((d->s > 0 && !d_syn) || (d->n > 0 && !d_err) || !d_conv)
         return fail(LDPC_ERR_INVALID_ARGUMENT, "syndromes/errors/converged pointer is NULL");
@@ -659,6 +672,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         lp.sum_iters = (u64 *)(ctrl + 8);
         lp.phase_ticks = (u64 *)(ctrl + 16);
         lp.done_count = (unsigned int *)d->done_ctr.p; lp.done_flag = nullptr; lp.done_ticket = 0;
+        lp.next_ctrl = nullptr;
         const size_t lds = lds_bytes_needed((int)s, (int)n, (int)d->nnz, 1 << logS, want_llr_early);
         // 512 threads when two or more workgroups share a CU; when the LDS footprint admits only
         // one, give that one all 16 waves (measured +21 % on the (9,10)-regular n=1000 code)
@@ -681,16 +695,19 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             HIP_TRY(hipGetLastError());
             return LDPC_OK;
         }
-        HIP_TRY(hipMemsetAsync(ctrl, 0, 64, stream));
-        HIP_TRY(hipEventRecord(ev[0], stream));
+        if (!d->ctrl_clean[slot]) HIP_TRY(hipMemsetAsync(ctrl, 0, 64, stream));
+        d->ctrl_clean[slot] = false;
+        lp.next_ctrl = (u64 *)next_ctrl;
         HIP_TRY(hipEventRecord(ev[1], stream));
         hipLaunchKernelGGL(lk, dim3((unsigned)lgrid), dim3((unsigned)lthreads), lds, stream, lp,
                            (const int *)d->row_ptr.p, (const int *)d->edge_bit.p, (const int *)d->col_ptr.p,
                            (const int *)d->csc2csr.p);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev[2], stream));
-        HIP_TRY(hipEventRecord(ev[3], stream));
+        d->ctrl_clean[nslot] = true;
+        d->timed[nslot] = false;
         d->timed[slot] = true;
+        d->two_events[slot] = true;
         return LDPC_OK;
     }
 
@@ -718,6 +735,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         np.sum_iters = (u64 *)(ctrl + 8);
         np.index = nullptr; np.count_dev = nullptr; np.count_max = 0;
         np.done_count = (unsigned int *)d->done_ctr.p; np.done_flag = nullptr; np.done_ticket = 0;
+        np.next_ctrl = nullptr;
         if (lat) {
             np.queue = nullptr; np.sum_iters = nullptr;
             np.done_flag = lat->flag; np.done_ticket = lat->ticket;
@@ -727,15 +745,18 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             HIP_TRY(hipGetLastError());
             return LDPC_OK;
         }
-        HIP_TRY(hipMemsetAsync(ctrl, 0, 64, stream));
-        HIP_TRY(hipEventRecord(ev[0], stream));
+        if (!d->ctrl_clean[slot]) HIP_TRY(hipMemsetAsync(ctrl, 0, 64, stream));
+        d->ctrl_clean[slot] = false;
+        np.next_ctrl = (u64 *)next_ctrl;
         HIP_TRY(hipEventRecord(ev[1], stream));
         hipLaunchKernelGGL(nk, dim3((unsigned)ngrid), dim3((unsigned)nthreads), nlds, stream, np,
                            (const int *)d->row_ptr.p, (const int *)d->edge_bit.p, (const int *)d->col_ptr.p,
                            (const int *)d->csc2csr.p);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev[2], stream));
-        HIP_TRY(hipEventRecord(ev[3], stream));
+        d->ctrl_clean[nslot] = true;
+        d->timed[nslot] = false;
+        d->two_events[slot] = true;
         d->timed[slot] = true;
         d->last_threads = nthreads; d->last_grid = ngrid;
         return LDPC_OK;
@@ -808,6 +829,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
                                    ? (unsigned)std::min<int64_t>(d->node_max_batch, (int64_t)ntiles * thresh) : 0u;
 
     HIP_TRY(hipMemsetAsync(ctrl, 0, 64, stream));
+    d->ctrl_clean[slot] = false;
     HIP_TRY(hipMemsetAsync(d->nevermask.p, 0, (size_t)ntiles * sizeof(u64), stream));
     HIP_TRY(hipEventRecord(ev[0], stream));
     if (s > 0) {
@@ -909,7 +931,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         np.queue = (unsigned int *)(ctrl + 48);
         np.sum_iters = (u64 *)(ctrl + 8);
         np.index = (const int *)d->defer_list.p; np.count_dev = defer_count; np.count_max = node_take;
-        np.done_count = nullptr; np.done_flag = nullptr; np.done_ticket = 0;
+        np.done_count = nullptr; np.done_flag = nullptr; np.done_ticket = 0; np.next_ctrl = nullptr;
         hipLaunchKernelGGL(nk, dim3((unsigned)ngrid), dim3((unsigned)nthreads), nlds, stream, np,
                            (const int *)d->row_ptr.p, (const int *)d->edge_bit.p, (const int *)d->col_ptr.p,
                            (const int *)d->csc2csr.p);
@@ -1105,15 +1127,16 @@ ldpc_status ldpc_bp_call_timing(ldpc_bp_decoder *d, int32_t calls_back, double *
     if (sweep_ms) *sweep_ms = 0.0;
     if (total_ms) *total_ms = 0.0;
     if (sum_iters) *sum_iters = 0;
-    if (calls_back < 0 || calls_back >= ldpc_bp_decoder::kRing || (uint64_t)calls_back >= d->ncalls)
+    if (calls_back < 0 || calls_back >= ldpc_bp_decoder::kHistory || (uint64_t)calls_back >= d->ncalls)
         return fail(LDPC_ERR_INVALID_ARGUMENT, "calls_back outside the timing ring");
     const int slot = (int)((d->ncalls - 1 - (uint64_t)calls_back) % ldpc_bp_decoder::kRing);
     if (!d->timed[slot]) return LDPC_OK;
     HIP_TRY(hipSetDevice(d->device));
-    HIP_TRY(hipEventSynchronize(d->ev[slot][3]));
+    const int e0 = d->two_events[slot] ? 1 : 0, e3 = d->two_events[slot] ? 2 : 3;
+    HIP_TRY(hipEventSynchronize(d->ev[slot][e3]));
     float a = 0.f, b = 0.f;
     HIP_TRY(hipEventElapsedTime(&a, d->ev[slot][1], d->ev[slot][2]));
-    HIP_TRY(hipEventElapsedTime(&b, d->ev[slot][0], d->ev[slot][3]));
+    HIP_TRY(hipEventElapsedTime(&b, d->ev[slot][e0], d->ev[slot][e3]));
     if (sweep_ms) *sweep_ms = a;
     if (total_ms) *total_ms = b;
     if (sum_iters) {
@@ -1128,12 +1151,12 @@ ldpc_status ldpc_bp_call_phase_ticks(ldpc_bp_decoder *d, int32_t calls_back, uin
 {
     if (!d || !ticks) return fail(LDPC_ERR_INVALID_ARGUMENT, "NULL argument");
     ticks[0] = ticks[1] = ticks[2] = 0;
-    if (calls_back < 0 || calls_back >= ldpc_bp_decoder::kRing || (uint64_t)calls_back >= d->ncalls)
+    if (calls_back < 0 || calls_back >= ldpc_bp_decoder::kHistory || (uint64_t)calls_back >= d->ncalls)
         return fail(LDPC_ERR_INVALID_ARGUMENT, "calls_back outside the timing ring");
     const int slot = (int)((d->ncalls - 1 - (uint64_t)calls_back) % ldpc_bp_decoder::kRing);
     if (!d->timed[slot]) return LDPC_OK;
     HIP_TRY(hipSetDevice(d->device));
-    HIP_TRY(hipEventSynchronize(d->ev[slot][3]));
+    HIP_TRY(hipEventSynchronize(d->ev[slot][d->two_events[slot] ? 2 : 3]));
     HIP_TRY(hipMemcpy(ticks, (char *)d->ctrl.p + 64 * slot + 16, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return LDPC_OK;
 }

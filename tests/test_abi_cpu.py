@@ -103,3 +103,36 @@ def test_c_host_decodes_on_the_gpu(tmp_path, gpu):
     exe = _build_driver(tmp_path)
     out = subprocess.run([exe, "gpu"], capture_output=True, text=True)
     assert out.returncode == 0 and "gpu ok" in out.stdout, (out.returncode, out.stdout, out.stderr)
+
+
+def test_hot_kernels_keep_their_register_budget(tmp_path):
+    """Three workgroups of 8 waves per CU need <= 80 VGPRs (512 / 6 waves per SIMD) and no scratch: the
+    tile kernel's C3 instantiation and the LDS kernel's C2 instantiation sit right at that edge, and an
+    innocent edit has cost a workgroup per CU (-20 % throughput) more than once.  Read from the code
+    object's metadata in the built library."""
+    import shutil
+    import subprocess
+
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (shutil.which("objcopy") and os.path.exists(f"{llvm}/clang-offload-bundler") and os.path.exists(f"{llvm}/llvm-readelf")):
+        pytest.skip("no code-object tools")
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
+    subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", ldpc._capi.LIB_PATH, fat])
+    subprocess.check_call([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o",
+                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}"])
+    notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
+    info, name = {}, None
+    for line in notes.splitlines():
+        m = re.match(r"\s*\.(name|vgpr_count|private_segment_fixed_size):\s+(\S+)", line)
+        if not m:
+            continue
+        if m.group(1) == "name":
+            name = m.group(2)
+            info[name] = {}
+        elif name:
+            info[name][m.group(1)] = int(m.group(2))
+    hot = [k for k in info if k.startswith("_ZN4ldpc14bp_tile_kernelILi8ELi4ELb0ELi512ELb0EEE")
+           or k.startswith("_ZN4ldpc13bp_lds_kernelILi8ELi4ELb0ELi512EEE")]
+    assert len(hot) == 2, sorted(info)[:5]
+    for k in hot:
+        assert info[k]["vgpr_count"] <= 80 and info[k]["private_segment_fixed_size"] == 0, (k, info[k])
