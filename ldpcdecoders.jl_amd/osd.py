@@ -110,6 +110,25 @@ class BeliefPropagationOSDDecoder(AbstractDecoder):
         dev = syn.device
         err = torch.empty((B, bp.n), dtype=torch.uint8, device=dev)
         conv = torch.empty(B, dtype=torch.uint8, device=dev)
+        if self.osd_order == 0 and getattr(self, "_osd_frac", 0.0) <= 0.2:
+            # Two passes: BP without LLRs for everybody (no 8n-byte LLR row per syndrome: 1.9 instead of
+            # 2.4 ms per 2^20 BB-72 syndromes), then the few unconverged ones once more WITH LLRs -- the
+            # decoder is deterministic per syndrome, so their hard decisions come out the same and the
+            # LLRs are the ones the one-pass run would have written.  If a batch turns out to need OSD for
+            # more than a fifth of its syndromes, later batches go back to one pass.
+            bp.decode_batch_device(syn, err, conv, None, None)
+            idx = torch.nonzero(conv == 0, as_tuple=False).flatten()
+            k = int(idx.numel())
+            self._osd_frac = k / max(B, 1)
+            if k:
+                sub = syn[idx].contiguous()
+                e2 = torch.empty((k, bp.n), dtype=torch.uint8, device=dev)
+                c2 = torch.empty(k, dtype=torch.uint8, device=dev)
+                l2 = torch.empty((k, bp.n), dtype=torch.float64, device=dev)
+                bp.decode_batch_device(sub, e2, c2, l2, None)
+                out = self._osd.postprocess(sub.cpu().numpy(), e2.cpu().numpy(), l2.cpu().numpy(), nthreads=nthreads)
+                err[idx] = torch.from_numpy(out).to(dev)
+            return err, conv, k
         llr = torch.empty((B, bp.n), dtype=torch.float64, device=dev)
         bp.decode_batch_device(syn, err, conv, llr, None)
         if self.osd_order == 0:
@@ -117,6 +136,7 @@ class BeliefPropagationOSDDecoder(AbstractDecoder):
         else:
             idx = torch.arange(B, device=dev)
         k = int(idx.numel())
+        self._osd_frac = k / max(B, 1) if self.osd_order == 0 else 1.0
         if k:
             out = self._osd.postprocess(syn[idx].cpu().numpy(), err[idx].cpu().numpy(), llr[idx].cpu().numpy(),
                                         nthreads=nthreads)
