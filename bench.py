@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="syndromes per GPU (default: the workload's)")
     ap.add_argument("--waves-per-tile", type=int, default=0)
     ap.add_argument("--resident-tiles", type=int, default=0)
-    ap.add_argument("--kernel-variant", type=int, default=0, help="0 auto, 1 HBM-streaming, 2 LDS-resident, 3 node-parallel")
+    ap.add_argument("--kernel-variant", type=int, default=0, help="0 auto, 1 HBM-streaming, 2 LDS-resident, 3 node-parallel, 4 team")
     ap.add_argument("--defer-threshold", type=int, default=0, help="0 auto (16), -1 off (streaming kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     # rehearsal of the N>1 control flow on a box with fewer GPUs than ranks (never used by the driver):
@@ -161,6 +161,7 @@ def main():
     iters = torch.empty(batch, dtype=torch.int32, device=device)
 
     osd_sent = [0]
+    device_calls = [0]   # library calls made by the timed steps (1 per step unless noted)
     if args.workload == "c5_bb72_bposd":
         bposd = ldpc.BeliefPropagationOSDDecoder(H, per, max_iters, osd_order=0, device=local_rank,
                                                  waves_per_tile=args.waves_per_tile, kernel_variant=args.kernel_variant)
@@ -171,6 +172,7 @@ def main():
             err.copy_(e)
             conv.copy_(c)
             osd_sent[0] = k
+            device_calls[0] += 2 if k else 1   # BP for all, then the unconverged ones once more with LLRs
     else:
         def step():
             dec.decode_batch_device(syn, err, conv, None, iters)
@@ -184,6 +186,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    device_calls[0] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -191,11 +194,12 @@ def main():
     elapsed = time.perf_counter() - t0
     # HIP-event times of the sweep kernel of the timed steps (the library keeps the events of
     # its last 16 calls, recorded on the launch stream), read after the timed region
-    k = min(args.steps, 16)
-    per_call = [dec.last_timing(i) for i in range(k)]
+    cps = max(1, device_calls[0] // max(args.steps, 1)) if device_calls[0] else 1   # calls per step
+    k = max(1, min(args.steps, 16 // cps))
+    per_call = [dec.last_timing(i) for i in range(k * cps)]
     sweep_ms = sum(t[0] for t in per_call) / k
     total_ms = sum(t[1] for t in per_call) / k
-    sum_iters = per_call[0][2]
+    sum_iters = sum(t[2] for t in per_call[:cps])
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -67,7 +67,10 @@ typedef struct ldpc_bp_options {
     int32_t kernel_variant;   /* 0 = auto (LDS-resident kernel when the edge messages fit the LDS; else the
                                  node-parallel kernel -- one workgroup per syndrome -- for batches too small to
                                  give every CU a 64-syndrome tile, and the HBM-streaming tile kernel above that);
-                                 1 = force streaming; 2 = force LDS-resident; 3 = force node-parallel */
+                                 in between -- up to one tile per CU -- the team kernel, several workgroups per tile);
+                                 1 = force streaming (one workgroup per tile); 2 = force LDS-resident;
+                                 3 = force node-parallel; 4 = team kernel wherever the batch has at most one tile per CU,
+                                 streaming otherwise (never LDS-resident / node-parallel) */
     int32_t defer_threshold;  /* HBM-streaming kernel: a 64-syndrome tile hands its unconverged syndromes to a
                                  densely packed second pass once at most this many are left (same results,
                                  fewer nearly-empty sweeps).  0 = auto (16), -1 = off, else 1..48 */

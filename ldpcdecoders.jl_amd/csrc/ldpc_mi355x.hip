@@ -13,6 +13,7 @@
 #include "bp_kernels.hpp"
 #include "bp_lds_kernels.hpp"
 #include "bp_node_kernels.hpp"
+#include "bp_team_kernels.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -142,6 +143,26 @@ lds_kernel_t pick_lds_kernel(int dc, int dv, bool llr, int threads)
     return llr ? lds_pick_dc<true>(dc, dv, threads) : lds_pick_dc<false>(dc, dv, threads);
 }
 
+typedef void (*team_kernel_t)(BPParams, TeamParams, const int *, const int *, const int *, const int *, const u64 *,
+                              const u64 *);
+template <int DC, bool LLR>
+team_kernel_t team_pick_dv(int dv)
+{
+    if (dv <= 4) return bp_team_kernel<DC, 4, LLR, 512>;
+    return bp_team_kernel<DC, 16, LLR, 512>;
+}
+template <bool LLR>
+team_kernel_t team_pick_dc(int dc, int dv)
+{
+    if (dc <= 8) return team_pick_dv<8, LLR>(dv);
+    if (dc <= 16) return team_pick_dv<16, LLR>(dv);
+    return team_pick_dv<32, LLR>(dv);
+}
+team_kernel_t pick_team_kernel(int dc, int dv, bool llr)
+{
+    return llr ? team_pick_dc<true>(dc, dv) : team_pick_dc<false>(dc, dv);
+}
+
 typedef void (*node_kernel_t)(NodeParams, const int *, const int *, const int *, const int *);
 
 template <int DC, int DV, bool LLR>
@@ -201,8 +222,13 @@ struct ldpc_bp_decoder {
     int blocks_cache[2][17];  // [want_llr][waves per tile] -> resident workgroups per CU, -1 = not queried yet
     int variant = 0;          // 0 auto, 1 HBM-streaming tile kernel, 2 LDS-resident kernel, 3 node-parallel kernel
     bool node_ok = false;     // syndrome + decision bytes of one syndrome fit the LDS (bp_node_kernels.hpp)
-    int64_t node_max_batch = 0;   // auto: largest batch the node-parallel kernel takes from the tile kernel
+    int64_t node_max_batch = 0;   // auto: largest batch the node-parallel kernel takes where the team kernel does not apply
+    int64_t node_take_max = 0;    // most stragglers the node-parallel kernel takes as the second pass of the hand-off
     DevBuf node_msg;          // [workgroups][nnz] double, the node-parallel kernel's message slots
+    // team kernel (bp_team_kernels.hpp): arrival counters + mismatch words, and the host-mapped fault word
+    DevBuf team_ws;
+    unsigned int *team_fault = nullptr, *team_fault_dev = nullptr;
+    int team_max = 32;        // workgroups per tile at most (LDPC_TEAM_MAX; 1 = team kernel off)
     // latency mode of the host-pointer entry (tiny batches, a plain decode!): the kernel reads and writes a
     // host-mapped staging image and raises a flag in it; no copies, no events, no stream synchronisation
     DevBuf done_ctr;          // one device word, zero between launches
@@ -251,11 +277,12 @@ struct ldpc_bp_decoder {
     ~ldpc_bp_decoder()
     {
         DevBuf *all[] = {&row_ptr, &edge_bit, &col_ptr, &csc2csr, &msg, &ctrl, &synmask, &nevermask,
-                         &errmask, &llr_t, &st_all, &node_msg, &done_ctr,
+                         &errmask, &llr_t, &st_all, &node_msg, &done_ctr, &team_ws,
                          &defer_list, &synmask2, &nevermask2, &errmask2, &llr_t2};
         for (DevBuf *b : all) b->release();
         if (pin) (void)hipHostFree(pin);
         if (lat_pin) (void)hipHostFree(lat_pin);
+        if (team_fault) (void)hipHostFree(team_fault);
         for (void *&q : pipe_pin)
             if (q) (void)hipHostFree(q);
         for (DevBuf &b : pipe_dev) b.release();
@@ -533,7 +560,21 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     for (auto &row : d->blocks_cache)
         for (int &v : row) v = -1;
     d->variant = options ? options->kernel_variant : 0;
-    if (d->variant < 0 || d->variant > 3) { delete d; return fail(LDPC_ERR_INVALID_ARGUMENT, "kernel_variant must be 0, 1, 2 or 3"); }
+    if (d->variant < 0 || d->variant > 4) { delete d; return fail(LDPC_ERR_INVALID_ARGUMENT, "kernel_variant must be 0 ... 4"); }
+    if (const char *e = std::getenv("LDPC_TEAM_MAX")) d->team_max = std::max(1, std::min(64, std::atoi(e)));
+    {
+        void *fp = nullptr, *fd = nullptr;
+        if (hipHostMalloc(&fp, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipHostGetDevicePointer(&fd, fp, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (fp) (void)hipHostFree(fp);
+            delete d;
+            return fail(LDPC_ERR_OUT_OF_MEMORY, "hipHostMalloc of the fault word failed");
+        }
+        std::memset(fp, 0, 64);
+        d->team_fault = (unsigned int *)fp;
+        d->team_fault_dev = (unsigned int *)fd;
+    }
     d->lds_logS[0] = lds_logS(s, n, nnz, false);
     d->lds_logS[1] = lds_logS(s, n, nnz, true);
     if (const char *e = std::getenv("LDPC_LDS_LOGS")) {   // tuning experiments only
@@ -556,6 +597,8 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     // (measured crossovers in DESIGN.md); LDPC_NODE_MAX_BATCH overrides for experiments.
     d->node_max_batch = (int64_t)d->num_cus * 8;
     if (const char *e = std::getenv("LDPC_NODE_MAX_BATCH")) d->node_max_batch = std::atoll(e);
+    d->node_take_max = (int64_t)d->num_cus * 8;
+    if (const char *e = std::getenv("LDPC_NODE_TAKE_MAX")) d->node_take_max = std::atoll(e);
     // keep the workspace inside a sane share of HBM (slots are nnz*512 B each)
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -618,11 +661,46 @@ struct LatencyCtl {
 // Which kernel a batch goes to (shared by the device entry and the host entry's latency path).
 static bool takes_lds_kernel(const ldpc_bp_decoder *d, bool want_llr)
 {
-    return d->variant != 1 && d->variant != 3 && d->lds_logS[want_llr ? 1 : 0] >= 0;
+    return d->variant != 1 && d->variant != 3 && d->variant != 4 && d->lds_logS[want_llr ? 1 : 0] >= 0;
 }
+// Workgroups per tile the team kernel (bp_team_kernels.hpp) would use for this batch; 1 = it does not apply.
+// Teams are formed inside one XCD (1/8 of the CUs), two workgroups per CU so that every member is
+// resident with room to spare (the register budget admits three), and a member should have >= 2048
+// message rows per sweep to pay for the three team barriers of an iteration.
+static int team_size(const ldpc_bp_decoder *d, int64_t batch)
+{
+    if (!(d->variant == 0 || d->variant == 4) || d->team_max < 2 || d->wpt_fixed || d->resident_fixed || d->nnz <= 0) return 1;
+    const int64_t ntiles = (batch + kTile - 1) / kTile;
+    if (ntiles < 1 || ntiles > d->num_cus) return 1;
+    static const int per_cu = [] { const char *e = std::getenv("LDPC_TEAM_PER_CU"); return e ? std::max(1, std::min(3, std::atoi(e))) : 2; }();
+    const int64_t teams_per_xcd = (ntiles + 7) / 8;
+    int64_t team = std::min<int64_t>(d->team_max, (int64_t)per_cu * (d->num_cus / 8) / teams_per_xcd);
+    team = std::min<int64_t>(team, std::max<int64_t>(1, d->nnz / 2048));
+    if ((size_t)ntiles * ((size_t)d->max_iters + 32) * sizeof(u64) > ((size_t)16 << 20)) team = 1;
+    return team < 3 ? 1 : (int)team;   // two workgroups per tile measured no better than the tile kernel's one of 16 waves
+}
+
+// Small batches on graphs beyond the LDS: one workgroup per syndrome (bp_node_kernels.hpp) or teams of
+// workgroups per 64-syndrome tile?  Estimated time of one iteration, from the measurements in DESIGN.md:
+//   node kernel: 1.9 ns per edge and syndrome on its CU (the CU's address path), one syndrome per CU at a
+//                time, three times that once the message slots in flight outgrow the L2s (32 MiB);
+//   team kernel: 41 ns per edge for a tile at one CU's pace, divided among the G members, + ~45 us for the
+//                three team barriers.
+// Where the team kernel does not apply, the node kernel keeps the batches up to node_max_batch.
 static bool takes_node_kernel(const ldpc_bp_decoder *d, int64_t batch, bool want_llr)
 {
-    return !takes_lds_kernel(d, want_llr) && d->node_ok && (d->variant == 3 || (d->variant == 0 && batch <= d->node_max_batch));
+    if (takes_lds_kernel(d, want_llr) || !d->node_ok) return false;
+    if (d->variant == 3) return true;
+    if (d->variant != 0) return false;
+    if (batch < kTile) return true;
+    const int G = team_size(d, batch);
+    if (G < 2) return batch <= d->node_max_batch;
+    const double edges = (double)d->nnz;
+    const double rounds = (double)((batch + d->num_cus - 1) / d->num_cus);
+    const double in_flight = (double)std::min<int64_t>(batch, 2 * (int64_t)d->num_cus) * edges * 8.0;
+    const double est_node = rounds * edges * 1.9e-3 * (in_flight > 32.0 * 1048576.0 ? 3.0 : 1.0);
+    const double est_team = edges * 41e-3 / (double)G + 45.0;
+    return est_node < est_team;
 }
 
 static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const uint8_t *d_syn,
@@ -647,6 +725,10 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         return fail(LDPC_ERR_INVALID_ARGUMENT, "syndromes/errors/converged pointer is NULL");
     HIP_TRY(hipSetDevice(d->device));
     const int64_t s = d->s, n = d->n;
+    if (d->team_fault && __atomic_load_n(d->team_fault, __ATOMIC_ACQUIRE) != 0u) {
+        __atomic_store_n(d->team_fault, 0u, __ATOMIC_RELEASE);
+        return fail(LDPC_ERR_HIP, "an earlier call on this decoder lost a workgroup of a team (team barrier timed out); its results are invalid");
+    }
 
     if (d->max_iters == 0) {
         // the loop at belief_propagation.jl:134 never runs: err = 0, log_probabs = 0, converged = false
@@ -798,8 +880,14 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         threads = wpt * 64;
         grid = std::min(slots, ntiles);
     }
+    // Medium batches: fewer tiles than CUs -- G workgroups share a tile (bp_team_kernels.hpp, team_size()).
+    const int team = team_size(d, batch);
+    // (kernel_variant 4 skips the LDS and node kernels; batches the team kernel cannot take -- more tiles than CUs,
+    // an empty graph -- go to the tile kernel)
+    if (team > 1) { threads = 512; grid = ntiles; }
     d->last_threads = threads;
-    d->last_grid = grid;
+    const int team_grid = team > 1 ? 8 * team * ((ntiles + 7) / 8) : 0;
+    d->last_grid = team > 1 ? team_grid : grid;
     const size_t slot_stride_bytes = std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double) + slot_pad_bytes();
     if ((st = ensure_workspace(d, (size_t)grid * slot_stride_bytes, grid, slot_stride_bytes, stream)) != LDPC_OK)
         return st;
@@ -825,8 +913,8 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     // syndrome straight from / into the caller's arrays, instead of a handful of tiles that each sweep
     // the whole graph with one or two lanes alive.  Decided on the device: the launches of the path not
     // taken find *defer_count on the wrong side of node_take and return at once.
-    const unsigned node_take = (thresh && d->node_ok && d->variant == 0 && d->node_max_batch > 0)
-                                   ? (unsigned)std::min<int64_t>(d->node_max_batch, (int64_t)ntiles * thresh) : 0u;
+    const unsigned node_take = (thresh && d->node_ok && d->variant == 0 && d->node_take_max > 0)
+                                   ? (unsigned)std::min<int64_t>(d->node_take_max, (int64_t)ntiles * thresh) : 0u;
 
     HIP_TRY(hipMemsetAsync(ctrl, 0, 64, stream));
     d->ctrl_clean[slot] = false;
@@ -860,11 +948,46 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     p.count_dev = nullptr;
     p.count_skip = 0;
     bp_kernel_t kfn = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, threads);
-    HIP_TRY(hipEventRecord(ev[1], stream));
-    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3((unsigned)threads), 0, stream, p,
-                       (const int *)d->row_ptr.p, (const int *)d->edge_bit.p, (const int *)d->col_ptr.p,
-                       (const int *)d->csc2csr.p, (const u64 *)d->synmask.p, (const u64 *)d->nevermask.p);
-    HIP_TRY(hipGetLastError());
+    if (team > 1) {
+        const size_t ctl_bytes = (size_t)ntiles * kTeamCtlWords * sizeof(unsigned int);
+        const size_t mism_stride = ((size_t)d->max_iters + 31) & ~(size_t)31;
+        const size_t ws_bytes = ctl_bytes + (size_t)ntiles * mism_stride * sizeof(u64);
+        if ((st = d->team_ws.ensure(ws_bytes)) != LDPC_OK) return st;
+        HIP_TRY(hipMemsetAsync(d->team_ws.p, 0, ws_bytes, stream));
+        TeamParams tp;
+        tp.G = team;
+        tp.ctl = (unsigned int *)d->team_ws.p;
+        tp.mism = (u64 *)((char *)d->team_ws.p + ctl_bytes);
+        tp.mism_stride = (int)mism_stride;
+        tp.fault = d->team_fault_dev;
+        static const int always_release = std::getenv("LDPC_TEAM_ALWAYS_RELEASE") ? 1 : 0;
+        tp.always_release = always_release;
+        team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr);
+        HIP_TRY(hipEventRecord(ev[1], stream));
+        // Cooperative launch: the runtime checks the grid against the kernel's residency and does not run
+        // two cooperative grids at once, so two decoders on two streams cannot starve each other's teams.
+        const int *a_row = (const int *)d->row_ptr.p, *a_eb = (const int *)d->edge_bit.p, *a_col = (const int *)d->col_ptr.p,
+                  *a_c2r = (const int *)d->csc2csr.p;
+        const u64 *a_syn = (const u64 *)d->synmask.p, *a_nev = (const u64 *)d->nevermask.p;
+        void *args[] = {&p, &tp, &a_row, &a_eb, &a_col, &a_c2r, &a_syn, &a_nev};
+        HIP_TRY(hipLaunchCooperativeKernel((const void *)tk, dim3((unsigned)team_grid), dim3(512), args, 0, stream));
+        if (std::getenv("LDPC_TEAM_DEBUG")) {   // diagnostics: which XCDs did the teams land on?
+            std::vector<unsigned> xm((size_t)ntiles);
+            (void)hipStreamSynchronize(stream);
+            for (int t = 0; t < ntiles; ++t)
+                (void)hipMemcpy(&xm[(size_t)t], tp.ctl + (size_t)t * kTeamCtlWords + 32, sizeof(unsigned), hipMemcpyDeviceToHost);
+            int single = 0;
+            for (unsigned v : xm) single += __builtin_popcount(v) == 1;
+            std::fprintf(stderr, "[ldpc] team kernel: %d tiles x %d workgroups, grid %d; %d teams on one XCD (first masks %x %x %x)\n",
+                         ntiles, team, team_grid, single, xm[0], ntiles > 1 ? xm[1] : 0u, ntiles > 2 ? xm[2] : 0u);
+        }
+    } else {
+        HIP_TRY(hipEventRecord(ev[1], stream));
+        hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3((unsigned)threads), 0, stream, p,
+                           (const int *)d->row_ptr.p, (const int *)d->edge_bit.p, (const int *)d->col_ptr.p,
+                           (const int *)d->csc2csr.p, (const u64 *)d->synmask.p, (const u64 *)d->nevermask.p);
+        HIP_TRY(hipGetLastError());
+    }
     if (thresh) {
         // second pass over the handed-off syndromes (grids sized for the worst case, blocks past the
         // device-side count return at once)

@@ -115,7 +115,7 @@ class BeliefPropagationDecoder(AbstractDecoder):
         opts.device = -1 if device is None else int(device)
         opts.waves_per_tile = int(waves_per_tile)
         opts.resident_tiles = int(resident_tiles)
-        opts.kernel_variant = int(kernel_variant)   # 0 auto, 1 HBM-streaming, 2 LDS-resident, 3 node-parallel
+        opts.kernel_variant = int(kernel_variant)   # 0 auto, 1 HBM-streaming, 2 LDS-resident, 3 node-parallel, 4 team
         opts.defer_threshold = int(defer_threshold)  # 0 auto (16), -1 off: straggler hand-off of the streaming kernel
         self._h = ctypes.c_void_p()
         L = _capi.lib()

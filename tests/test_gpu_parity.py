@@ -20,10 +20,12 @@ def assert_parity(ldpc, H, per, max_iters, syn_bs, **kw):
     M.sort_indices()
     oc = BPOracle(csc=(M.indptr, M.indices), shape=M.shape, per=per, max_iters=max_iters)
     oerr, oconv, ollr, oits = oc.batchdecode(syn_bs, want_llr=True)
-    # all three kernels: 1 = HBM-streaming tile kernel, 0 = auto (the LDS-resident kernel whenever the
+    # all four kernels: 1 = HBM-streaming tile kernel, 0 = auto (the LDS-resident kernel whenever the
     # edge messages fit the LDS, which is the case for every small code used here; the node-parallel
-    # kernel for small batches on larger codes), 3 = node-parallel kernel (one workgroup per syndrome)
-    for variant in ([kw.pop("kernel_variant")] if "kernel_variant" in kw else [1, 0, 3]):
+    # kernel for small batches on larger codes, the team kernel for medium ones), 3 = node-parallel
+    # kernel (one workgroup per syndrome), 4 = team kernel (several workgroups per 64-syndrome tile)
+    default = [1, 0, 3] if ("waves_per_tile" in kw or "resident_tiles" in kw) else [1, 0, 3, 4]
+    for variant in ([kw.pop("kernel_variant")] if "kernel_variant" in kw else default):
         dec = ldpc.BeliefPropagationDecoder(H, per, max_iters, kernel_variant=variant, **kw)
         err, conv, llr, its = dec.decode_batch_host(syn_bs, want_llr=True, want_iters=True)
         # a second call without LLRs exercises the other kernel instantiation
@@ -166,6 +168,39 @@ def test_straggler_handoff_second_pass_kinds(ldpc, gpu, node_max, monkeypatch):
     syn = ldpc.codes.syndromes_of(H, e)
     err, conv, its = assert_parity(ldpc, H, 0.065, 40, syn, kernel_variant=0)
     assert 0.2 < conv.mean() and len(np.unique(its)) > 8   # the hand-off has something to do
+
+
+@pytest.mark.parametrize("B,per", [(640, 0.02), (4160, 0.065), (3000, 0.10)])
+def test_team_kernel_is_bit_identical_to_the_tile_kernel(ldpc, gpu, B, per):
+    """Several workgroups per tile (agent-scope release / acquire between the sweeps) against one
+    workgroup per tile: same node updates, so EVERYTHING must come out bit for bit the same, LLRs
+    included -- one stale message row anywhere would show.  n = 4096 beyond the LDS, 10 ... 65 tiles
+    of very different iteration counts (uneven load), teams of 32 down to 7 workgroups."""
+    import torch
+
+    n = 4096
+    H = ldpc.codes.parity_check_csc(n, 8, 4)
+    syn = torch.from_numpy(ldpc.codes.syndromes_of(H, ldpc.codes.random_errors(n, B, per, seed=B))).cuda()
+    res = {}
+    for variant in (1, 4):
+        dec = ldpc.BeliefPropagationDecoder(H, per, 40, kernel_variant=variant)
+        for rep in range(3 if variant == 4 else 1):     # the team kernel thrice: placement and timing vary
+            err = torch.empty((B, n), dtype=torch.uint8, device="cuda")
+            conv = torch.empty(B, dtype=torch.uint8, device="cuda")
+            llr = torch.full((B, n), float("nan"), dtype=torch.float64, device="cuda")
+            its = torch.empty(B, dtype=torch.int32, device="cuda")
+            dec.decode_batch_device(syn, err, conv, llr, its)
+            torch.cuda.synchronize()
+            out = (err, conv, its, llr.view(torch.int64))
+            if variant in res:
+                assert all(torch.equal(a, b) for a, b in zip(out, res[variant])), "team kernel not reproducible"
+            res[variant] = out
+        if variant == 4:
+            assert dec.info().resident_tiles > (B + 63) // 64          # really several workgroups per tile
+        dec.close()
+    names = ("hard decisions", "converged", "iterations", "LLR bits")
+    for a, b, nm in zip(res[1], res[4], names):
+        assert torch.equal(a, b), f"{nm} differ between the tile and the team kernel"
 
 
 def test_device_resident_entry(ldpc, gpu):

@@ -49,10 +49,10 @@ while time.time() - t0 < budget:
         syn[rng.integers(0, B), rng.integers(0, s)] = rng.integers(2, 5)
     oc = BPOracle(csc=(H.indptr, H.indices), shape=H.shape, per=per, max_iters=iters)
     oerr, oconv, ollr, oits = oc.batchdecode(syn)
-    for variant in (0, 1, 3):
-        kw = dict(kernel_variant=variant, waves_per_tile=int(rng.choice([0, 4, 8, 16])),
+    for variant in (0, 1, 3, 4):
+        kw = dict(kernel_variant=variant, waves_per_tile=0 if variant == 4 else int(rng.choice([0, 4, 8, 16])),
                   defer_threshold=int(rng.choice([0, -1, 4, 40])))
-        if rng.random() < 0.3:
+        if variant != 4 and rng.random() < 0.3:
             kw["resident_tiles"] = int(rng.integers(1, 5))
         dec = ldpc.BeliefPropagationDecoder(H, per, iters, **kw)
         want_llr = bool(rng.random() < 0.5)

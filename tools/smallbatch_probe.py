@@ -11,11 +11,14 @@ import ldpcdecoders_jl_amd as ldpc
 from oracle import BPOracle
 
 cases = [(4096, 0.02), (16384, 0.02), (16384, 0.10), (65536, 0.02)]
+if os.environ.get("CASES"):
+    cases = [(int(c.split(":")[0]), float(c.split(":")[1])) for c in os.environ["CASES"].split(",")]
+AUTO = os.environ.get("AUTO") == "1"   # AUTO=1: time kernel_variant 0 (what a caller gets) instead of the forced node kernel
 batches = [int(x) for x in os.environ.get("BATCHES", "1,64,256,512,1024,2048,4096").split(",")]
 for n, per in cases:
     H = ldpc.codes.parity_check_csc(n, 8, 4)
     oc = BPOracle(csc=(H.indptr, H.indices), shape=H.shape, per=per, max_iters=50, dense=False)
-    decs = {v: ldpc.BeliefPropagationDecoder(H, per, 50, kernel_variant=v) for v in (1, 3)}
+    decs = {v: ldpc.BeliefPropagationDecoder(H, per, 50, kernel_variant=v) for v in (1, (0 if AUTO else 3), 4)}
     for batch in batches:
         E = ldpc.codes.random_errors(n, batch, per, seed=3)
         S = ldpc.codes.syndromes_of(H, E)
@@ -33,12 +36,12 @@ for n, per in cases:
                 t0 = time.perf_counter(); dec.decode_batch_device(Sd, err, conv); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
             res[v] = np.median(ts) * 1e3
             outs[v] = (err.cpu().numpy(), conv.cpu().numpy())
-        same = np.array_equal(outs[1][0], outs[3][0]) and np.array_equal(outs[1][1], outs[3][1])
+        same = all(np.array_equal(outs[1][0], outs[v][0]) and np.array_equal(outs[1][1], outs[v][1]) for v in list(decs)[1:])
         t0 = time.perf_counter()
         for b in range(min(batch, 4)):
             oc.decode(S[b])
         cpu = (time.perf_counter() - t0) / min(batch, 4)
-        print(f"n {n:6d} per {per:.2f} batch {batch:5d}: tile {res[1]:9.3f} ms  node {res[3]:9.3f} ms  identical {same}  "
+        print(f"n {n:6d} per {per:.2f} batch {batch:5d}: tile {res[1]:9.3f} ms  {'auto' if AUTO else 'node'} {res[list(decs)[1]]:9.3f} ms  team {res[4]:9.3f} ms  identical {same}  "
               f"CPU oracle {cpu*1e3:7.3f} ms/syndrome", flush=True)
     for d in decs.values():
         d.close()
