@@ -667,15 +667,22 @@ static bool takes_lds_kernel(const ldpc_bp_decoder *d, bool want_llr)
 // Teams are formed inside one XCD (1/8 of the CUs), two workgroups per CU so that every member is
 // resident with room to spare (the register budget admits three), and a member should have >= 2048
 // message rows per sweep to pay for the three team barriers of an iteration.
-static int team_size(const ldpc_bp_decoder *d, int64_t batch)
+static int team_size(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
 {
     if (!(d->variant == 0 || d->variant == 4) || d->team_max < 2 || d->wpt_fixed || d->resident_fixed || d->nnz <= 0) return 1;
     const int64_t ntiles = (batch + kTile - 1) / kTile;
     if (ntiles < 1 || ntiles > d->num_cus) return 1;
-    static const int per_cu = [] { const char *e = std::getenv("LDPC_TEAM_PER_CU"); return e ? std::max(1, std::min(3, std::atoi(e))) : 2; }();
+    static const int per_cu_want = [] { const char *e = std::getenv("LDPC_TEAM_PER_CU"); return e ? std::max(1, std::min(3, std::atoi(e))) : 2; }();
+    // what this instantiation's registers admit (the wide-degree buckets: one 8-wave workgroup per CU), less one
+    // as the margin where that leaves at least one
+    int occ = 0;
+    if (d->prepare_kernel((const void *)pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr), 512, 0, &occ) != LDPC_OK) return 1;
+    const int per_cu = std::min(per_cu_want, occ >= 2 ? occ - (occ > per_cu_want ? 0 : 1) : occ);
+    if (per_cu < 1) return 1;
     const int64_t teams_per_xcd = (ntiles + 7) / 8;
     int64_t team = std::min<int64_t>(d->team_max, (int64_t)per_cu * (d->num_cus / 8) / teams_per_xcd);
-    team = std::min<int64_t>(team, std::max<int64_t>(1, d->nnz / 2048));
+    static const int64_t min_rows = [] { const char *e = std::getenv("LDPC_TEAM_MIN_ROWS"); return e ? std::max<int64_t>(1, std::atoll(e)) : (int64_t)2048; }();
+    team = std::min<int64_t>(team, std::max<int64_t>(1, d->nnz / min_rows));   // (LDPC_TEAM_MIN_ROWS=1: tests put teams on tiny graphs)
     if ((size_t)ntiles * ((size_t)d->max_iters + 32) * sizeof(u64) > ((size_t)16 << 20)) team = 1;
     return team < 3 ? 1 : (int)team;   // two workgroups per tile measured no better than the tile kernel's one of 16 waves
 }
@@ -687,13 +694,13 @@ static int team_size(const ldpc_bp_decoder *d, int64_t batch)
 //   team kernel: 41 ns per edge for a tile at one CU's pace, divided among the G members, + ~45 us for the
 //                three team barriers.
 // Where the team kernel does not apply, the node kernel keeps the batches up to node_max_batch.
-static bool takes_node_kernel(const ldpc_bp_decoder *d, int64_t batch, bool want_llr)
+static bool takes_node_kernel(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
 {
     if (takes_lds_kernel(d, want_llr) || !d->node_ok) return false;
     if (d->variant == 3) return true;
     if (d->variant != 0) return false;
     if (batch < kTile) return true;
-    const int G = team_size(d, batch);
+    const int G = team_size(d, batch, want_llr);
     if (G < 2) return batch <= d->node_max_batch;
     const double edges = (double)d->nnz;
     const double rounds = (double)((batch + d->num_cus - 1) / d->num_cus);
@@ -881,7 +888,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         grid = std::min(slots, ntiles);
     }
     // Medium batches: fewer tiles than CUs -- G workgroups share a tile (bp_team_kernels.hpp, team_size()).
-    const int team = team_size(d, batch);
+    const int team = team_size(d, batch, want_llr);
     // (kernel_variant 4 skips the LDS and node kernels; batches the team kernel cannot take -- more tiles than CUs,
     // an empty graph -- go to the tile kernel)
     if (team > 1) { threads = 512; grid = ntiles; }

@@ -10,6 +10,7 @@ import numpy as np
 import scipy.sparse as sp
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("LDPC_TEAM_MIN_ROWS", "1")   # kernel_variant 4: teams of workgroups also on these tiny graphs
 import ldpcdecoders_jl_amd as ldpc  # noqa: E402
 from oracle import BPOracle, BPOTSOracle  # noqa: E402
 
