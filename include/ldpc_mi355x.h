@@ -57,6 +57,9 @@ typedef struct ldpc_bp_info {
     int32_t waves_per_tile;   /* wavefronts cooperating on one tile */
     int32_t resident_tiles;   /* workspace slots = workgroups in the persistent grid */
     int64_t workspace_bytes;  /* device bytes held by the handle */
+    int32_t last_kernel;      /* kernel the most recent batch call ran: 0 none yet, 1 HBM-streaming tile kernel,
+                                 2 LDS-resident, 3 node-parallel, 4 team (numbered like kernel_variant) */
+    int32_t last_team_size;   /* workgroups per tile of that call (1 unless last_kernel == 4) */
 } ldpc_bp_info;
 
 /* Optional knobs; pass NULL to ldpc_bp_create for defaults.  Zero = default. */

@@ -63,6 +63,7 @@ class BPInfo(ctypes.Structure):
         ("device", ctypes.c_int32), ("tile_syndromes", ctypes.c_int32),
         ("waves_per_tile", ctypes.c_int32), ("resident_tiles", ctypes.c_int32),
         ("workspace_bytes", ctypes.c_int64),
+        ("last_kernel", ctypes.c_int32), ("last_team_size", ctypes.c_int32),
     ]
 
 

@@ -218,6 +218,7 @@ struct ldpc_bp_decoder {
     int wpt_fixed = 0;        // waves per tile requested by the caller, 0 = chosen per batch
     int resident_fixed = 0;   // workspace slots requested by the caller, 0 = fill the chip
     int last_threads = 512, last_grid = 0;   // geometry of the most recent streaming launch (info)
+    int last_kernel = 0, last_team = 1;      // which kernel the most recent call ran (info)
     size_t ws_budget = 0;     // bytes the message workspace may take
     int blocks_cache[2][17];  // [want_llr][waves per tile] -> resident workgroups per CU, -1 = not queried yet
     int variant = 0;          // 0 auto, 1 HBM-streaming tile kernel, 2 LDS-resident kernel, 3 node-parallel kernel
@@ -647,6 +648,8 @@ ldpc_status ldpc_bp_get_info(const ldpc_bp_decoder *d, ldpc_bp_info *info)
                            &d->nevermask, &d->errmask, &d->llr_t, &d->st_all, &d->defer_list, &d->synmask2,
                            &d->nevermask2, &d->errmask2, &d->llr_t2, &d->node_msg, &d->pipe_dev[0], &d->pipe_dev[1], &d->pipe_dev[2]};
     for (const DevBuf *b : all) info->workspace_bytes += (int64_t)b->cap;
+    info->last_kernel = d->last_kernel;
+    info->last_team_size = d->last_team;
     return LDPC_OK;
 }
 
@@ -752,6 +755,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         const int logS = d->lds_logS[want_llr_early ? 1 : 0];
         const int64_t ngroups64 = (batch + (1ll << logS) - 1) >> logS;
         if (ngroups64 > (1ll << 30)) return fail(LDPC_ERR_UNSUPPORTED, "batch too large for one call");
+        d->last_kernel = 2; d->last_team = 1;
         LdsParams lp;
         lp.s = (int)s; lp.n = (int)n; lp.nnz = (int)d->nnz; lp.max_iters = (int)d->max_iters;
         lp.logS = logS; lp.ngroups = (int)ngroups64; lp.batch = batch;
@@ -815,6 +819,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         const size_t stride = (std::max<size_t>((size_t)d->nnz, 1) + 63) & ~(size_t)63;   // 512-byte aligned slots
         ldpc_status nst = d->node_msg.ensure((size_t)ngrid * stride * sizeof(double));
         if (nst != LDPC_OK) return nst;
+        d->last_kernel = 3; d->last_team = 1;
         NodeParams np;
         np.s = (int)s; np.n = (int)n; np.nnz = (int)d->nnz; np.max_iters = (int)d->max_iters;
         np.batch = batch; np.r = d->per / (1 - d->per);
@@ -895,6 +900,8 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     d->last_threads = threads;
     const int team_grid = team > 1 ? 8 * team * ((ntiles + 7) / 8) : 0;
     d->last_grid = team > 1 ? team_grid : grid;
+    d->last_kernel = team > 1 ? 4 : 1;
+    d->last_team = team;
     const size_t slot_stride_bytes = std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double) + slot_pad_bytes();
     if ((st = ensure_workspace(d, (size_t)grid * slot_stride_bytes, grid, slot_stride_bytes, stream)) != LDPC_OK)
         return st;

@@ -196,11 +196,35 @@ def test_team_kernel_is_bit_identical_to_the_tile_kernel(ldpc, gpu, B, per):
                 assert all(torch.equal(a, b) for a, b in zip(out, res[variant])), "team kernel not reproducible"
             res[variant] = out
         if variant == 4:
-            assert dec.info().resident_tiles > (B + 63) // 64          # really several workgroups per tile
+            info = dec.info()
+            assert info.last_kernel == 4 and info.last_team_size >= 3     # really several workgroups per tile
+            assert info.resident_tiles >= info.last_team_size * ((B + 63) // 64)
+        else:
+            assert dec.info().last_kernel == 1
         dec.close()
     names = ("hard decisions", "converged", "iterations", "LLR bits")
     for a, b, nm in zip(res[1], res[4], names):
         assert torch.equal(a, b), f"{nm} differ between the tile and the team kernel"
+
+
+def test_auto_dispatch_picks_the_kernel_by_code_and_batch(ldpc, gpu):
+    """kernel_variant 0: LDS-resident kernel for a code that fits the LDS; beyond it the node-parallel
+    kernel below one tile, the team kernel for medium batches, the tile kernel once there is a tile per CU
+    (ldpc_bp_info.last_kernel, numbered like kernel_variant).  Results against the oracle on a sample."""
+    small = ldpc.codes.parity_check_csc(1008, 6, 3)
+    big = ldpc.codes.parity_check_csc(4096, 8, 4)
+    d_small = ldpc.BeliefPropagationDecoder(small, 0.01, 50)
+    d_small.decode_batch_host(ldpc.codes.syndromes_of(small, ldpc.codes.random_errors(1008, 3000, 0.01, seed=1)))
+    assert d_small.info().last_kernel == 2
+    d_big = ldpc.BeliefPropagationDecoder(big, 0.03, 30)
+    oc = BPOracle(csc=(big.indptr, big.indices), shape=big.shape, per=0.03, max_iters=30)
+    for B, want in [(1, 3), (40, 3), (2048, 4), (20000, 1)]:
+        syn = ldpc.codes.syndromes_of(big, ldpc.codes.random_errors(4096, B, 0.03, seed=B))
+        err, conv, _, its = d_big.decode_batch_host(syn, want_iters=True)
+        assert d_big.info().last_kernel == want, (B, d_big.info().last_kernel)
+        k = min(B, 200)
+        oerr, oconv, _, oits = oc.batchdecode(syn[:k])
+        assert np.array_equal(err[:k], oerr) and np.array_equal(conv[:k], oconv) and np.array_equal(its[:k], oits)
 
 
 def test_device_resident_entry(ldpc, gpu):
