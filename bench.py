@@ -29,6 +29,9 @@ WORKLOADS = {
     # name: (n, wr, wc, batch per GPU, per, max_iters)
     "c3_full50": (16384, 8, 4, 65536, 0.10, 50),
     "c3_realistic": (16384, 8, 4, 65536, 0.02, 50),
+    # the same code in the waterfall (threshold of the (4,8) ensemble ~0.076): broad iteration distribution,
+    # thousands of stragglers for the hand-off
+    "c3_waterfall": (16384, 8, 4, 65536, 0.06, 50),
     "c2_n1008": (1008, 6, 3, 4096, 0.01, 50),
     # the code of the reference's own tests and benchmark suite (test/test_bp_decoder.jl:7,
     # benchmark/benchmarks.jl:8-11): (9,10)-regular n=1000, per 0.01, 100 iterations

@@ -105,6 +105,8 @@ struct BPParams {
     // from scratch, densely packed, by a second pass (index / count_dev describe that pass).
     int defer_thresh;           // 0 = never give up (second pass, or feature off)
     int defer_min_iter;         // do not give up before this many iterations
+    int defer_max_iter;         // ... nor after this many: the second pass starts from scratch, so handing off a
+                                // syndrome that has already run long doubles its work (waterfall workloads)
     int *defer_list;            // [<= ntiles*defer_thresh] batch positions handed to the second pass
     unsigned int *defer_count;  // number of entries in defer_list
     const int *index;           // second pass: batch position of compact syndrome q (nullptr in the first pass)
@@ -410,7 +412,7 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
             const u64 t3 = wall_clock64();
             tk_check += t1 - t0; tk_var += t2 - t1; tk_conv += t3 - t2;
             // few stragglers left: hand them to the second pass instead of sweeping a nearly empty tile
-            if (p.defer_thresh != 0 && active != 0 && it >= p.defer_min_iter && it < p.max_iters &&
+            if (p.defer_thresh != 0 && active != 0 && it >= p.defer_min_iter && it <= p.defer_max_iter && it < p.max_iters &&
                 __popcll(active) <= p.defer_thresh) {
                 if (w == 0) {
                     unsigned base = 0;

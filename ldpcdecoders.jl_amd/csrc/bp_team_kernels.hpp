@@ -211,7 +211,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
         const u64 t4 = wall_clock64();
         tk_check += t1 - t0; tk_var += t3 - t2; tk_rest += (t2 - t1) + (t4 - t3);   // rest = barriers + test
         // few stragglers left: hand them to the second pass (decided alike by every member; rank 0 files them)
-        if (p.defer_thresh != 0 && active != 0 && it >= p.defer_min_iter && it < p.max_iters &&
+        if (p.defer_thresh != 0 && active != 0 && it >= p.defer_min_iter && it <= p.defer_max_iter && it < p.max_iters &&
             __popcll(active) <= p.defer_thresh) {
             if (rank == 0 && w == 0) {
                 unsigned base = 0;

@@ -956,6 +956,8 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     p.phase_ticks = (u64 *)(ctrl + 16);
     p.defer_thresh = thresh;
     p.defer_min_iter = 2;
+    static const int defer_max_iter = [] { const char *e = std::getenv("LDPC_DEFER_MAX_ITER"); return e ? std::max(2, std::atoi(e)) : 8; }();
+    p.defer_max_iter = defer_max_iter;
     p.defer_list = (int *)d->defer_list.p;
     p.defer_count = defer_count;
     p.index = nullptr;
