@@ -77,7 +77,8 @@ class BPOptions(ctypes.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("ldpc_mi355x.hip", "ldpc_bpots.hip", "osd_host.cpp", "bp_kernels.hpp", "bp_lds_kernels.hpp", "bp_node_kernels.hpp", "bp_team_kernels.hpp", "latency_mode.hpp",
+    srcs = [os.path.join(CSRC, f) for f in ("ldpc_mi355x.hip", "pick_tile.hip", "pick_lds.hip", "pick_node.hip", "pick_team.hip", "pickers.hpp",
+                                             "ldpc_bpots.hip", "osd_host.cpp", "bp_kernels.hpp", "bp_lds_kernels.hpp", "bp_node_kernels.hpp", "bp_team_kernels.hpp", "latency_mode.hpp",
                                              "bpots_kernels.hpp", "portable_math.h", "Makefile")]
     srcs.append(os.path.join(_HERE, "..", "include", "ldpc_mi355x.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(

@@ -449,6 +449,7 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
     }
 }
 
+#ifdef LDPC_AUX_KERNELS   // the small non-template kernels: only the host translation unit (ldpc_mi355x.hip) defines them
 // ---------------------------------------------------------------------------
 // placement probe: the variable sweep's access pattern on a candidate workspace -- every wave of a
 // slot's workgroup gathers 4 pseudo-random rows of the slot and writes them back.  The host times it
@@ -543,5 +544,7 @@ __global__ void __launch_bounds__(256) unpack_llr_kernel(const double *llr_t, lo
             llr[(size_t)b * n + j0 + tx] = t[tx][rr];
         }
 }
+
+#endif  // LDPC_AUX_KERNELS
 
 }  // namespace ldpc

@@ -10,10 +10,12 @@
 // There is deliberately no CPU path in this file: if HIP or the device is not
 // usable every compute entry fails with a status code.
 #include "../../include/ldpc_mi355x.h"
+#define LDPC_AUX_KERNELS 1
 #include "bp_kernels.hpp"
 #include "bp_lds_kernels.hpp"
 #include "bp_node_kernels.hpp"
 #include "bp_team_kernels.hpp"
+#include "pickers.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -79,114 +81,6 @@ struct DevBuf {
         cap = 0;
     }
 };
-
-typedef void (*bp_kernel_t)(BPParams, const int *, const int *, const int *, const int *, const u64 *,
-                            const u64 *);
-
-template <int DC, int DV, bool LLR, bool SECOND>
-bp_kernel_t pick_threads(int threads)
-{
-    switch (threads) {
-    case 256: return bp_tile_kernel<DC, DV, LLR, 256, SECOND>;
-    case 512: return bp_tile_kernel<DC, DV, LLR, 512, SECOND>;
-    default: return bp_tile_kernel<DC, DV, LLR, 1024, SECOND>;
-    }
-}
-
-template <int DC, bool LLR, bool SECOND>
-bp_kernel_t pick_dv(int dv, int threads)
-{
-    if (dv <= 4) return pick_threads<DC, 4, LLR, SECOND>(threads);
-    return pick_threads<DC, 16, LLR, SECOND>(threads);
-}
-
-template <bool LLR, bool SECOND>
-bp_kernel_t pick_dc(int dc, int dv, int threads)
-{
-    if (dc <= 8) return pick_dv<8, LLR, SECOND>(dv, threads);
-    if (dc <= 16) return pick_dv<16, LLR, SECOND>(dv, threads);
-    return pick_dv<32, LLR, SECOND>(dv, threads);
-}
-
-bp_kernel_t pick_kernel(int dc, int dv, bool llr, int threads, bool second = false)
-{
-    if (second) return llr ? pick_dc<true, true>(dc, dv, threads) : pick_dc<false, true>(dc, dv, threads);
-    return llr ? pick_dc<true, false>(dc, dv, threads) : pick_dc<false, false>(dc, dv, threads);
-}
-
-typedef void (*lds_kernel_t)(LdsParams, const int *, const int *, const int *, const int *);
-
-template <int DC, int DV, bool LLR>
-lds_kernel_t lds_pick_threads(int threads)
-{
-    switch (threads) {
-    case 256: return bp_lds_kernel<DC, DV, LLR, 256>;
-    case 512: return bp_lds_kernel<DC, DV, LLR, 512>;
-    default: return bp_lds_kernel<DC, DV, LLR, 1024>;
-    }
-}
-template <int DC, bool LLR>
-lds_kernel_t lds_pick_dv(int dv, int threads)
-{
-    if (dv <= 4) return lds_pick_threads<DC, 4, LLR>(threads);
-    return lds_pick_threads<DC, 16, LLR>(threads);
-}
-template <bool LLR>
-lds_kernel_t lds_pick_dc(int dc, int dv, int threads)
-{
-    if (dc <= 8) return lds_pick_dv<8, LLR>(dv, threads);
-    if (dc <= 16) return lds_pick_dv<16, LLR>(dv, threads);
-    return lds_pick_dv<32, LLR>(dv, threads);
-}
-lds_kernel_t pick_lds_kernel(int dc, int dv, bool llr, int threads)
-{
-    return llr ? lds_pick_dc<true>(dc, dv, threads) : lds_pick_dc<false>(dc, dv, threads);
-}
-
-typedef void (*team_kernel_t)(BPParams, TeamParams, const int *, const int *, const int *, const int *, const u64 *,
-                              const u64 *);
-template <int DC, bool LLR>
-team_kernel_t team_pick_dv(int dv)
-{
-    if (dv <= 4) return bp_team_kernel<DC, 4, LLR, 512>;
-    return bp_team_kernel<DC, 16, LLR, 512>;
-}
-template <bool LLR>
-team_kernel_t team_pick_dc(int dc, int dv)
-{
-    if (dc <= 8) return team_pick_dv<8, LLR>(dv);
-    if (dc <= 16) return team_pick_dv<16, LLR>(dv);
-    return team_pick_dv<32, LLR>(dv);
-}
-team_kernel_t pick_team_kernel(int dc, int dv, bool llr)
-{
-    return llr ? team_pick_dc<true>(dc, dv) : team_pick_dc<false>(dc, dv);
-}
-
-typedef void (*node_kernel_t)(NodeParams, const int *, const int *, const int *, const int *);
-
-template <int DC, int DV, bool LLR>
-node_kernel_t node_pick_threads(int threads)
-{
-    return threads == 512 ? bp_node_kernel<DC, DV, LLR, 512> : bp_node_kernel<DC, DV, LLR, 1024>;
-}
-template <int DC, bool LLR>
-node_kernel_t node_pick_dv(int dv, int threads)
-{
-    if (dv <= 4) return node_pick_threads<DC, 4, LLR>(threads);
-    return node_pick_threads<DC, 16, LLR>(threads);
-}
-template <bool LLR>
-node_kernel_t node_pick_dc(int dc, int dv, int threads)
-{
-    if (dc <= 8) return node_pick_dv<8, LLR>(dv, threads);
-    if (dc <= 16) return node_pick_dv<16, LLR>(dv, threads);
-    return node_pick_dv<32, LLR>(dv, threads);
-}
-node_kernel_t pick_node_kernel(int dc, int dv, bool llr, int threads)
-{
-    return llr ? node_pick_dc<true>(dc, dv, threads) : node_pick_dc<false>(dc, dv, threads);
-}
 
 // How many syndromes per workgroup pass the LDS kernel holds (log2), or -1 if even one
 // syndrome's messages do not fit.  Workgroups per CU come first (the check sweep is VALU-bound, the

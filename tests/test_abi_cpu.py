@@ -116,11 +116,19 @@ def test_hot_kernels_keep_their_register_budget(tmp_path):
     llvm = "/opt/rocm/lib/llvm/bin"
     if not (shutil.which("objcopy") and os.path.exists(f"{llvm}/clang-offload-bundler") and os.path.exists(f"{llvm}/llvm-readelf")):
         pytest.skip("no code-object tools")
-    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
+    fat = str(tmp_path / "fat.bin")
     subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", ldpc._capi.LIB_PATH, fat])
-    subprocess.check_call([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o",
-                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}"])
-    notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
+    blob = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+    assert starts, "no offload bundle in .hip_fatbin"
+    notes = ""
+    for k, a in enumerate(starts):   # one bundle per translation unit (pick_*.hip, ...)
+        part, co = str(tmp_path / f"bundle{k}.bin"), str(tmp_path / f"dev{k}.co")
+        open(part, "wb").write(blob[a:starts[k + 1] if k + 1 < len(starts) else len(blob)])
+        subprocess.check_call([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o",
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={part}", f"--output={co}"])
+        notes += subprocess.run([f"{llvm}/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
     info, name = {}, None
     for line in notes.splitlines():
         m = re.match(r"\s*\.(name|vgpr_count|private_segment_fixed_size):\s+(\S+)", line)
