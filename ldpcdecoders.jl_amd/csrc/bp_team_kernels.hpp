@@ -36,6 +36,8 @@ struct TeamParams {
     int mism_stride;            // >= max_iters, a multiple of 32 words
     unsigned int *fault;        // host-mapped: set when a team barrier timed out
     int always_release;         // experiments: 1 = release at every barrier even when the team shares one XCD
+    int scatter;                // tests: 1 = deal a team's members over ALL XCDs (exercises the release path and
+                                // the XCC check that selects it); gridDim.x == ntiles * G
 };
 
 // Team barrier number k (1, 2, ...).  Control block of a tile: arrival counter at word 0, XCC mask at word
@@ -109,8 +111,8 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     // one.  Teams are formed among the blocks of one residue class, so that normally a team sits on ONE
     // XCD; the members check it (xccs) and fall back to full release / acquire barriers if it is not so.
     const int q = (int)(blockIdx.x >> 3), xslot = (int)(blockIdx.x & 7u);   // gridDim.x == 8 * G * ceil(ntiles / 8)
-    const int tile = (q / G) * 8 + xslot;
-    const int rank = q % G;
+    const int tile = tp.scatter ? (int)(blockIdx.x / (unsigned)G) : (q / G) * 8 + xslot;
+    const int rank = tp.scatter ? (int)(blockIdx.x % (unsigned)G) : q % G;
     if (tile >= p.ntiles) return;                              // whole teams only: nobody waits for these
     const int gw = rank * W + w, GW = G * W;                   // this wave among the team's waves
     double *const Mt = p.msg + (size_t)tile * (size_t)p.slot_stride + lane;

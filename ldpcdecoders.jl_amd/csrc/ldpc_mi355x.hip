@@ -872,6 +872,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         tp.fault = d->team_fault_dev;
         static const int always_release = std::getenv("LDPC_TEAM_ALWAYS_RELEASE") ? 1 : 0;
         tp.always_release = always_release;
+        tp.scatter = std::getenv("LDPC_TEAM_SCATTER") ? 1 : 0;   // (read per call: a test switches it on and off)
         team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr);
         HIP_TRY(hipEventRecord(ev[1], stream));
         // Cooperative launch: the runtime checks the grid against the kernel's residency and does not run

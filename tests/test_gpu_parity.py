@@ -170,14 +170,20 @@ def test_straggler_handoff_second_pass_kinds(ldpc, gpu, node_max, monkeypatch):
     assert 0.2 < conv.mean() and len(np.unique(its)) > 8   # the hand-off has something to do
 
 
-@pytest.mark.parametrize("B,per", [(640, 0.02), (4160, 0.065), (3000, 0.10)])
-def test_team_kernel_is_bit_identical_to_the_tile_kernel(ldpc, gpu, B, per):
+@pytest.mark.parametrize("B,per,scatter", [(640, 0.02, False), (4160, 0.065, False), (3000, 0.10, False),
+                                           (640, 0.10, True), (2900, 0.065, True)])
+def test_team_kernel_is_bit_identical_to_the_tile_kernel(ldpc, gpu, B, per, scatter, monkeypatch):
     """Several workgroups per tile (agent-scope release / acquire between the sweeps) against one
     workgroup per tile: same node updates, so EVERYTHING must come out bit for bit the same, LLRs
     included -- one stale message row anywhere would show.  n = 4096 beyond the LDS, 10 ... 65 tiles
-    of very different iteration counts (uneven load), teams of 32 down to 7 workgroups."""
+    of very different iteration counts (uneven load), teams of 8 or 7 workgroups (n = 16384 teams of 32 run
+    in test_c3_code_n16384_small_batch).  scatter: the members of a team are dealt over ALL XCDs
+    (LDPC_TEAM_SCATTER), so the teams find themselves on several XCDs and every barrier writes the L2
+    back -- the path taken if the round-robin placement of workgroups ever changes."""
     import torch
 
+    if scatter:
+        monkeypatch.setenv("LDPC_TEAM_SCATTER", "1")
     n = 4096
     H = ldpc.codes.parity_check_csc(n, 8, 4)
     syn = torch.from_numpy(ldpc.codes.syndromes_of(H, ldpc.codes.random_errors(n, B, per, seed=B))).cuda()
