@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3_full50", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="syndromes per GPU (default: the workload's)")
+    ap.add_argument("--per", type=float, default=0.0, help="physical error rate (default: the workload's)")
     ap.add_argument("--waves-per-tile", type=int, default=0)
     ap.add_argument("--resident-tiles", type=int, default=0)
     ap.add_argument("--kernel-variant", type=int, default=0, help="0 auto, 1 HBM-streaming, 2 LDS-resident, 3 node-parallel, 4 team")
@@ -147,6 +148,8 @@ def main():
     n, wr, wc, batch, per, max_iters = WORKLOADS[args.workload]
     if args.batch:
         batch = args.batch
+    if args.per > 0:
+        per = args.per
     if args.workload == "c5_bb72_bposd":
         import scipy.sparse as sp
 
@@ -243,7 +246,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(args.workload)[0] if (not args.batch and world == 1) else None,
+                "traffic": pmc_traffic(args.workload)[0] if (not args.batch and not args.per and world == 1) else None,
                 "traffic_source": pmc_traffic(args.workload)[1],
                 "alg_bytes_per_launch": alg_bytes,
                 "kernel_ms": sweep_ms,

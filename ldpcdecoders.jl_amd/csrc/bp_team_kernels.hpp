@@ -38,6 +38,10 @@ struct TeamParams {
     int always_release;         // experiments: 1 = release at every barrier even when the team shares one XCD
     int scatter;                // tests: 1 = deal a team's members over ALL XCDs (exercises the release path and
                                 // the XCC check that selects it); gridDim.x == ntiles * G
+    // As the second pass of the straggler hand-off (p.count_dev != nullptr): the number of syndromes is
+    // only known on the device, so the geometry is worked out here -- G above is then the cap, and the
+    // pass runs only for p.count_skip < *count_dev <= count_max (fewer: node kernel, more: packed tiles).
+    unsigned int count_max;
 };
 
 // Team barrier number k (1, 2, ...).  Control block of a tile: arrival counter at word 0, XCC mask at word
@@ -106,14 +110,22 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     constexpr int W = THREADS / 64;
     const int s = p.s, n = p.n;
     const double r = p.r;
-    const int G = tp.G;
+    int G = tp.G, ntiles = p.ntiles;
+    long long batch = p.batch;
+    if (p.count_dev) {                                         // second pass: sized on the device
+        batch = (long long)*p.count_dev;
+        if (batch <= (long long)p.count_skip || batch > (long long)tp.count_max) return;
+        ntiles = (int)((batch + kTile - 1) / kTile);
+        G = min(G, (int)(gridDim.x >> 3) / ((ntiles + 7) / 8));
+        if (G < 1) return;                                     // (count_max keeps this from happening)
+    }
     // Workgroups are dealt round-robin over the 8 XCDs (observed, not promised): blocks b and b + 8 share
     // one.  Teams are formed among the blocks of one residue class, so that normally a team sits on ONE
     // XCD; the members check it (xccs) and fall back to full release / acquire barriers if it is not so.
     const int q = (int)(blockIdx.x >> 3), xslot = (int)(blockIdx.x & 7u);   // gridDim.x == 8 * G * ceil(ntiles / 8)
     const int tile = tp.scatter ? (int)(blockIdx.x / (unsigned)G) : (q / G) * 8 + xslot;
     const int rank = tp.scatter ? (int)(blockIdx.x % (unsigned)G) : q % G;
-    if (tile >= p.ntiles) return;                              // whole teams only: nobody waits for these
+    if (tile >= ntiles || (p.count_dev && q >= G * ((ntiles + 7) / 8))) return;   // whole teams only: nobody waits for these
     const int gw = rank * W + w, GW = G * W;                   // this wave among the team's waves
     double *const Mt = p.msg + (size_t)tile * (size_t)p.slot_stride + lane;
     unsigned int *const ctr = tp.ctl + (size_t)tile * kTeamCtlWords;
@@ -131,7 +143,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     const u64 *syn = synmask + (size_t)tile * s;
     u64 *em = p.errmask + (size_t)tile * n;
     const long long b0 = (long long)tile * kTile;
-    const long long left = p.batch - b0;
+    const long long left = batch - b0;
     u64 deferred = 0;
     const u64 valid = left >= kTile ? ~0ull : ((1ull << left) - 1ull);
     const u64 never = nevermask[tile];
@@ -229,8 +241,9 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     if ((active >> lane) & 1ull) { my_iters = it; my_conv = 0; }
     if (rank == 0 && w == 0) {
         if (((valid & ~deferred) >> lane) & 1ull) {
-            p.conv[b0 + lane] = (unsigned char)my_conv;
-            if (p.iters) p.iters[b0 + lane] = my_iters;
+            const long long ob = p.index ? (long long)p.index[b0 + lane] : b0 + lane;
+            p.conv[ob] = (unsigned char)my_conv;
+            if (p.iters) p.iters[ob] = my_iters;
         } else {
             my_iters = 0;
         }

@@ -121,7 +121,7 @@ struct ldpc_bp_decoder {
     int64_t node_take_max = 0;    // most stragglers the node-parallel kernel takes as the second pass of the hand-off
     DevBuf node_msg;          // [workgroups][nnz] double, the node-parallel kernel's message slots
     // team kernel (bp_team_kernels.hpp): arrival counters + mismatch words, and the host-mapped fault word
-    DevBuf team_ws;
+    DevBuf team_ws, team_ws2;   // control blocks of the first-pass / second-pass team kernel
     unsigned int *team_fault = nullptr, *team_fault_dev = nullptr;
     int team_max = 32;        // workgroups per tile at most (LDPC_TEAM_MAX; 1 = team kernel off)
     // latency mode of the host-pointer entry (tiny batches, a plain decode!): the kernel reads and writes a
@@ -145,6 +145,7 @@ struct ldpc_bp_decoder {
     // second pass of the straggler hand-off
     DevBuf defer_list, synmask2, nevermask2, errmask2, llr_t2;
     int defer_thresh = 0;     // 0 auto (16 lanes), -1 off, else the lane count at which a tile gives up
+    int defer_max_iter = 8;   // tiles hand off only up to this iteration (LDPC_DEFER_MAX_ITER, read at create)
     float placement_ms = 0.f; // probe time of the chosen workspace allocation (0 = no probing happened)
     int placement_candidates = 0;
     // staging for the host-pointer entry
@@ -172,7 +173,7 @@ struct ldpc_bp_decoder {
     ~ldpc_bp_decoder()
     {
         DevBuf *all[] = {&row_ptr, &edge_bit, &col_ptr, &csc2csr, &msg, &ctrl, &synmask, &nevermask,
-                         &errmask, &llr_t, &st_all, &node_msg, &done_ctr, &team_ws,
+                         &errmask, &llr_t, &st_all, &node_msg, &done_ctr, &team_ws, &team_ws2,
                          &defer_list, &synmask2, &nevermask2, &errmask2, &llr_t2};
         for (DevBuf *b : all) b->release();
         if (pin) (void)hipHostFree(pin);
@@ -492,6 +493,7 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     // (measured crossovers in DESIGN.md); LDPC_NODE_MAX_BATCH overrides for experiments.
     d->node_max_batch = (int64_t)d->num_cus * 8;
     if (const char *e = std::getenv("LDPC_NODE_MAX_BATCH")) d->node_max_batch = std::atoll(e);
+    if (const char *e = std::getenv("LDPC_DEFER_MAX_ITER")) d->defer_max_iter = std::max(2, std::atoi(e));
     d->node_take_max = (int64_t)d->num_cus * 8;
     if (const char *e = std::getenv("LDPC_NODE_TAKE_MAX")) d->node_take_max = std::atoll(e);
     // keep the workspace inside a sane share of HBM (slots are nnz*512 B each)
@@ -564,22 +566,31 @@ static bool takes_lds_kernel(const ldpc_bp_decoder *d, bool want_llr)
 // Teams are formed inside one XCD (1/8 of the CUs), two workgroups per CU so that every member is
 // resident with room to spare (the register budget admits three), and a member should have >= 2048
 // message rows per sweep to pay for the three team barriers of an iteration.
-static int team_size(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
+// (per_xcd: team workgroups one XCD hosts; gcap: members per tile at most; false = no teams for this decoder)
+static bool team_geometry(ldpc_bp_decoder *d, bool want_llr, int *per_xcd, int *gcap)
 {
-    if (!(d->variant == 0 || d->variant == 4) || d->team_max < 2 || d->wpt_fixed || d->resident_fixed || d->nnz <= 0) return 1;
-    const int64_t ntiles = (batch + kTile - 1) / kTile;
-    if (ntiles < 1 || ntiles > d->num_cus) return 1;
+    if (!(d->variant == 0 || d->variant == 4) || d->team_max < 2 || d->wpt_fixed || d->resident_fixed || d->nnz <= 0) return false;
     static const int per_cu_want = [] { const char *e = std::getenv("LDPC_TEAM_PER_CU"); return e ? std::max(1, std::min(3, std::atoi(e))) : 2; }();
     // what this instantiation's registers admit (the wide-degree buckets: one 8-wave workgroup per CU), less one
     // as the margin where that leaves at least one
     int occ = 0;
-    if (d->prepare_kernel((const void *)pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr), 512, 0, &occ) != LDPC_OK) return 1;
+    if (d->prepare_kernel((const void *)pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr), 512, 0, &occ) != LDPC_OK) return false;
     const int per_cu = std::min(per_cu_want, occ >= 2 ? occ - (occ > per_cu_want ? 0 : 1) : occ);
-    if (per_cu < 1) return 1;
-    const int64_t teams_per_xcd = (ntiles + 7) / 8;
-    int64_t team = std::min<int64_t>(d->team_max, (int64_t)per_cu * (d->num_cus / 8) / teams_per_xcd);
+    if (per_cu < 1) return false;
     static const int64_t min_rows = [] { const char *e = std::getenv("LDPC_TEAM_MIN_ROWS"); return e ? std::max<int64_t>(1, std::atoll(e)) : (int64_t)2048; }();
-    team = std::min<int64_t>(team, std::max<int64_t>(1, d->nnz / min_rows));   // (LDPC_TEAM_MIN_ROWS=1: tests put teams on tiny graphs)
+    *per_xcd = per_cu * (d->num_cus / 8);
+    *gcap = (int)std::min<int64_t>(d->team_max, std::max<int64_t>(1, d->nnz / min_rows));   // (LDPC_TEAM_MIN_ROWS=1: tests put teams on tiny graphs)
+    return *per_xcd >= 1;
+}
+
+static int team_size(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
+{
+    int per_xcd = 0, gcap = 0;
+    if (!team_geometry(d, want_llr, &per_xcd, &gcap)) return 1;
+    const int64_t ntiles = (batch + kTile - 1) / kTile;
+    if (ntiles < 1 || ntiles > d->num_cus) return 1;
+    const int64_t teams_per_xcd = (ntiles + 7) / 8;
+    int64_t team = std::min<int64_t>(gcap, (int64_t)per_xcd / teams_per_xcd);
     if ((size_t)ntiles * ((size_t)d->max_iters + 32) * sizeof(u64) > ((size_t)16 << 20)) team = 1;
     return team < 3 ? 1 : (int)team;   // two workgroups per tile measured no better than the tile kernel's one of 16 waves
 }
@@ -850,8 +861,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     p.phase_ticks = (u64 *)(ctrl + 16);
     p.defer_thresh = thresh;
     p.defer_min_iter = 2;
-    static const int defer_max_iter = [] { const char *e = std::getenv("LDPC_DEFER_MAX_ITER"); return e ? std::max(2, std::atoi(e)) : 8; }();
-    p.defer_max_iter = defer_max_iter;
+    p.defer_max_iter = d->defer_max_iter;
     p.defer_list = (int *)d->defer_list.p;
     p.defer_count = defer_count;
     p.index = nullptr;
@@ -873,6 +883,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         static const int always_release = std::getenv("LDPC_TEAM_ALWAYS_RELEASE") ? 1 : 0;
         tp.always_release = always_release;
         tp.scatter = std::getenv("LDPC_TEAM_SCATTER") ? 1 : 0;   // (read per call: a test switches it on and off)
+        tp.count_max = 0;
         team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr);
         HIP_TRY(hipEventRecord(ev[1], stream));
         // Cooperative launch: the runtime checks the grid against the kernel's residency and does not run
@@ -909,6 +920,15 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
                                (const unsigned int *)defer_count, node_take);
             HIP_TRY(hipGetLastError());
         }
+        // Three regimes for the second pass, told apart on the device by the hand-off count: up to node_take
+        // syndromes the node kernel (below), up to team2_cap teams of workgroups on packed tiles, beyond
+        // that one workgroup per packed tile.
+        unsigned team2_cap = 0;
+        int t2_per_xcd = 0, t2_gcap = 0;
+        if (node_take && d->max_iters <= 4096 && team_geometry(d, want_llr, &t2_per_xcd, &t2_gcap) && t2_gcap >= 3) {
+            const int tiles_max = std::min(std::min(8 * (t2_per_xcd / 3), ntiles2), grid);   // >= 3 members per tile
+            if ((unsigned)tiles_max * kTile > node_take) team2_cap = (unsigned)tiles_max * kTile;
+        }
         BPParams p2 = p;
         p2.errmask = (u64 *)d->errmask2.p;
         p2.llr = want_llr ? (double *)d->llr_t2.p : nullptr;
@@ -916,12 +936,37 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         p2.defer_thresh = 0;
         p2.index = (const int *)d->defer_list.p;
         p2.count_dev = defer_count;
-        p2.count_skip = node_take;
+        p2.count_skip = std::max(node_take, team2_cap);
         bp_kernel_t kfn2 = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, threads, true);
         hipLaunchKernelGGL(kfn2, dim3((unsigned)std::min(grid, ntiles2)), dim3((unsigned)threads), 0, stream, p2,
                            (const int *)d->row_ptr.p, (const int *)d->edge_bit.p, (const int *)d->col_ptr.p,
                            (const int *)d->csc2csr.p, (const u64 *)d->synmask2.p, (const u64 *)d->nevermask2.p);
         HIP_TRY(hipGetLastError());
+        if (team2_cap) {
+            const int tiles_max = (int)(team2_cap / kTile);
+            const size_t ctl_bytes = (size_t)tiles_max * kTeamCtlWords * sizeof(unsigned int);
+            const size_t mism_stride = ((size_t)d->max_iters + 31) & ~(size_t)31;
+            const size_t ws2 = ctl_bytes + (size_t)tiles_max * mism_stride * sizeof(u64);
+            if ((st = d->team_ws2.ensure(ws2)) != LDPC_OK) return st;
+            HIP_TRY(hipMemsetAsync(d->team_ws2.p, 0, ws2, stream));
+            BPParams p3 = p2;
+            p3.count_skip = node_take;
+            TeamParams tp;
+            tp.G = t2_gcap;
+            tp.ctl = (unsigned int *)d->team_ws2.p;
+            tp.mism = (u64 *)((char *)d->team_ws2.p + ctl_bytes);
+            tp.mism_stride = (int)mism_stride;
+            tp.fault = d->team_fault_dev;
+            tp.always_release = 0;
+            tp.scatter = 0;
+            tp.count_max = team2_cap;
+            team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr);
+            const int *a_row = (const int *)d->row_ptr.p, *a_eb = (const int *)d->edge_bit.p, *a_col = (const int *)d->col_ptr.p,
+                      *a_c2r = (const int *)d->csc2csr.p;
+            const u64 *a_syn = (const u64 *)d->synmask2.p, *a_nev = (const u64 *)d->nevermask2.p;
+            void *args[] = {&p3, &tp, &a_row, &a_eb, &a_col, &a_c2r, &a_syn, &a_nev};
+            HIP_TRY(hipLaunchCooperativeKernel((const void *)tk, dim3((unsigned)(8 * t2_per_xcd)), dim3(512), args, 0, stream));
+        }
     }
     HIP_TRY(hipEventRecord(ev[2], stream));
     if (n > 0) {

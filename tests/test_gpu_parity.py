@@ -153,17 +153,21 @@ def test_c3_code_n16384_small_batch(ldpc, gpu):
             assert not conv.any() and (its == 50).all()
 
 
-@pytest.mark.parametrize("node_max", ["8", "256", None])
-def test_straggler_handoff_second_pass_kinds(ldpc, gpu, node_max, monkeypatch):
-    """A batch large enough for the tile kernel on a code beyond the LDS, broad iteration distribution:
-    tiles hand their stragglers to a second pass, which is the node-parallel kernel while there are at
-    most LDPC_NODE_MAX_BATCH of them (read at create) and packed tiles above that -- decided on the
-    device.  Every syndrome against the oracle, LLRs included."""
-    if node_max is not None:
-        monkeypatch.setenv("LDPC_NODE_MAX_BATCH", node_max)
+@pytest.mark.parametrize("take,team_max", [("8", None), ("8", "1"), ("256", None), (None, None)])
+def test_straggler_handoff_second_pass_kinds(ldpc, gpu, take, team_max, monkeypatch):
+    """A medium batch on a code beyond the LDS, broad iteration distribution: tiles hand their stragglers
+    to a second pass -- decided on the device from their number: the node-parallel kernel up to
+    LDPC_NODE_TAKE_MAX of them, teams of workgroups on packed tiles above that, one workgroup per packed
+    tile where teams are off (LDPC_TEAM_MAX=1) or the stragglers too many.  (take 8: teams / packed
+    tiles; 256 and default: node kernel.)  Every syndrome against the oracle, LLRs included."""
+    if take is not None:
+        monkeypatch.setenv("LDPC_NODE_TAKE_MAX", take)
+    if team_max is not None:
+        monkeypatch.setenv("LDPC_TEAM_MAX", team_max)
+    monkeypatch.setenv("LDPC_DEFER_MAX_ITER", "30")      # the default (8) rarely hands off at this error rate
     n = 4096
     H = ldpc.codes.parity_check_csc(n, 8, 4)
-    B = 2600 if node_max is None else 1200          # > the node-parallel kernel's own batch limit
+    B = 2600 if take is None else 1200
     e = ldpc.codes.random_errors(n, B, 0.065, seed=41)
     syn = ldpc.codes.syndromes_of(H, e)
     err, conv, its = assert_parity(ldpc, H, 0.065, 40, syn, kernel_variant=0)
