@@ -278,18 +278,21 @@ static ldpc_status ensure_workspace(ldpc_bp_decoder *d, size_t bytes, int grid, 
     void *keep = nullptr;      // best allocation so far (held across rounds)
     float keep_ms = 0.f;
     int probed = 0;
-    // Round 0 probes as many candidates as fit.  Measured classes on C3: ~8.6 ms (fast), ~9.4 ms, ~10.1 ms
-    // per probe pass, and a round of nine often holds no fast one; so unless the best is clearly of the
-    // fast class (<= 0.875 x the slowest seen), further rounds repeat behind a shim of 1/2, then 1/4
-    // workspace so that the windows fall on other addresses.
-    float worst_ms = 0.f;
-    for (int round = 0; round < 3; ++round) {
+    // Round 0 probes as many candidates as fit.  Measured classes on C3: ~8.6 ms (fast, 6.0 TB/s of probe
+    // traffic), ~9.4 ms (5.5), ~10.1 ms (5.1) per probe pass, and a round of nine often holds no fast one
+    // (one box's best was 8.97 ms, "clearly better than the slowest", and the launches took 1.27 s instead
+    // of 1.17 s); so unless the best reaches the fast class in absolute terms (>= 5.95 TB/s: 8.66 ms at C3), further
+    // rounds repeat behind a shim of 1/2, then 1/4 workspace so that the windows fall on other addresses.
+    static const int max_rounds = [] { const char *e = std::getenv("LDPC_PLACEMENT_ROUNDS"); return e ? std::max(1, std::min(8, std::atoi(e))) : 6; }();
+    for (int round = 0; round < max_rounds; ++round) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); break; }
         void *shim = nullptr;
-        const size_t shim_bytes = round == 0 ? 0 : (round == 1 ? bytes / 2 : bytes / 4);
+        // shims of 1/2, 1/4, 3/4, 1/8, 3/8, ... workspace move the candidate windows to other addresses
+        static const int shim_eighths[8] = {0, 4, 2, 6, 1, 3, 5, 7};
+        const size_t shim_bytes = bytes / 8 * (size_t)shim_eighths[round & 7];
         if (shim_bytes && hipMalloc(&shim, shim_bytes) != hipSuccess) { (void)hipGetLastError(); shim = nullptr; }
-        const size_t budget = free_b / 10 * 8 - shim_bytes;
+        const size_t budget = free_b / 10 * 8 > shim_bytes ? free_b / 10 * 8 - shim_bytes : 0;
         const int K = std::min<int>(want, (int)(budget / std::max<size_t>(bytes, 1)));
         std::vector<void *> cand;
         std::vector<float> ms;
@@ -311,14 +314,14 @@ static ldpc_status ensure_workspace(ldpc_bp_decoder *d, size_t bytes, int grid, 
             if (ms[k] > 0 && (best < 0 || ms[k] < ms[(size_t)best])) best = (int)k;
         bool standout = true;
         if (best >= 0) {
-            for (float t : ms) worst_ms = std::max(worst_ms, t);
             if (!keep || ms[(size_t)best] < keep_ms) {
                 if (keep) (void)hipFree(keep);
                 keep = cand[(size_t)best];
                 keep_ms = ms[(size_t)best];
                 cand[(size_t)best] = nullptr;
             }
-            standout = keep_ms <= 0.875f * worst_ms;
+            const double probe_bytes = 2.0 * (double)grid * (double)d->nnz * 512.0;
+            standout = probe_bytes / ((double)keep_ms * 1e-3) >= 5.95e12;
         }
         probed += (int)cand.size();
         for (void *q : cand)
