@@ -18,6 +18,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 t0, cases, decoded = time.time(), 0, 0
+last_note = t0
 while time.time() - t0 < budget:
     kind = rng.integers(0, 4)
     if kind == 0:      # Gallager regular
@@ -80,4 +81,7 @@ while time.time() - t0 < budget:
             sys.exit(1)
         d2.close()
     cases += 1
+    if time.time() - last_note > 60:   # a silent GPU job looks hung to the runner
+        last_note = time.time()
+        print(f"... {cases} cases, {decoded} syndromes, {time.time() - t0:.0f} s", flush=True)
 print(f"fuzz ok: {cases} random cases, {decoded} syndromes decoded on the GPU in {time.time() - t0:.0f} s, seed {seed}")
