@@ -321,7 +321,9 @@ static ldpc_status ensure_workspace(ldpc_bp_decoder *d, size_t bytes, int grid, 
                 cand[(size_t)best] = nullptr;
             }
             const double probe_bytes = 2.0 * (double)grid * (double)d->nnz * 512.0;
-            standout = probe_bytes / ((double)keep_ms * 1e-3) >= 5.95e12;
+            // (the absolute mark is what 512+ streaming workgroups reach; a smaller grid -- the team kernel's
+            // medium batches -- takes the best of two rounds)
+            standout = grid >= 512 ? probe_bytes / ((double)keep_ms * 1e-3) >= 5.95e12 : round >= 1;
         }
         probed += (int)cand.size();
         for (void *q : cand)
