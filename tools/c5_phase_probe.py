@@ -1,6 +1,10 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4] (BB-72, 2^20 syndromes, BP + OSD-0 on the host): where the time of
+BeliefPropagationOSDDecoder.batchdecode_device goes -- allocation, BP on the GPU, finding the unconverged
+syndromes, copying them to the host, OSD, copying the estimates back."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ldpcdecoders_jl_amd as ldpc
 HX,_ = ldpc.codes.bivariate_bicycle_72_12_6()
 B=1<<20

@@ -1,6 +1,11 @@
+#!/usr/bin/env python3
+"""Team kernel (kernel_variant 4) on the C3 code, all 50 iterations: ms per call for a few batch sizes and, from
+the kernel's own phase clocks (ldpc_bp_call_phase_ticks), what one member spends per iteration in its check
+sweep, its variable sweep and everything else (team barriers + convergence test, waiting included).
+BATCHES=64,512,...  LDPC_TEAM_DEBUG=1 additionally prints which XCDs the teams landed on."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ldpcdecoders_jl_amd as ldpc
 n=16384; per=0.10
 H = ldpc.codes.parity_check_csc(n, 8, 4)
