@@ -209,3 +209,27 @@ def test_decoder_lifecycle_does_not_leak_device_memory(ldpc, gpu):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < (64 << 20), f"device memory shrank by {(free0 - free1) >> 20} MiB over 25 decoder life cycles"
+
+
+def test_timing_history_reaches_sixteen_calls_back(ldpc, gpu):
+    """ldpc_bp_call_timing: the last 16 batch calls keep their HIP-event times and iteration sums (bench.py
+    reads them after its timed region); one further back is an argument error, not stale data."""
+    import torch
+
+    H = ldpc.codes.parity_check_csc(1008, 6, 3)
+    dec = ldpc.BeliefPropagationDecoder(H, 0.01, 50)
+    B = 700
+    sums = []
+    for k in range(20):
+        syn = torch.from_numpy(ldpc.codes.syndromes_of(H, ldpc.codes.random_errors(1008, B, 0.01, seed=k))).cuda()
+        err = torch.empty((B, 1008), dtype=torch.uint8, device="cuda")
+        conv = torch.empty(B, dtype=torch.uint8, device="cuda")
+        its = torch.empty(B, dtype=torch.int32, device="cuda")
+        dec.decode_batch_device(syn, err, conv, None, its)
+        torch.cuda.synchronize()
+        sums.append(int(its.sum().item()))
+    for back in range(16):
+        sweep_ms, total_ms, sum_iters = dec.last_timing(back)
+        assert sum_iters == sums[19 - back] and 0 < sweep_ms <= total_ms
+    with pytest.raises(ldpc.LdpcError):
+        dec.last_timing(16)
