@@ -37,6 +37,8 @@ WORKLOADS = {
     # benchmark/benchmarks.jl:8-11): (9,10)-regular n=1000, per 0.01, 100 iterations
     "ref_1000_10_9": (1000, 10, 9, 65536, 0.01, 100),
     "ref_1000_10_9_hard": (1000, 10, 9, 65536, 0.06, 100),
+    # a code whose messages fit a CU's LDS (128 KiB) but whose graph copy does not: node kernel, messages in LDS
+    "mid_4096": (4096, 8, 4, 65536, 0.02, 50),
     # a large code with wider nodes (row weight 10, column weight 5): the 16-wide register bucket
     "wide_16000_10_5": (16000, 10, 5, 32768, 0.10, 50),
     # BASELINE configs[4]: BB [[72,12,6]] H_X, BP on the GPU + OSD-0 on the host for what BP leaves

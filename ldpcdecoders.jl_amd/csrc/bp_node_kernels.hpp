@@ -49,7 +49,10 @@ struct NodeParams {
 
 __host__ __device__ inline size_t node_lds_bytes(int s, int n) { return ((size_t)s + (size_t)n + 15) & ~(size_t)15; }
 
-template <int DC, int DV, bool WANT_LLR, int THREADS>
+// MSG_LDS: the nnz messages of the syndrome sit in LDS behind the syndrome / decision bytes instead of in the
+// global slot -- graphs whose messages fit a CU's LDS but whose uint16 graph copy and 64-bit masks (the LDS
+// kernel's layout) do not: the scattered 8-byte accesses then cost LDS cycles instead of the CU's address path.
+template <int DC, int DV, bool WANT_LLR, int THREADS, bool MSG_LDS>
 __global__ void __launch_bounds__(THREADS)
 bp_node_kernel(NodeParams p, const int *__restrict__ row_ptr, const int *__restrict__ edge_bit,
                const int *__restrict__ col_ptr, const int *__restrict__ csc2csr)
@@ -61,7 +64,8 @@ bp_node_kernel(NodeParams p, const int *__restrict__ row_ptr, const int *__restr
     const int s = p.s, n = p.n;
     const int tid = threadIdx.x;
     const double r = p.r;
-    double *M = p.msg + (size_t)blockIdx.x * (size_t)p.slot_stride;
+    double *M = MSG_LDS ? (double *)(node_lds + node_lds_bytes(p.s, p.n))
+                        : p.msg + (size_t)blockIdx.x * (size_t)p.slot_stride;
     u64 acc_iters = 0;
     if (p.next_ctrl && blockIdx.x == 0 && tid < 8) p.next_ctrl[tid] = 0;
     long long batch = p.batch;

@@ -117,6 +117,7 @@ struct ldpc_bp_decoder {
     int blocks_cache[2][17];  // [want_llr][waves per tile] -> resident workgroups per CU, -1 = not queried yet
     int variant = 0;          // 0 auto, 1 HBM-streaming tile kernel, 2 LDS-resident kernel, 3 node-parallel kernel
     bool node_ok = false;     // syndrome + decision bytes of one syndrome fit the LDS (bp_node_kernels.hpp)
+    bool node_msg_lds = false;   // ... and its nnz messages too (LDPC_NODE_MSG_LDS=0 keeps them in the global slots)
     int64_t node_max_batch = 0;   // auto: largest batch the node-parallel kernel takes where the team kernel does not apply
     int64_t node_take_max = 0;    // most stragglers the node-parallel kernel takes as the second pass of the hand-off
     DevBuf node_msg;          // [workgroups][nnz] double, the node-parallel kernel's message slots
@@ -490,6 +491,8 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
         return fail(LDPC_ERR_UNSUPPORTED, "kernel_variant 2 (LDS-resident) requested but the edge messages do not fit the LDS");
     }
     d->node_ok = node_lds_bytes((int)s, (int)n) + 1024 <= (size_t)160 * 1024;
+    d->node_msg_lds = d->node_ok && node_lds_bytes((int)s, (int)n) + (size_t)nnz * sizeof(double) + 1024 <= (size_t)160 * 1024;
+    if (const char *e = std::getenv("LDPC_NODE_MSG_LDS")) d->node_msg_lds = d->node_msg_lds && std::atoi(e) != 0;
     if (d->variant == 3 && !d->node_ok) {
         delete d;
         return fail(LDPC_ERR_UNSUPPORTED, "kernel_variant 3 (node-parallel) requested but s + n bytes do not fit the LDS");
@@ -613,6 +616,7 @@ static bool takes_node_kernel(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
     if (d->variant == 3) return true;
     if (d->variant != 0) return false;
     if (batch < kTile) return true;
+    if (d->node_msg_lds) return true;   // messages in LDS: not HBM-bound at any batch size (n = 4096)
     const int G = team_size(d, batch, want_llr);
     if (G < 2) return batch <= d->node_max_batch;
     const double edges = (double)d->nnz;
@@ -718,16 +722,17 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         // ---- small batch on a large graph: one workgroup per syndrome, one thread per node (bp_node_kernels.hpp)
         if (batch > (1ll << 30)) return fail(LDPC_ERR_UNSUPPORTED, "batch too large for one call");
         // all 16 waves of a CU on one syndrome while there are CUs to spare, else two 8-wave workgroups per CU
-        const int nthreads = d->wpt_fixed ? (d->wpt_fixed >= 12 ? 1024 : 512) : (batch <= d->num_cus ? 1024 : 512);
-        const size_t nlds = node_lds_bytes((int)s, (int)n);
-        node_kernel_t nk = pick_node_kernel(d->max_cdeg, d->max_bdeg, want_llr_early, nthreads);
+        const bool mlds = d->node_msg_lds;   // messages in LDS: one 16-wave workgroup per CU
+        const int nthreads = mlds ? 1024 : (d->wpt_fixed ? (d->wpt_fixed >= 12 ? 1024 : 512) : (batch <= d->num_cus ? 1024 : 512));
+        const size_t nlds = node_lds_bytes((int)s, (int)n) + (mlds ? (size_t)d->nnz * sizeof(double) : 0);
+        node_kernel_t nk = pick_node_kernel(d->max_cdeg, d->max_bdeg, want_llr_early, nthreads, mlds);
         int per_cu = 0;
         ldpc_status pst = d->prepare_kernel((const void *)nk, nthreads, nlds, &per_cu);
         if (pst != LDPC_OK) return pst;
         per_cu = std::min(per_cu, 2);
         const int ngrid = lat ? (int)batch : (int)std::min<int64_t>(batch, (int64_t)per_cu * d->num_cus);
         const size_t stride = (std::max<size_t>((size_t)d->nnz, 1) + 63) & ~(size_t)63;   // 512-byte aligned slots
-        ldpc_status nst = d->node_msg.ensure((size_t)ngrid * stride * sizeof(double));
+        ldpc_status nst = d->node_msg.ensure(mlds ? 64 : (size_t)ngrid * stride * sizeof(double));
         if (nst != LDPC_OK) return nst;
         d->last_kernel = 3; d->last_team = 1;
         NodeParams np;
@@ -999,14 +1004,15 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         }
     }
     if (node_take) {
-        const int nthreads = 512;   // 1024 x 1 per CU measured the same
-        const size_t nlds = node_lds_bytes((int)s, (int)n);
-        node_kernel_t nk = pick_node_kernel(d->max_cdeg, d->max_bdeg, want_llr, nthreads);
+        const bool mlds = d->node_msg_lds;
+        const int nthreads = mlds ? 1024 : 512;   // (global slots: 1024 x 1 per CU measured the same as 512 x 2)
+        const size_t nlds = node_lds_bytes((int)s, (int)n) + (mlds ? (size_t)d->nnz * sizeof(double) : 0);
+        node_kernel_t nk = pick_node_kernel(d->max_cdeg, d->max_bdeg, want_llr, nthreads, mlds);
         int per_cu_unused = 0;
         if ((st = d->prepare_kernel((const void *)nk, nthreads, nlds, &per_cu_unused)) != LDPC_OK) return st;
-        const int ngrid = (int)std::min<int64_t>((int64_t)node_take, (int64_t)2 * d->num_cus);
+        const int ngrid = (int)std::min<int64_t>((int64_t)node_take, (int64_t)(mlds ? 1 : 2) * d->num_cus);
         const size_t stride = (std::max<size_t>((size_t)d->nnz, 1) + 63) & ~(size_t)63;
-        if ((st = d->node_msg.ensure((size_t)ngrid * stride * sizeof(double))) != LDPC_OK) return st;
+        if ((st = d->node_msg.ensure(mlds ? 64 : (size_t)ngrid * stride * sizeof(double))) != LDPC_OK) return st;
         NodeParams np;
         np.s = (int)s; np.n = (int)n; np.nnz = (int)d->nnz; np.max_iters = (int)d->max_iters;
         np.batch = 0; np.r = p.r;

@@ -165,6 +165,8 @@ def test_straggler_handoff_second_pass_kinds(ldpc, gpu, take, team_max, monkeypa
     if team_max is not None:
         monkeypatch.setenv("LDPC_TEAM_MAX", team_max)
     monkeypatch.setenv("LDPC_DEFER_MAX_ITER", "30")      # the default (8) rarely hands off at this error rate
+    monkeypatch.setenv("LDPC_NODE_MSG_LDS", "0")         # (by default this code's messages live in LDS and no batch
+                                                         # of it ever reaches the tile / team kernels)
     n = 4096
     H = ldpc.codes.parity_check_csc(n, 8, 4)
     B = 2600 if take is None else 1200
@@ -217,12 +219,18 @@ def test_team_kernel_is_bit_identical_to_the_tile_kernel(ldpc, gpu, B, per, scat
         assert torch.equal(a, b), f"{nm} differ between the tile and the team kernel"
 
 
-def test_auto_dispatch_picks_the_kernel_by_code_and_batch(ldpc, gpu):
-    """kernel_variant 0: LDS-resident kernel for a code that fits the LDS; beyond it the node-parallel
+def test_auto_dispatch_picks_the_kernel_by_code_and_batch(ldpc, gpu, monkeypatch):
+    """kernel_variant 0: LDS-resident kernel for a code that fits the LDS; node-parallel kernel with the messages
+    in LDS at every batch size for a code whose messages alone fit it (n = 4096); beyond that the node-parallel
     kernel below one tile, the team kernel for medium batches, the tile kernel once there is a tile per CU
     (ldpc_bp_info.last_kernel, numbered like kernel_variant).  Results against the oracle on a sample."""
     small = ldpc.codes.parity_check_csc(1008, 6, 3)
     big = ldpc.codes.parity_check_csc(4096, 8, 4)
+    d_mid = ldpc.BeliefPropagationDecoder(big, 0.03, 30)
+    d_mid.decode_batch_host(ldpc.codes.syndromes_of(big, ldpc.codes.random_errors(4096, 20000, 0.03, seed=20000)))
+    assert d_mid.info().last_kernel == 3
+    d_mid.close()
+    monkeypatch.setenv("LDPC_NODE_MSG_LDS", "0")    # from here on: as if the messages did not fit the LDS
     d_small = ldpc.BeliefPropagationDecoder(small, 0.01, 50)
     d_small.decode_batch_host(ldpc.codes.syndromes_of(small, ldpc.codes.random_errors(1008, 3000, 0.01, seed=1)))
     assert d_small.info().last_kernel == 2
