@@ -233,3 +233,40 @@ def test_timing_history_reaches_sixteen_calls_back(ldpc, gpu):
         assert sum_iters == sums[19 - back] and 0 < sweep_ms <= total_ms
     with pytest.raises(ldpc.LdpcError):
         dec.last_timing(16)
+
+
+def test_two_handles_from_two_threads(ldpc, gpu):
+    """"Different handles may be used from different threads" (include/ldpc_mi355x.h): two decoders, each
+    hammered from its own host thread with single decode! calls (latency path), small and medium batches
+    (staged path; LDS, node-parallel and team kernels, the latter launched cooperatively) -- every result
+    must equal the one the same handle gives when it runs alone."""
+    import threading
+
+    H1 = ldpc.codes.parity_check_csc(1008, 6, 3)
+    H2 = ldpc.codes.parity_check_csc(16384, 8, 4)
+    S1 = ldpc.codes.syndromes_of(H1, ldpc.codes.random_errors(1008, 900, 0.02, seed=5))
+    S2 = ldpc.codes.syndromes_of(H2, ldpc.codes.random_errors(16384, 300, 0.02, seed=6))
+    d1 = ldpc.BeliefPropagationDecoder(H1, 0.02, 50)
+    d2 = ldpc.BeliefPropagationDecoder(H2, 0.02, 50)
+    plan1 = [slice(k, k + 1) for k in range(40)] + [slice(0, 900), slice(100, 164)]
+    plan2 = [slice(k, k + 1) for k in range(6)] + [slice(0, 300), slice(0, 64), slice(10, 140)]
+    ref1 = [d1.decode_batch_host(S1[sl], want_iters=True) for sl in plan1]
+    ref2 = [d2.decode_batch_host(S2[sl], want_iters=True) for sl in plan2]
+    errors = []
+
+    def worker(dec, S, plan, ref):
+        try:
+            for rep in range(3):
+                for sl, want in zip(plan, ref):
+                    got = dec.decode_batch_host(S[sl], want_iters=True)
+                    if not (np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and np.array_equal(got[3], want[3])):
+                        errors.append((S.shape, sl))
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(d1, S1, plan1, ref1)), threading.Thread(target=worker, args=(d2, S2, plan2, ref2))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:3]
