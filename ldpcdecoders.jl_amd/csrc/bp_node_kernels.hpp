@@ -45,14 +45,69 @@ struct NodeParams {
     unsigned int *done_count;
     unsigned int *done_flag;
     unsigned int done_ticket;
+    // hybrid placement (MSG == 2): the messages of checks [0, split_check) = edges [0, split_edge) sit in LDS,
+    // the rest in the global slot (edge e at msg[e - split_edge])
+    int split_check, split_edge;
 };
 
 __host__ __device__ inline size_t node_lds_bytes(int s, int n) { return ((size_t)s + (size_t)n + 15) & ~(size_t)15; }
 
-// MSG_LDS: the nnz messages of the syndrome sit in LDS behind the syndrome / decision bytes instead of in the
-// global slot -- graphs whose messages fit a CU's LDS but whose uint16 graph copy and 64-bit masks (the LDS
-// kernel's layout) do not: the scattered 8-byte accesses then cost LDS cycles instead of the CU's address path.
-template <int DC, int DV, bool WANT_LLR, int THREADS, bool MSG_LDS>
+// Variable-node update with the message array split between LDS and the global slot (MSG == 2): lds_bit_unit's
+// arithmetic on addresses chosen per edge (generic pointers: the hardware routes each access).
+template <int DV>
+__device__ __forceinline__ double hybrid_bit_unit(double *Ml, double *Mg, int split, const int *pos, int deg, double r)
+{
+    double F = r;                                                     // :153
+    if (deg <= DV) {
+        double c[DV], pre[DV];
+        double *at[DV];
+#pragma unroll
+        for (int k = 0; k < DV; ++k)
+            if (k < deg) { const int e = pos[k]; at[k] = e < split ? Ml + e : Mg + (e - split); c[k] = *at[k]; }
+#pragma unroll
+        for (int k = 0; k < DV; ++k)
+            if (k < deg) {
+                pre[k] = F;                                           // :156
+                F = F * c[k];                                         // :157
+                if (F != F) F = 1.0;                                  // :158-160
+            }
+        double G = 1.0;                                               // :170
+#pragma unroll
+        for (int k = DV - 1; k >= 0; --k)
+            if (k < deg) {
+                *at[k] = pre[k] * G;                                  // :172
+                G = G * c[k];                                         // :173
+                if (G != G) G = 1.0;                                  // :174-176
+            }
+    } else {
+        auto addr = [&](int k) { const int e = pos[k]; return e < split ? Ml + e : Mg + (e - split); };
+        for (int k = 0; k < deg; ++k) {
+            F = F * *addr(k);
+            if (F != F) F = 1.0;
+        }
+        double G = 1.0;
+        for (int k = deg - 1; k >= 0; --k) {
+            double Pk = r;
+            for (int q = 0; q < k; ++q) {
+                Pk = Pk * *addr(q);
+                if (Pk != Pk) Pk = 1.0;
+            }
+            double *a = addr(k);
+            const double ck = *a;
+            *a = Pk * G;
+            G = G * ck;
+            if (G != G) G = 1.0;
+        }
+    }
+    return F;
+}
+
+// MSG: where the nnz messages of the syndrome live.  0 = the workgroup's global slot (any size; the CU's L2
+// keeps it).  1 = LDS, behind the syndrome / decision bytes -- graphs whose messages fit a CU's LDS but whose
+// uint16 graph copy and 64-bit masks (the LDS kernel's layout) do not: the scattered 8-byte accesses then
+// cost LDS cycles instead of the CU's address path.  2 = hybrid: as many leading checks' messages in LDS as
+// fit, the rest in the global slot.
+template <int DC, int DV, bool WANT_LLR, int THREADS, int MSG>
 __global__ void __launch_bounds__(THREADS)
 bp_node_kernel(NodeParams p, const int *__restrict__ row_ptr, const int *__restrict__ edge_bit,
                const int *__restrict__ col_ptr, const int *__restrict__ csc2csr)
@@ -64,8 +119,10 @@ bp_node_kernel(NodeParams p, const int *__restrict__ row_ptr, const int *__restr
     const int s = p.s, n = p.n;
     const int tid = threadIdx.x;
     const double r = p.r;
-    double *M = MSG_LDS ? (double *)(node_lds + node_lds_bytes(p.s, p.n))
-                        : p.msg + (size_t)blockIdx.x * (size_t)p.slot_stride;
+    double *const Ml = (double *)(node_lds + node_lds_bytes(p.s, p.n));
+    double *const Mg = p.msg + (size_t)blockIdx.x * (size_t)p.slot_stride;
+    double *const M = MSG == 1 ? Ml : Mg;                      // MSG 0 / 1: the one array
+    const int split_check = p.split_check, split_edge = p.split_edge;   // MSG 2
     u64 acc_iters = 0;
     if (p.next_ctrl && blockIdx.x == 0 && tid < 8) p.next_ctrl[tid] = 0;
     long long batch = p.batch;
@@ -106,14 +163,20 @@ bp_node_kernel(NodeParams p, const int *__restrict__ row_ptr, const int *__restr
                 const int e0 = row_ptr[i];
                 const int deg = row_ptr[i + 1] - e0;
                 const double sigma = sbit[i] ? -1.0 : 1.0;
-                lds_check_unit<DC>(M + e0, 1, deg, sigma, first, r);
+                if (MSG == 2) {
+                    if (i < split_check) lds_check_unit<DC>(Ml + e0, 1, deg, sigma, first, r);
+                    else lds_check_unit<DC>(Mg + (e0 - split_edge), 1, deg, sigma, first, r);
+                } else {
+                    lds_check_unit<DC>(M + e0, 1, deg, sigma, first, r);
+                }
             }
             __syncthreads();
             // ---- variable sweep: one thread per bit
             for (int j = tid; j < n; j += THREADS) {
                 const int c0 = col_ptr[j];
                 const int deg = col_ptr[j + 1] - c0;
-                const double T = lds_bit_unit<DV, int>(M, 1, csc2csr + c0, deg, r);
+                const double T = MSG == 2 ? hybrid_bit_unit<DV>(Ml, Mg, split_edge, csc2csr + c0, deg, r)
+                                          : lds_bit_unit<DV, int>(M, 1, csc2csr + c0, deg, r);
                 if (WANT_LLR) p.llr[(size_t)b * n + j] = log(1.0 / T);   // :163, final at the last iteration run
                 ebit[j] = (unsigned char)(T >= 1.0);                      // :164-168
             }

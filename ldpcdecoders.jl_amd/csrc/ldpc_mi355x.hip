@@ -118,6 +118,7 @@ struct ldpc_bp_decoder {
     int variant = 0;          // 0 auto, 1 HBM-streaming tile kernel, 2 LDS-resident kernel, 3 node-parallel kernel
     bool node_ok = false;     // syndrome + decision bytes of one syndrome fit the LDS (bp_node_kernels.hpp)
     bool node_msg_lds = false;   // ... and its nnz messages too (LDPC_NODE_MSG_LDS=0 keeps them in the global slots)
+    int node_split_check = 0, node_split_edge = 0;   // hybrid placement: checks [0, split) keep their messages in LDS (0 = off)
     int64_t node_max_batch = 0;   // auto: largest batch the node-parallel kernel takes where the team kernel does not apply
     int64_t node_take_max = 0;    // most stragglers the node-parallel kernel takes as the second pass of the hand-off
     DevBuf node_msg;          // [workgroups][nnz] double, the node-parallel kernel's message slots
@@ -493,6 +494,16 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     d->node_ok = node_lds_bytes((int)s, (int)n) + 1024 <= (size_t)160 * 1024;
     d->node_msg_lds = d->node_ok && node_lds_bytes((int)s, (int)n) + (size_t)nnz * sizeof(double) + 1024 <= (size_t)160 * 1024;
     if (const char *e = std::getenv("LDPC_NODE_MSG_LDS")) d->node_msg_lds = d->node_msg_lds && std::atoi(e) != 0;
+    if (d->node_ok && !d->node_msg_lds && !(std::getenv("LDPC_NODE_HYBRID") && std::atoi(std::getenv("LDPC_NODE_HYBRID")) == 0)) {
+        // hybrid: as many leading checks as fit keep their messages in LDS
+        const size_t room = (size_t)160 * 1024 - 1024 - node_lds_bytes((int)s, (int)n);
+        int64_t k = 0;
+        while (k < s && (size_t)row_ptr[(size_t)k + 1] * sizeof(double) <= room) ++k;
+        if (k > 0 && (size_t)row_ptr[(size_t)k] * sizeof(double) >= (size_t)16 * 1024) {
+            d->node_split_check = (int)k;
+            d->node_split_edge = row_ptr[(size_t)k];
+        }
+    }
     if (d->variant == 3 && !d->node_ok) {
         delete d;
         return fail(LDPC_ERR_UNSUPPORTED, "kernel_variant 3 (node-parallel) requested but s + n bytes do not fit the LDS");
@@ -606,7 +617,8 @@ static int team_size(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
 // Small batches on graphs beyond the LDS: one workgroup per syndrome (bp_node_kernels.hpp) or teams of
 // workgroups per 64-syndrome tile?  Estimated time of one iteration, from the measurements in DESIGN.md:
 //   node kernel: 1.9 ns per edge and syndrome on its CU (the CU's address path), one syndrome per CU at a
-//                time, three times that once the message slots in flight outgrow the L2s (32 MiB);
+//                time, three times that once the message slots in flight outgrow the L2s (32 MiB); 1.07 ns
+//                for the edges whose messages the hybrid placement keeps in LDS;
 //   team kernel: 41 ns per edge for a tile at one CU's pace, divided among the G members, + ~45 us for the
 //                three team barriers.
 // Where the team kernel does not apply, the node kernel keeps the batches up to node_max_batch.
@@ -621,8 +633,11 @@ static bool takes_node_kernel(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
     if (G < 2) return batch <= d->node_max_batch;
     const double edges = (double)d->nnz;
     const double rounds = (double)((batch + d->num_cus - 1) / d->num_cus);
-    const double in_flight = (double)std::min<int64_t>(batch, 2 * (int64_t)d->num_cus) * edges * 8.0;
-    const double est_node = rounds * edges * 1.9e-3 * (in_flight > 32.0 * 1048576.0 ? 3.0 : 1.0);
+    // hybrid placement: the share g of the messages that stays in global memory pays the address-path price, the
+    // rest the LDS price (1.07 ns per edge: 17.5 us per iteration at nnz = 16384)
+    const double g = d->node_split_check > 0 ? 1.0 - (double)d->node_split_edge / std::max(edges, 1.0) : 1.0;
+    const double in_flight = (double)std::min<int64_t>(batch, 2 * (int64_t)d->num_cus) * edges * g * 8.0;
+    const double est_node = rounds * (edges * (1.0 - g) * 1.07e-3 + edges * g * 1.9e-3 * (in_flight > 32.0 * 1048576.0 ? 3.0 : 1.0));
     const double est_team = edges * 41e-3 / (double)G + 45.0;
     return est_node < est_team;
 }
@@ -723,9 +738,11 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         if (batch > (1ll << 30)) return fail(LDPC_ERR_UNSUPPORTED, "batch too large for one call");
         // all 16 waves of a CU on one syndrome while there are CUs to spare, else two 8-wave workgroups per CU
         const bool mlds = d->node_msg_lds;   // messages in LDS: one 16-wave workgroup per CU
-        const int nthreads = mlds ? 1024 : (d->wpt_fixed ? (d->wpt_fixed >= 12 ? 1024 : 512) : (batch <= d->num_cus ? 1024 : 512));
-        const size_t nlds = node_lds_bytes((int)s, (int)n) + (mlds ? (size_t)d->nnz * sizeof(double) : 0);
-        node_kernel_t nk = pick_node_kernel(d->max_cdeg, d->max_bdeg, want_llr_early, nthreads, mlds);
+        const int msg_mode = mlds ? 1 : (d->node_split_check > 0 ? 2 : 0);
+        const int nthreads = msg_mode ? 1024 : (d->wpt_fixed ? (d->wpt_fixed >= 12 ? 1024 : 512) : (batch <= d->num_cus ? 1024 : 512));
+        const size_t nlds = node_lds_bytes((int)s, (int)n) +
+                            (msg_mode == 1 ? (size_t)d->nnz : msg_mode == 2 ? (size_t)d->node_split_edge : 0) * sizeof(double);
+        node_kernel_t nk = pick_node_kernel(d->max_cdeg, d->max_bdeg, want_llr_early, nthreads, msg_mode);
         int per_cu = 0;
         ldpc_status pst = d->prepare_kernel((const void *)nk, nthreads, nlds, &per_cu);
         if (pst != LDPC_OK) return pst;
@@ -743,6 +760,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         np.queue = (unsigned int *)ctrl;
         np.sum_iters = (u64 *)(ctrl + 8);
         np.index = nullptr; np.count_dev = nullptr; np.count_max = 0;
+        np.split_check = d->node_split_check; np.split_edge = d->node_split_edge;
         np.done_count = (unsigned int *)d->done_ctr.p; np.done_flag = nullptr; np.done_ticket = 0;
         np.next_ctrl = nullptr;
         if (lat) {
@@ -1005,12 +1023,14 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     }
     if (node_take) {
         const bool mlds = d->node_msg_lds;
-        const int nthreads = mlds ? 1024 : 512;   // (global slots: 1024 x 1 per CU measured the same as 512 x 2)
-        const size_t nlds = node_lds_bytes((int)s, (int)n) + (mlds ? (size_t)d->nnz * sizeof(double) : 0);
-        node_kernel_t nk = pick_node_kernel(d->max_cdeg, d->max_bdeg, want_llr, nthreads, mlds);
+        const int msg_mode = mlds ? 1 : (d->node_split_check > 0 ? 2 : 0);
+        const int nthreads = msg_mode ? 1024 : 512;   // (global slots: 1024 x 1 per CU measured the same as 512 x 2)
+        const size_t nlds = node_lds_bytes((int)s, (int)n) +
+                            (msg_mode == 1 ? (size_t)d->nnz : msg_mode == 2 ? (size_t)d->node_split_edge : 0) * sizeof(double);
+        node_kernel_t nk = pick_node_kernel(d->max_cdeg, d->max_bdeg, want_llr, nthreads, msg_mode);
         int per_cu_unused = 0;
         if ((st = d->prepare_kernel((const void *)nk, nthreads, nlds, &per_cu_unused)) != LDPC_OK) return st;
-        const int ngrid = (int)std::min<int64_t>((int64_t)node_take, (int64_t)(mlds ? 1 : 2) * d->num_cus);
+        const int ngrid = (int)std::min<int64_t>((int64_t)node_take, (int64_t)(msg_mode ? 1 : 2) * d->num_cus);
         const size_t stride = (std::max<size_t>((size_t)d->nnz, 1) + 63) & ~(size_t)63;
         if ((st = d->node_msg.ensure(mlds ? 64 : (size_t)ngrid * stride * sizeof(double))) != LDPC_OK) return st;
         NodeParams np;
@@ -1022,6 +1042,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         np.sum_iters = (u64 *)(ctrl + 8);
         np.index = (const int *)d->defer_list.p; np.count_dev = defer_count; np.count_max = node_take;
         np.done_count = nullptr; np.done_flag = nullptr; np.done_ticket = 0; np.next_ctrl = nullptr;
+        np.split_check = d->node_split_check; np.split_edge = d->node_split_edge;
         hipLaunchKernelGGL(nk, dim3((unsigned)ngrid), dim3((unsigned)nthreads), nlds, stream, np,
                            (const int *)d->row_ptr.p, (const int *)d->edge_bit.p, (const int *)d->col_ptr.p,
                            (const int *)d->csc2csr.p);

@@ -5,30 +5,31 @@ namespace ldpc {
 
 namespace {
 template <int DC, int DV, bool LLR>
-node_kernel_t node_pick_threads(int threads, bool msg_lds)
+node_kernel_t node_pick_threads(int threads, int msg)
 {
-    if (msg_lds) return bp_node_kernel<DC, DV, LLR, 1024, true>;   // one 16-wave workgroup owns the CU's LDS
-    return threads == 512 ? bp_node_kernel<DC, DV, LLR, 512, false> : bp_node_kernel<DC, DV, LLR, 1024, false>;
+    if (msg == 1) return bp_node_kernel<DC, DV, LLR, 1024, 1>;   // one 16-wave workgroup owns the CU's LDS
+    if (msg == 2) return bp_node_kernel<DC, DV, LLR, 1024, 2>;
+    return threads == 512 ? bp_node_kernel<DC, DV, LLR, 512, 0> : bp_node_kernel<DC, DV, LLR, 1024, 0>;
 }
 template <int DC, bool LLR>
-node_kernel_t node_pick_dv(int dv, int threads, bool msg_lds)
+node_kernel_t node_pick_dv(int dv, int threads, int msg)
 {
-    if (dv <= 4) return node_pick_threads<DC, 4, LLR>(threads, msg_lds);
-    return node_pick_threads<DC, 16, LLR>(threads, msg_lds);
+    if (dv <= 4) return node_pick_threads<DC, 4, LLR>(threads, msg);
+    return node_pick_threads<DC, 16, LLR>(threads, msg);
 }
 template <bool LLR>
-node_kernel_t node_pick_dc(int dc, int dv, int threads, bool msg_lds)
+node_kernel_t node_pick_dc(int dc, int dv, int threads, int msg)
 {
-    if (dc <= 8) return node_pick_dv<8, LLR>(dv, threads, msg_lds);
-    if (dc <= 16) return node_pick_dv<16, LLR>(dv, threads, msg_lds);
-    return node_pick_dv<32, LLR>(dv, threads, msg_lds);
+    if (dc <= 8) return node_pick_dv<8, LLR>(dv, threads, msg);
+    if (dc <= 16) return node_pick_dv<16, LLR>(dv, threads, msg);
+    return node_pick_dv<32, LLR>(dv, threads, msg);
 }
 
 }  // namespace
 
-node_kernel_t pick_node_kernel(int dc, int dv, bool llr, int threads, bool msg_lds)
+node_kernel_t pick_node_kernel(int dc, int dv, bool llr, int threads, int msg)
 {
-    return llr ? node_pick_dc<true>(dc, dv, threads, msg_lds) : node_pick_dc<false>(dc, dv, threads, msg_lds);
+    return llr ? node_pick_dc<true>(dc, dv, threads, msg) : node_pick_dc<false>(dc, dv, threads, msg);
 }
 
 }  // namespace ldpc
