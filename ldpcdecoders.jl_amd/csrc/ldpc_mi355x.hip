@@ -496,10 +496,12 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     if (const char *e = std::getenv("LDPC_NODE_MSG_LDS")) d->node_msg_lds = d->node_msg_lds && std::atoi(e) != 0;
     if (d->node_ok && !d->node_msg_lds && !(std::getenv("LDPC_NODE_HYBRID") && std::atoi(std::getenv("LDPC_NODE_HYBRID")) == 0)) {
         // hybrid: as many leading checks as fit keep their messages in LDS
-        const size_t room = (size_t)160 * 1024 - 1024 - node_lds_bytes((int)s, (int)n);
+        size_t room = (size_t)160 * 1024 - 1024 - node_lds_bytes((int)s, (int)n);
+        const char *room_env = std::getenv("LDPC_NODE_LDS_ROOM");   // tests: bytes of LDS the messages may take
+        if (room_env) room = std::min(room, (size_t)std::atoll(room_env));
         int64_t k = 0;
         while (k < s && (size_t)row_ptr[(size_t)k + 1] * sizeof(double) <= room) ++k;
-        if (k > 0 && (size_t)row_ptr[(size_t)k] * sizeof(double) >= (size_t)16 * 1024) {
+        if (k > 0 && (room_env || (size_t)row_ptr[(size_t)k] * sizeof(double) >= (size_t)16 * 1024)) {
             d->node_split_check = (int)k;
             d->node_split_edge = row_ptr[(size_t)k];
         }

@@ -52,6 +52,17 @@ while time.time() - t0 < budget:
     oc = BPOracle(csc=(H.indptr, H.indices), shape=H.shape, per=per, max_iters=iters)
     oerr, oconv, ollr, oits = oc.batchdecode(syn)
     for variant in (0, 1, 3, 4):
+        # node kernel: messages in LDS (default for these small graphs), split between LDS and the global slot
+        # at a random point (hybrid), or all in the global slot
+        for k in ("LDPC_NODE_MSG_LDS", "LDPC_NODE_HYBRID", "LDPC_NODE_LDS_ROOM"):
+            os.environ.pop(k, None)
+        place = int(rng.integers(0, 3)) if variant == 3 else 0
+        if place >= 1:
+            os.environ["LDPC_NODE_MSG_LDS"] = "0"
+        if place == 1:
+            os.environ["LDPC_NODE_LDS_ROOM"] = str(int(rng.integers(8, max(9, 8 * H.nnz))))
+        if place == 2:
+            os.environ["LDPC_NODE_HYBRID"] = "0"
         kw = dict(kernel_variant=variant, waves_per_tile=0 if variant == 4 else int(rng.choice([0, 4, 8, 16])),
                   defer_threshold=int(rng.choice([0, -1, 4, 40])))
         if variant != 4 and rng.random() < 0.3:
