@@ -413,7 +413,7 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
             tk_check += t1 - t0; tk_var += t2 - t1; tk_conv += t3 - t2;
             // few stragglers left: hand them to the second pass instead of sweeping a nearly empty tile
             if (p.defer_thresh != 0 && active != 0 && it >= p.defer_min_iter && it <= p.defer_max_iter && it < p.max_iters &&
-                __popcll(active) <= p.defer_thresh) {
+                (int)__popcll(active) <= p.defer_thresh) {
                 if (w == 0) {
                     unsigned base = 0;
                     if (lane == 0) base = atomicAdd(p.defer_count, (unsigned)__popcll(active));

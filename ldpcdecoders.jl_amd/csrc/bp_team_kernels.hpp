@@ -122,10 +122,10 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     // Workgroups are dealt round-robin over the 8 XCDs (observed, not promised): blocks b and b + 8 share
     // one.  Teams are formed among the blocks of one residue class, so that normally a team sits on ONE
     // XCD; the members check it (xccs) and fall back to full release / acquire barriers if it is not so.
-    const int q = (int)(blockIdx.x >> 3), xslot = (int)(blockIdx.x & 7u);   // gridDim.x == 8 * G * ceil(ntiles / 8)
-    const int tile = tp.scatter ? (int)(blockIdx.x / (unsigned)G) : (q / G) * 8 + xslot;
-    const int rank = tp.scatter ? (int)(blockIdx.x % (unsigned)G) : q % G;
-    if (tile >= ntiles || (p.count_dev && q >= G * ((ntiles + 7) / 8))) return;   // whole teams only: nobody waits for these
+    const int bq = (int)(blockIdx.x >> 3), xslot = (int)(blockIdx.x & 7u);   // gridDim.x == 8 * G * ceil(ntiles / 8)
+    const int tile = tp.scatter ? (int)(blockIdx.x / (unsigned)G) : (bq / G) * 8 + xslot;
+    const int rank = tp.scatter ? (int)(blockIdx.x % (unsigned)G) : bq % G;
+    if (tile >= ntiles || (p.count_dev && bq >= G * ((ntiles + 7) / 8))) return;   // whole teams only: nobody waits for these
     const int gw = rank * W + w, GW = G * W;                   // this wave among the team's waves
     double *const Mt = p.msg + (size_t)tile * (size_t)p.slot_stride + lane;
     unsigned int *const ctr = tp.ctl + (size_t)tile * kTeamCtlWords;
@@ -212,10 +212,10 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
         if (lane == 0) sh_mism[w] = mism;
         __syncthreads();
         if (threadIdx.x == 0) {
-            u64 U = 0;
+            u64 part = 0;
 #pragma unroll
-            for (int q = 0; q < W; ++q) U |= sh_mism[q];
-            if (U) __hip_atomic_fetch_or(&mw[it - 1], U, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int q = 0; q < W; ++q) part |= sh_mism[q];
+            if (part) __hip_atomic_fetch_or(&mw[it - 1], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, &sh_ok, one_xcd)) return;
         const u64 U = never | __hip_atomic_load(&mw[it - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -226,7 +226,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
         tk_check += t1 - t0; tk_var += t3 - t2; tk_rest += (t2 - t1) + (t4 - t3);   // rest = barriers + test
         // few stragglers left: hand them to the second pass (decided alike by every member; rank 0 files them)
         if (p.defer_thresh != 0 && active != 0 && it >= p.defer_min_iter && it <= p.defer_max_iter && it < p.max_iters &&
-            __popcll(active) <= p.defer_thresh) {
+            (int)__popcll(active) <= p.defer_thresh) {
             if (rank == 0 && w == 0) {
                 unsigned base = 0;
                 if (lane == 0) base = atomicAdd(p.defer_count, (unsigned)__popcll(active));
