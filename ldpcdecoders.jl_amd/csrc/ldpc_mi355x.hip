@@ -912,7 +912,11 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         tp.fault = d->team_fault_dev;
         static const int always_release = std::getenv("LDPC_TEAM_ALWAYS_RELEASE") ? 1 : 0;
         tp.always_release = always_release;
-        tp.scatter = std::getenv("LDPC_TEAM_SCATTER") ? 1 : 0;   // (read per call: a test switches it on and off)
+        // fewer than 8 tiles: a team inside one XCD would be bound by that XCD's share of the bandwidth (1.1 TB/s);
+        // dealt over all XCDs its sweeps run 1.4x faster and the barriers (now with the L2 write-back) twice as
+        // long -- 6.1 -> 5.4 ms for 64 syndromes of the C3 code, all 50 iterations.  (The environment switch is
+        // read per call: a test turns it on and off.)
+        tp.scatter = (std::getenv("LDPC_TEAM_SCATTER") || ntiles <= 4) ? 1 : 0;
         tp.count_max = 0;
         team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr);
         HIP_TRY(hipEventRecord(ev[1], stream));
