@@ -126,6 +126,7 @@ struct ldpc_bp_decoder {
     DevBuf team_ws, team_ws2;   // control blocks of the first-pass / second-pass team kernel
     unsigned int *team_fault = nullptr, *team_fault_dev = nullptr;
     int team_max = 32;        // workgroups per tile at most (LDPC_TEAM_MAX; 1 = team kernel off)
+    bool team_max_set = false;   // ... given by the environment: no automatic 64 for batches of <= 4 tiles
     // latency mode of the host-pointer entry (tiny batches, a plain decode!): the kernel reads and writes a
     // host-mapped staging image and raises a flag in it; no copies, no events, no stream synchronisation
     DevBuf done_ctr;          // one device word, zero between launches
@@ -464,7 +465,7 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
         for (int &v : row) v = -1;
     d->variant = options ? options->kernel_variant : 0;
     if (d->variant < 0 || d->variant > 4) { delete d; return fail(LDPC_ERR_INVALID_ARGUMENT, "kernel_variant must be 0 ... 4"); }
-    if (const char *e = std::getenv("LDPC_TEAM_MAX")) d->team_max = std::max(1, std::min(64, std::atoi(e)));
+    if (const char *e = std::getenv("LDPC_TEAM_MAX")) { d->team_max = std::max(1, std::min(64, std::atoi(e))); d->team_max_set = true; }
     {
         void *fp = nullptr, *fd = nullptr;
         if (hipHostMalloc(&fp, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
@@ -612,6 +613,12 @@ static int team_size(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
     if (ntiles < 1 || ntiles > d->num_cus) return 1;
     const int64_t teams_per_xcd = (ntiles + 7) / 8;
     int64_t team = std::min<int64_t>(gcap, (int64_t)per_xcd / teams_per_xcd);
+    if (ntiles <= 4 && !d->team_max_set) {
+        // dealt over all 8 XCDs (scatter mode of the kernel): larger teams pay -- one tile of the C3 code, 50
+        // iterations: 32 members 5.4 ms, 48: 4.3 ms, 64: 3.4 ms (a member still has >= 1024 message rows per sweep)
+        const int64_t cap = std::min<int64_t>(64, std::max<int64_t>(gcap, d->nnz / 1024));
+        team = std::min<int64_t>(cap, (int64_t)8 * per_xcd / ntiles);
+    }
     if ((size_t)ntiles * ((size_t)d->max_iters + 32) * sizeof(u64) > ((size_t)16 << 20)) team = 1;
     return team < 3 ? 1 : (int)team;   // two workgroups per tile measured no better than the tile kernel's one of 16 waves
 }
@@ -622,17 +629,18 @@ static int team_size(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
 //                time, three times that once the message slots in flight outgrow the L2s (32 MiB); 1.07 ns
 //                for the edges whose messages the hybrid placement keeps in LDS;
 //   team kernel: 41 ns per edge for a tile at one CU's pace, divided among the G members, + ~45 us for the
-//                three team barriers.
+//                three team barriers (~30 us for the small teams-over-all-XCDs geometry of <= 4 tiles).
+// (A partial tile costs the team kernel as much as a full one, so below 64 syndromes this is a contest between
+// one syndrome per workgroup and up to 64 workgroups on one tile: n = 16384 and larger go to the team.)
 // Where the team kernel does not apply, the node kernel keeps the batches up to node_max_batch.
 static bool takes_node_kernel(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
 {
     if (takes_lds_kernel(d, want_llr) || !d->node_ok) return false;
     if (d->variant == 3) return true;
     if (d->variant != 0) return false;
-    if (batch < kTile) return true;
     if (d->node_msg_lds) return true;   // messages in LDS: not HBM-bound at any batch size (n = 4096)
     const int G = team_size(d, batch, want_llr);
-    if (G < 2) return batch <= d->node_max_batch;
+    if (G < 2) return batch < kTile || batch <= d->node_max_batch;
     const double edges = (double)d->nnz;
     const double rounds = (double)((batch + d->num_cus - 1) / d->num_cus);
     // hybrid placement: the share g of the messages that stays in global memory pays the address-path price, the
@@ -640,7 +648,7 @@ static bool takes_node_kernel(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
     const double g = d->node_split_check > 0 ? 1.0 - (double)d->node_split_edge / std::max(edges, 1.0) : 1.0;
     const double in_flight = (double)std::min<int64_t>(batch, 2 * (int64_t)d->num_cus) * edges * g * 8.0;
     const double est_node = rounds * (edges * (1.0 - g) * 1.07e-3 + edges * g * 1.9e-3 * (in_flight > 32.0 * 1048576.0 ? 3.0 : 1.0));
-    const double est_team = edges * 41e-3 / (double)G + 45.0;
+    const double est_team = edges * 41e-3 / (double)G + (batch <= 4 * kTile ? 30.0 : 45.0);   // (<= 4 tiles: dealt over all XCDs)
     return est_node < est_team;
 }
 
