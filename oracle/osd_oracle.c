@@ -161,7 +161,7 @@ void osd_oracle_postprocess(const uint8_t *H, int64_t m, int64_t n, const uint8_
                             const uint8_t *bp_err, const double *log_probabs, int64_t osd_order,
                             uint8_t *out)
 {
-    double *key = (double *)malloc(sizeof(double) * (size_t)(n ? n : 1));
+    double *key = (double *)calloc((size_t)(n ? n : 1), sizeof(double));
     int64_t *perm = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n ? n : 1));
     int64_t *tmp = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n ? n : 1));
     for (int64_t j = 0; j < n; ++j) {
