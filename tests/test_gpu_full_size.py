@@ -91,3 +91,28 @@ def test_c3_full_batch(ldpc, gpu, per, subset):
     assert np.array_equal(conv[tidx].cpu().numpy(), oconv)
     assert np.array_equal(its[tidx].cpu().numpy(), oits)
     assert np.array_equal(err[tidx].cpu().numpy(), oerr)
+
+
+@pytest.mark.parametrize("Bp", [(1, 0.06), (130, 0.07), (700, 0.06)])
+def test_c3_code_team_kernel_is_bit_identical_to_the_tile_kernel(ldpc, gpu, Bp):
+    """The C3 code at batches the team kernel takes -- one syndrome (64 workgroups on the one tile, dealt over
+    all XCDs), 3 tiles, 11 tiles (teams of 32 inside one XCD): tile kernel, team kernel and auto-dispatch agree
+    bit for bit, LLR bit patterns included (the oracle would need minutes for these)."""
+    B, per = Bp
+    H = ldpc.codes.parity_check_csc(N, WR, WC)
+    syn = torch.from_numpy(ldpc.codes.syndromes_of(H, ldpc.codes.random_errors(N, B, per, seed=B))).cuda()
+    res = {}
+    for variant in (1, 4, 0):
+        dec = ldpc.BeliefPropagationDecoder(H, per, ITERS, kernel_variant=variant)
+        err = torch.empty((B, N), dtype=torch.uint8, device="cuda")
+        conv = torch.empty(B, dtype=torch.uint8, device="cuda")
+        llr = torch.full((B, N), float("nan"), dtype=torch.float64, device="cuda")
+        its = torch.empty(B, dtype=torch.int32, device="cuda")
+        dec.decode_batch_device(syn, err, conv, llr, its)
+        torch.cuda.synchronize()
+        res[variant] = (err, conv, its, llr.view(torch.int64))
+        if variant != 1:
+            assert dec.info().last_kernel == 4 and dec.info().last_team_size >= 32
+        dec.close()
+    for v in (4, 0):
+        assert all(torch.equal(a, b) for a, b in zip(res[1], res[v]))
