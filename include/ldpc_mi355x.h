@@ -67,13 +67,16 @@ typedef struct ldpc_bp_options {
     int32_t device;           /* HIP device ordinal; -1 = current device */
     int32_t waves_per_tile;   /* 0 = auto (8; 16 when the batch has at most one tile per CU); else 4, 8, 16 */
     int32_t resident_tiles;   /* 0 = auto (fills the chip) */
-    int32_t kernel_variant;   /* 0 = auto (LDS-resident kernel when the edge messages fit the LDS; else the
-                                 node-parallel kernel -- one workgroup per syndrome -- for batches too small to
-                                 give every CU a 64-syndrome tile, and the HBM-streaming tile kernel above that);
-                                 in between -- up to one tile per CU -- the team kernel, several workgroups per tile);
-                                 1 = force streaming (one workgroup per tile); 2 = force LDS-resident;
-                                 3 = force node-parallel; 4 = team kernel wherever the batch has at most one tile per CU,
-                                 streaming otherwise (never LDS-resident / node-parallel) */
+    int32_t kernel_variant;   /* 0 = auto: LDS-resident kernel when the edge messages of >= 1 syndromes, the masks and
+                                 the graph fit a CU's LDS; node-parallel kernel (one workgroup per syndrome) when
+                                 only ONE syndrome's messages fit it, at every batch size; beyond that a cost
+                                 model picks between the node-parallel kernel and the team kernel (several
+                                 workgroups per 64-syndrome tile) while there are fewer tiles than CUs, and the
+                                 HBM-streaming tile kernel (one persistent workgroup per tile) takes the rest.
+                                 1 = force streaming; 2 = force LDS-resident (error if it does not fit);
+                                 3 = force node-parallel; 4 = team kernel wherever the batch has at most one tile
+                                 per CU, streaming otherwise (never LDS-resident / node-parallel).
+                                 ldpc_bp_info.last_kernel reports what ran */
     int32_t defer_threshold;  /* HBM-streaming kernel: a 64-syndrome tile hands its unconverged syndromes to a
                                  densely packed second pass once at most this many are left (same results,
                                  fewer nearly-empty sweeps).  0 = auto (16), -1 = off, else 1..48 */
