@@ -42,6 +42,7 @@ struct TeamParams {
     // only known on the device, so the geometry is worked out here -- G above is then the cap, and the
     // pass runs only for p.count_skip < *count_dev <= count_max (fewer: node kernel, more: packed tiles).
     unsigned int count_max;
+    int inject_fault;           // tests: raise the fault word and leave at once, as if a team barrier had timed out
 };
 
 // Team barrier number k (1, 2, ...).  Control block of a tile: arrival counter at word 0, XCC mask at word
@@ -110,6 +111,10 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     constexpr int W = THREADS / 64;
     const int s = p.s, n = p.n;
     const double r = p.r;
+    if (tp.inject_fault) {
+        if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(tp.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     int G = tp.G, ntiles = p.ntiles;
     long long batch = p.batch;
     if (p.count_dev) {                                         // second pass: sized on the device

@@ -926,6 +926,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         // read per call: a test turns it on and off.)
         tp.scatter = (std::getenv("LDPC_TEAM_SCATTER") || ntiles <= 4) ? 1 : 0;
         tp.count_max = 0;
+        tp.inject_fault = std::getenv("LDPC_TEAM_INJECT_FAULT") ? 1 : 0;   // (tests)
         team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr);
         HIP_TRY(hipEventRecord(ev[1], stream));
         // Cooperative launch: the runtime checks the grid against the kernel's residency and does not run
@@ -1002,6 +1003,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             tp.always_release = 0;
             tp.scatter = 0;
             tp.count_max = team2_cap;
+            tp.inject_fault = 0;
             team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr);
             const int *a_row = (const int *)d->row_ptr.p, *a_eb = (const int *)d->edge_bit.p, *a_col = (const int *)d->col_ptr.p,
                       *a_c2r = (const int *)d->csc2csr.p;
@@ -1076,8 +1078,26 @@ ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *d, int64_t batch, const
     return decode_device_impl(d, batch, d_syn, d_err, d_conv, d_llr, d_iters, stream_v, nullptr);
 }
 
+static ldpc_status decode_batch_host_impl(ldpc_bp_decoder *d, int64_t batch, const uint8_t *syn, uint8_t *err,
+                                          uint8_t *conv, double *llr, int32_t *iters);
+
 ldpc_status ldpc_bp_decode_batch(ldpc_bp_decoder *d, int64_t batch, const uint8_t *syn, uint8_t *err,
                                  uint8_t *conv, double *llr, int32_t *iters)
+{
+    ldpc_status st = decode_batch_host_impl(d, batch, syn, err, conv, llr, iters);
+    // This entry is synchronous, so a team that lost a workgroup (bp_team_kernels.hpp: bounded polls, fault
+    // word) is known by now: do not hand the caller garbage -- decode once more without teams, and keep them
+    // off for this decoder.  (The device entry cannot know yet; there the NEXT call reports it.)
+    if (st == LDPC_OK && d && d->team_fault && __atomic_load_n(d->team_fault, __ATOMIC_ACQUIRE) != 0u) {
+        __atomic_store_n(d->team_fault, 0u, __ATOMIC_RELEASE);
+        d->team_max = 1;
+        st = decode_batch_host_impl(d, batch, syn, err, conv, llr, iters);
+    }
+    return st;
+}
+
+static ldpc_status decode_batch_host_impl(ldpc_bp_decoder *d, int64_t batch, const uint8_t *syn, uint8_t *err,
+                                          uint8_t *conv, double *llr, int32_t *iters)
 {
     if (!d) return fail(LDPC_ERR_INVALID_ARGUMENT, "decoder is NULL");
     if (batch < 0) return fail(LDPC_ERR_INVALID_ARGUMENT, "negative batch");

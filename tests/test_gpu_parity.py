@@ -283,3 +283,35 @@ def test_degenerate_shapes(ldpc, gpu):
         syn = rng.integers(0, 2, (70, shape[0])).astype(np.uint8)
         for per in (0.1, 0.7):
             assert_parity(ldpc, H, per, 5, syn)
+
+
+def test_lost_team_is_reported_or_repaired_never_silent(ldpc, gpu, monkeypatch):
+    """A team barrier that times out raises a fault word (here injected): the synchronous host entry decodes
+    once more without teams and returns correct results; the asynchronous device entry reports the fault at
+    the next call on the handle."""
+    import torch
+
+    n = 4096
+    H = ldpc.codes.parity_check_csc(n, 8, 4)
+    syn = ldpc.codes.syndromes_of(H, ldpc.codes.random_errors(n, 700, 0.03, seed=9))
+    oc = BPOracle(csc=(H.indptr, H.indices), shape=H.shape, per=0.03, max_iters=30)
+    oerr, oconv, _, oits = oc.batchdecode(syn)
+    monkeypatch.setenv("LDPC_TEAM_INJECT_FAULT", "1")
+    dec = ldpc.BeliefPropagationDecoder(H, 0.03, 30, kernel_variant=4)
+    err, conv, _, its = dec.decode_batch_host(syn, want_iters=True)         # repaired inside the call
+    assert np.array_equal(err, oerr) and np.array_equal(conv, oconv) and np.array_equal(its, oits)
+    assert dec.info().last_kernel == 1                                       # teams are off for this decoder now
+    dec.close()
+    dec = ldpc.BeliefPropagationDecoder(H, 0.03, 30, kernel_variant=4)
+    d_syn = torch.from_numpy(syn).cuda()
+    d_err = torch.empty((700, n), dtype=torch.uint8, device="cuda")
+    d_conv = torch.empty(700, dtype=torch.uint8, device="cuda")
+    dec.decode_batch_device(d_syn, d_err, d_conv)                            # asynchronous: cannot know yet
+    torch.cuda.synchronize()
+    with pytest.raises(ldpc.LdpcError, match="lost a workgroup"):
+        dec.decode_batch_device(d_syn, d_err, d_conv)
+    monkeypatch.delenv("LDPC_TEAM_INJECT_FAULT")
+    dec.decode_batch_device(d_syn, d_err, d_conv)                            # the fault is cleared once reported
+    torch.cuda.synchronize()
+    assert np.array_equal(d_err.cpu().numpy(), oerr) and np.array_equal(d_conv.cpu().numpy(), oconv)
+    dec.close()
