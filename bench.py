@@ -272,6 +272,9 @@ def main():
                 "gpu_matches_oracle_on_sample": ok,
             }
         print(json.dumps(out), flush=True)
+    # explicit teardown, in this order, before the interpreter starts dismantling modules: the decoder handle
+    # (hipDeviceSynchronize + frees), then the process group
+    dec.close()
     if world > 1:
         dist.destroy_process_group()
 

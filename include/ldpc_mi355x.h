@@ -138,11 +138,29 @@ ldpc_status ldpc_bp_decode_batch(ldpc_bp_decoder *dec, int64_t batch, const uint
  * shards of INTEGRATION.md, and bench.py).  Work is enqueued on `stream`
  * (a hipStream_t passed as void*; NULL = the default stream) and is
  * asynchronous; outputs are valid once the stream has been synchronised.
+ * Calls on one handle share its workspace and therefore execute in call
+ * order: a call given another stream than its predecessor waits (on the
+ * device) for that predecessor first.  ldpc_bp_last_status() tells whether
+ * the asynchronous work went well.
  */
 ldpc_status ldpc_bp_decode_batch_device(ldpc_bp_decoder *dec, int64_t batch,
                                         const uint8_t *d_syndromes, uint8_t *d_errors,
                                         uint8_t *d_converged, double *d_llr, int32_t *d_iters,
                                         void *stream);
+
+/*
+ * Was everything enqueued on this handle so far good?  Waits for the most recent
+ * ldpc_bp_decode_batch_device call (and with it every earlier one: calls on a handle run in call
+ * order, whatever streams they were given) and returns LDPC_OK, or LDPC_ERR_HIP if a team of
+ * workgroups lost a member during one of them (a team barrier timed out after ~10 s; the team
+ * kernel serves medium batches on large codes).  ldpc_last_error() then names the first call hit;
+ * the outputs of that call and of every team-kernel call enqueued after it are invalid and must be
+ * decoded again -- the decoder keeps teams off from then on, so the retry cannot fail the same way.
+ * The fault is reported exactly once: by this function, or by the next
+ * ldpc_bp_decode_batch_device call on the handle (which then enqueues nothing), whichever comes
+ * first.  The host-buffer entry ldpc_bp_decode_batch is synchronous and repairs such a call itself.
+ */
+ldpc_status ldpc_bp_last_status(ldpc_bp_decoder *dec);
 
 /*
  * Timing of the most recent ldpc_bp_decode_batch[_device] call, taken with HIP

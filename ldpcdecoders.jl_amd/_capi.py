@@ -35,6 +35,7 @@ EXPORTED_SYMBOLS = (
     "ldpc_bp_get_info",
     "ldpc_bp_decode_batch",
     "ldpc_bp_decode_batch_device",
+    "ldpc_bp_last_status",
     "ldpc_bp_last_timing",
     "ldpc_bp_call_timing",
     "ldpc_bp_call_phase_ticks",
@@ -130,6 +131,8 @@ def lib() -> ctypes.CDLL:
     L.ldpc_bp_decode_batch.argtypes = [vp, i64, vp, vp, vp, vp, vp]
     L.ldpc_bp_decode_batch_device.restype = i32
     L.ldpc_bp_decode_batch_device.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
+    L.ldpc_bp_last_status.restype = i32
+    L.ldpc_bp_last_status.argtypes = [vp]
     L.ldpc_bp_last_timing.restype = i32
     L.ldpc_bp_last_timing.argtypes = [vp, ctypes.POINTER(f64), ctypes.POINTER(f64), ctypes.POINTER(i64)]
     L.ldpc_bp_call_timing.restype = i32

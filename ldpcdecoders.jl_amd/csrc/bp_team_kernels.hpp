@@ -43,6 +43,8 @@ struct TeamParams {
     // pass runs only for p.count_skip < *count_dev <= count_max (fewer: node kernel, more: packed tiles).
     unsigned int count_max;
     int inject_fault;           // tests: raise the fault word and leave at once, as if a team barrier had timed out
+    unsigned int ticket;        // what a timed-out barrier writes into the fault word: the number of this call on its
+                                // handle (never 0), so that the report can name the first call that was hit
 };
 
 // Team barrier number k (1, 2, ...).  Control block of a tile: arrival counter at word 0, XCC mask at word
@@ -57,7 +59,7 @@ struct TeamParams {
 constexpr int kTeamCtlWords = 32 * (2 + 64);   // per tile: counter line, XCC line, up to 64 member lines
 
 __device__ __forceinline__ bool team_barrier(unsigned int *ctl, int G, int rank, unsigned int k, unsigned int *fault,
-                                             int *sh_ok, bool one_xcd)
+                                             unsigned int ticket, int *sh_ok, bool one_xcd)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its own stores
     __syncthreads();
@@ -82,7 +84,7 @@ __device__ __forceinline__ bool team_barrier(unsigned int *ctl, int G, int rank,
                 if ((++polls & 255u) == 0u) {
                     if (__hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) { ok = 0; break; }
                     if (wall_clock64() - t0 > 1000000000ull) {   // 10 s of the 100 MHz clock
-                        __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_store(fault, ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         ok = 0;
                         break;
                     }
@@ -112,7 +114,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     const int s = p.s, n = p.n;
     const double r = p.r;
     if (tp.inject_fault) {
-        if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(tp.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(tp.fault, tp.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
     int G = tp.G, ntiles = p.ntiles;
@@ -169,7 +171,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
             else check_update<DC, false>(Mt + (size_t)e0 * kTile, deg, sigma, r);
         }
         const u64 t1 = wall_clock64();
-        if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, &sh_ok, one_xcd)) return;
+        if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd)) return;
         if (first) {
             if (threadIdx.x == 0)
                 sh_one_xcd = __popc(__hip_atomic_load(xccs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 1;
@@ -195,7 +197,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
             }
         }
         const u64 t3 = wall_clock64();
-        if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, &sh_ok, one_xcd)) return;
+        if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd)) return;
         // ---- convergence test (:180-184): lane = check, words = 64 syndromes; the team ORs into mw[it-1]
         u64 mism = 0;
         for (int i = gw * 64 + lane; i < s; i += GW * 64) {
@@ -222,7 +224,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
             for (int q = 0; q < W; ++q) part |= sh_mism[q];
             if (part) __hip_atomic_fetch_or(&mw[it - 1], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, &sh_ok, one_xcd)) return;
+        if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd)) return;
         const u64 U = never | __hip_atomic_load(&mw[it - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const u64 newly = active & ~U;
         if ((newly >> lane) & 1ull) { my_iters = it; my_conv = 1; }

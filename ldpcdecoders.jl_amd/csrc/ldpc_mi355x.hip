@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -172,6 +173,11 @@ struct ldpc_bp_decoder {
     bool two_events[kRing] = {};   // the call recorded ev[1] / ev[2] only (single-kernel paths)
     bool ctrl_clean[kRing] = {};   // the slot's 64 control bytes are known to be zero
     uint64_t ncalls = 0;
+    // Calls on one handle share its workspace, so they execute in call order whatever streams they are
+    // given: a call that arrives on another stream than its predecessor first waits for that one's last event.
+    hipStream_t last_stream = nullptr;
+    hipEvent_t last_ev = nullptr;  // one of ev[][] (not owned): completion of the most recent enqueued call
+    bool inject_fault = false;     // tests (LDPC_TEAM_INJECT_FAULT at create): team kernels raise the fault word at once
 
     ~ldpc_bp_decoder()
     {
@@ -465,6 +471,7 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
         for (int &v : row) v = -1;
     d->variant = options ? options->kernel_variant : 0;
     if (d->variant < 0 || d->variant > 4) { delete d; return fail(LDPC_ERR_INVALID_ARGUMENT, "kernel_variant must be 0 ... 4"); }
+    d->inject_fault = std::getenv("LDPC_TEAM_INJECT_FAULT") != nullptr;   // (tests)
     if (const char *e = std::getenv("LDPC_TEAM_MAX")) { d->team_max = std::max(1, std::min(64, std::atoi(e))); d->team_max_set = true; }
     {
         void *fp = nullptr, *fd = nullptr;
@@ -573,6 +580,42 @@ ldpc_status ldpc_bp_get_info(const ldpc_bp_decoder *d, ldpc_bp_info *info)
 
 }  // extern "C"
 
+// Launch of a team grid (bp_team_kernels.hpp): every member of a team must be resident at once, so
+//   * the host sizes the grid from the instantiation's occupancy (team_geometry(): at most that many
+//     workgroups per CU, with a margin where the registers admit more than one), and
+//   * no two team grids of this process run at the same time on one device: a team launch first makes its
+//     stream wait for the previous team grid's completion event and then records its own -- two decoders on
+//     two streams cannot leave each other's teams half resident.
+// That is what hipLaunchCooperativeKernel promises too, and the first version used it; but a process that has
+// made ONE cooperative launch crashes inside exit() under rocprofv3 (SIGSEGV in the runtime's exit handler
+// after the tool has finalised: profiles/README.md, round 2), and the launch costs 15-19 us more.  A plain
+// launch of the same grid has the same residency (MI355X_MICROARCH.md, "Residency and cooperative launch").
+// LDPC_TEAM_COOP_LAUNCH=1 brings the cooperative launch back (experiments).
+namespace {
+std::mutex g_team_mu;
+hipEvent_t g_team_ev[64] = {};   // per device: completion of the most recent team grid (process lifetime)
+}  // namespace
+
+static hipError_t launch_team_grid(ldpc_bp_decoder *d, team_kernel_t tk, int grid, void **args, hipStream_t stream)
+{
+    static const bool coop = std::getenv("LDPC_TEAM_COOP_LAUNCH") != nullptr;
+    if (coop) return hipLaunchCooperativeKernel((const void *)tk, dim3((unsigned)grid), dim3(512), args, 0, stream);
+    std::lock_guard<std::mutex> lk(g_team_mu);
+    hipEvent_t *gev = (d->device >= 0 && d->device < 64) ? &g_team_ev[d->device] : nullptr;
+    if (gev) {
+        if (!*gev) {
+            if (hipEventCreateWithFlags(gev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); *gev = nullptr; }
+        } else {
+            const hipError_t w = hipStreamWaitEvent(stream, *gev, 0);
+            if (w != hipSuccess) return w;
+        }
+    }
+    hipError_t e = hipLaunchKernel((const void *)tk, dim3((unsigned)grid), dim3(512), args, 0, stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess && gev && *gev) e = hipEventRecord(*gev, stream);
+    return e;
+}
+
 // Latency mode (see ldpc_bp_decoder::lat_pin): the word the last workgroup raises, and its value.
 struct LatencyCtl {
     unsigned int *flag;
@@ -652,6 +695,29 @@ static bool takes_node_kernel(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
     return est_node < est_team;
 }
 
+// A team barrier that timed out (bp_team_kernels.hpp) has written the number of its call into the host-mapped
+// fault word; every team grid enqueued since has seen the word and left without results.  Wait for everything
+// enqueued on the handle (no member may still be polling the word when it is cleared), clear it, keep teams off
+// for this decoder, and say which calls were hit.  LDPC_OK when nothing happened.
+static ldpc_status report_team_fault(ldpc_bp_decoder *d)
+{
+    if (!d->team_fault) return LDPC_OK;
+    const unsigned ticket = __atomic_load_n(d->team_fault, __ATOMIC_ACQUIRE);
+    if (ticket == 0u) return LDPC_OK;
+    if (d->last_ev) {
+        (void)hipSetDevice(d->device);
+        if (hipEventSynchronize(d->last_ev) != hipSuccess) (void)hipGetLastError();
+    }
+    __atomic_store_n(d->team_fault, 0u, __ATOMIC_RELEASE);
+    d->team_max = 1;
+    // the ticket holds the low 31 bits of the call number (counting from 1)
+    uint64_t first = (d->ncalls & ~(uint64_t)0x7fffffff) | (uint64_t)(ticket & 0x7fffffffu);
+    if (first > d->ncalls && first >= ((uint64_t)1 << 31)) first -= (uint64_t)1 << 31;
+    return fail(LDPC_ERR_HIP, "call #" + std::to_string(first) + " on this decoder lost a workgroup of a team (team barrier timed out): "
+                "the results of that call and of every team-kernel call enqueued after it (up to call #" + std::to_string(d->ncalls) +
+                ") are invalid; teams are off for this decoder from here on");
+}
+
 static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const uint8_t *d_syn,
                                       uint8_t *d_err, uint8_t *d_conv, double *d_llr, int32_t *d_iters,
                                       void *stream_v, const LatencyCtl *lat)
@@ -659,6 +725,18 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     if (!d) return fail(LDPC_ERR_INVALID_ARGUMENT, "decoder is NULL");
     if (batch < 0) return fail(LDPC_ERR_INVALID_ARGUMENT, "negative batch");
     hipStream_t stream = (hipStream_t)stream_v;
+    if (batch == 0) return LDPC_OK;
+    if ((d->s > 0 && !d_syn) || (d->n > 0 && !d_err) || !d_conv)
+        return fail(LDPC_ERR_INVALID_ARGUMENT, "syndromes/errors/converged pointer is NULL");
+    HIP_TRY(hipSetDevice(d->device));
+    const int64_t s = d->s, n = d->n;
+    {
+        const ldpc_status fst = report_team_fault(d);   // a refused call is not counted and enqueues nothing
+        if (fst != LDPC_OK) return fst;
+    }
+    // From here on the call has a number and a slot of the timing ring.  If a HIP call fails further down the
+    // function returns with the launches made so far enqueued (they only touch this call's own buffers and the
+    // handle's workspace), the slot consumed and `timed` false: ldpc_bp_call_timing reports zeros for it.
     const int slot = (int)(d->ncalls++ % ldpc_bp_decoder::kRing);
     hipEvent_t *ev = d->ev[slot];
     char *ctrl = (char *)d->ctrl.p + 64 * slot;
@@ -669,15 +747,11 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     // 4096: fill kernel 3.5 us + ~10 us of dependency gap on either side of a 94 us decode kernel)
     const int nslot = (slot + 1) % ldpc_bp_decoder::kRing;
     char *next_ctrl = (char *)d->ctrl.p + 64 * nslot;
-    if (batch == 0) return LDPC_OK;
-    if ((d->s > 0 && !d_syn) || (d->n > 0 && !d_err) || !d_conv)
-        return fail(LDPC_ERR_INVALID_ARGUMENT, "syndromes/errors/converged pointer is NULL");
-    HIP_TRY(hipSetDevice(d->device));
-    const int64_t s = d->s, n = d->n;
-    if (d->team_fault && __atomic_load_n(d->team_fault, __ATOMIC_ACQUIRE) != 0u) {
-        __atomic_store_n(d->team_fault, 0u, __ATOMIC_RELEASE);
-        return fail(LDPC_ERR_HIP, "an earlier call on this decoder lost a workgroup of a team (team barrier timed out); its results are invalid");
-    }
+    // Calls on one handle execute in call order whatever streams they are given (they share its workspace and
+    // its control slots -- a kernel of call N zeroes the slot of call N+1): a call that arrives on another
+    // stream than its predecessor waits for that one's last event first.
+    if (d->last_ev && d->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, d->last_ev, 0));
+    d->last_stream = stream;
 
     if (d->max_iters == 0) {
         // the loop at belief_propagation.jl:134 never runs: err = 0, log_probabs = 0, converged = false
@@ -740,6 +814,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         d->timed[nslot] = false;
         d->timed[slot] = true;
         d->two_events[slot] = true;
+        d->last_ev = ev[2];
         return LDPC_OK;
     }
 
@@ -795,6 +870,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         d->timed[nslot] = false;
         d->two_events[slot] = true;
         d->timed[slot] = true;
+        d->last_ev = ev[2];
         d->last_threads = nthreads; d->last_grid = ngrid;
         return LDPC_OK;
     }
@@ -841,7 +917,14 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     // an empty graph -- go to the tile kernel)
     if (team > 1) { threads = 512; grid = ntiles; }
     d->last_threads = threads;
-    const int team_grid = team > 1 ? 8 * team * ((ntiles + 7) / 8) : 0;
+    // fewer than 8 tiles: a team inside one XCD would be bound by that XCD's share of the bandwidth (1.1 TB/s);
+    // dealt over all XCDs (scatter mode: tile = block / G) its sweeps run 1.4x faster and the barriers (now with
+    // the L2 write-back) twice as long -- 6.1 -> 5.4 ms for 64 syndromes of the C3 code, all 50 iterations.
+    // (The environment switch is read per call: a test turns it on and off.)
+    const bool team_scatter = team > 1 && (std::getenv("LDPC_TEAM_SCATTER") || ntiles <= 4);
+    // scatter mode launches exactly the members (8 * team blocks for <= 4 tiles would be up to 512 workgroups,
+    // more than the wide-degree instantiations can keep resident: one 8-wave workgroup per CU)
+    const int team_grid = team > 1 ? (team_scatter ? ntiles * team : 8 * team * ((ntiles + 7) / 8)) : 0;
     d->last_grid = team > 1 ? team_grid : grid;
     d->last_kernel = team > 1 ? 4 : 1;
     d->last_team = team;
@@ -906,6 +989,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     p.count_dev = nullptr;
     p.count_skip = 0;
     bp_kernel_t kfn = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, threads);
+    bool team_ran = team > 1;
     if (team > 1) {
         const size_t ctl_bytes = (size_t)ntiles * kTeamCtlWords * sizeof(unsigned int);
         const size_t mism_stride = ((size_t)d->max_iters + 31) & ~(size_t)31;
@@ -920,22 +1004,25 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         tp.fault = d->team_fault_dev;
         static const int always_release = std::getenv("LDPC_TEAM_ALWAYS_RELEASE") ? 1 : 0;
         tp.always_release = always_release;
-        // fewer than 8 tiles: a team inside one XCD would be bound by that XCD's share of the bandwidth (1.1 TB/s);
-        // dealt over all XCDs its sweeps run 1.4x faster and the barriers (now with the L2 write-back) twice as
-        // long -- 6.1 -> 5.4 ms for 64 syndromes of the C3 code, all 50 iterations.  (The environment switch is
-        // read per call: a test turns it on and off.)
-        tp.scatter = (std::getenv("LDPC_TEAM_SCATTER") || ntiles <= 4) ? 1 : 0;
+        tp.scatter = team_scatter ? 1 : 0;
         tp.count_max = 0;
-        tp.inject_fault = std::getenv("LDPC_TEAM_INJECT_FAULT") ? 1 : 0;   // (tests)
+        tp.inject_fault = d->inject_fault ? 1 : 0;   // (tests)
+        tp.ticket = (unsigned)(d->ncalls & 0x7fffffffu) ? (unsigned)(d->ncalls & 0x7fffffffu) : 0x7fffffffu;
         team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr);
         HIP_TRY(hipEventRecord(ev[1], stream));
-        // Cooperative launch: the runtime checks the grid against the kernel's residency and does not run
-        // two cooperative grids at once, so two decoders on two streams cannot starve each other's teams.
         const int *a_row = (const int *)d->row_ptr.p, *a_eb = (const int *)d->edge_bit.p, *a_col = (const int *)d->col_ptr.p,
                   *a_c2r = (const int *)d->csc2csr.p;
         const u64 *a_syn = (const u64 *)d->synmask.p, *a_nev = (const u64 *)d->nevermask.p;
         void *args[] = {&p, &tp, &a_row, &a_eb, &a_col, &a_c2r, &a_syn, &a_nev};
-        HIP_TRY(hipLaunchCooperativeKernel((const void *)tk, dim3((unsigned)team_grid), dim3(512), args, 0, stream));
+        const hipError_t te = launch_team_grid(d, tk, team_grid, args, stream);
+        if (te != hipSuccess) {
+            // a team grid the runtime refuses must not fail the call: the tile kernel decodes the batch (one
+            // workgroup per tile, same results), and teams stay off for this decoder
+            (void)hipGetLastError();
+            d->team_max = 1;
+            d->last_kernel = 1; d->last_team = 1; d->last_grid = grid;
+            team_ran = false;
+        }
         if (std::getenv("LDPC_TEAM_DEBUG")) {   // diagnostics: which XCDs did the teams land on?
             std::vector<unsigned> xm((size_t)ntiles);
             (void)hipStreamSynchronize(stream);
@@ -946,8 +1033,9 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             std::fprintf(stderr, "[ldpc] team kernel: %d tiles x %d workgroups, grid %d; %d teams on one XCD (first masks %x %x %x)\n",
                          ntiles, team, team_grid, single, xm[0], ntiles > 1 ? xm[1] : 0u, ntiles > 2 ? xm[2] : 0u);
         }
-    } else {
-        HIP_TRY(hipEventRecord(ev[1], stream));
+    }
+    if (!team_ran) {
+        if (team <= 1) HIP_TRY(hipEventRecord(ev[1], stream));
         hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3((unsigned)threads), 0, stream, p,
                            (const int *)d->row_ptr.p, (const int *)d->edge_bit.p, (const int *)d->col_ptr.p,
                            (const int *)d->csc2csr.p, (const u64 *)d->synmask.p, (const u64 *)d->nevermask.p);
@@ -1004,12 +1092,13 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             tp.scatter = 0;
             tp.count_max = team2_cap;
             tp.inject_fault = 0;
+            tp.ticket = (unsigned)(d->ncalls & 0x7fffffffu) ? (unsigned)(d->ncalls & 0x7fffffffu) : 0x7fffffffu;
             team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr);
             const int *a_row = (const int *)d->row_ptr.p, *a_eb = (const int *)d->edge_bit.p, *a_col = (const int *)d->col_ptr.p,
                       *a_c2r = (const int *)d->csc2csr.p;
             const u64 *a_syn = (const u64 *)d->synmask2.p, *a_nev = (const u64 *)d->nevermask2.p;
             void *args[] = {&p3, &tp, &a_row, &a_eb, &a_col, &a_c2r, &a_syn, &a_nev};
-            HIP_TRY(hipLaunchCooperativeKernel((const void *)tk, dim3((unsigned)(8 * t2_per_xcd)), dim3(512), args, 0, stream));
+            HIP_TRY(launch_team_grid(d, tk, 8 * t2_per_xcd, args, stream));
         }
     }
     HIP_TRY(hipEventRecord(ev[2], stream));
@@ -1066,6 +1155,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     }
     HIP_TRY(hipEventRecord(ev[3], stream));
     d->timed[slot] = true;
+    d->last_ev = ev[3];
     return LDPC_OK;
 }
 
@@ -1088,11 +1178,8 @@ ldpc_status ldpc_bp_decode_batch(ldpc_bp_decoder *d, int64_t batch, const uint8_
     // This entry is synchronous, so a team that lost a workgroup (bp_team_kernels.hpp: bounded polls, fault
     // word) is known by now: do not hand the caller garbage -- decode once more without teams, and keep them
     // off for this decoder.  (The device entry cannot know yet; there the NEXT call reports it.)
-    if (st == LDPC_OK && d && d->team_fault && __atomic_load_n(d->team_fault, __ATOMIC_ACQUIRE) != 0u) {
-        __atomic_store_n(d->team_fault, 0u, __ATOMIC_RELEASE);
-        d->team_max = 1;
+    if (st == LDPC_OK && d && report_team_fault(d) != LDPC_OK)   // (clears the word, turns teams off)
         st = decode_batch_host_impl(d, batch, syn, err, conv, llr, iters);
-    }
     return st;
 }
 
@@ -1263,6 +1350,14 @@ static ldpc_status decode_batch_host_impl(ldpc_bp_decoder *d, int64_t batch, con
         }
         return pst;
     }
+}
+
+ldpc_status ldpc_bp_last_status(ldpc_bp_decoder *d)
+{
+    if (!d) return fail(LDPC_ERR_INVALID_ARGUMENT, "decoder is NULL");
+    HIP_TRY(hipSetDevice(d->device));
+    if (d->last_ev) HIP_TRY(hipEventSynchronize(d->last_ev));
+    return report_team_fault(d);
 }
 
 ldpc_status ldpc_bp_call_timing(ldpc_bp_decoder *d, int32_t calls_back, double *sweep_ms, double *total_ms,

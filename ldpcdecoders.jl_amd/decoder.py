@@ -141,6 +141,11 @@ class BeliefPropagationDecoder(AbstractDecoder):
         _capi.check(_capi.lib().ldpc_bp_get_info(self._h, ctypes.byref(info)))
         return info
 
+    def last_status(self) -> None:
+        """Wait for everything enqueued on the handle and raise LdpcError if a team of workgroups lost a
+        member in one of those calls (ldpc_bp_last_status): their outputs must then be decoded again."""
+        _capi.check(_capi.lib().ldpc_bp_last_status(self._h))
+
     def last_timing(self, calls_back: int = 0) -> Tuple[float, float, int]:
         """(sweep_ms, total_ms, sum_iters) of a recent batch call (0 = the latest), from HIP
         events recorded on the stream the kernels ran on."""
