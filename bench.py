@@ -88,7 +88,7 @@ def make_syndromes(torch, H_csr, n, batch, per, seed, device):
     return syn
 
 
-def cpu_baseline(H, per, max_iters, syn_sample, gpu_err, gpu_conv, budget_s=20.0):
+def cpu_baseline_dense(H, per, max_iters, syn_sample, gpu_err, gpu_conv, budget_s=12.0):
     """Oracle in reference-faithful DENSE mode (two dense s x n Float64 matrices, full reset
     per decode, strided access: the cost structure of belief_propagation.jl:83-91,121-188),
     single thread like the reference.  Also re-checks the GPU result on the sample."""
@@ -106,6 +106,36 @@ def cpu_baseline(H, per, max_iters, syn_sample, gpu_err, gpu_conv, budget_s=20.0
     return done / dt, done, ok
 
 
+def cpu_baseline_edge_list(H, per, max_iters, syn_sample, gpu_err, gpu_conv, gpu_iters, threads, budget_s=20.0):
+    """The same arithmetic on the structural non-zeros only (the strongest honest CPU figure: no dense
+    reset!, no strided access), one oracle decoder per host thread (the reference decoder is not
+    re-entrant; the C code runs without the GIL).  Every decoded syndrome is compared with the GPU's
+    hard decisions, flag and iteration count."""
+    import concurrent.futures as cf
+
+    from oracle import BPOracle
+
+    def work(idx):
+        oc = BPOracle(csc=(H.indptr, H.indices), shape=H.shape, per=per, max_iters=max_iters)
+        t0, done, ok = time.perf_counter(), 0, True
+        for b0 in range(0, len(idx), 16):
+            sl = idx[b0:b0 + 16]
+            err, conv, _, its = oc.batchdecode(syn_sample[sl], want_llr=False)
+            ok = ok and np.array_equal(err, gpu_err[sl]) and np.array_equal(conv, gpu_conv[sl]) and np.array_equal(its, gpu_iters[sl])
+            done += len(sl)
+            if time.perf_counter() - t0 > budget_s:
+                break
+        return done, ok
+
+    chunks = np.array_split(np.arange(syn_sample.shape[0]), threads)
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(threads) as ex:
+        res = list(ex.map(work, chunks))
+    wall = time.perf_counter() - t0
+    done = sum(r[0] for r in res)
+    return done / wall, done, all(r[1] for r in res)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,16 +144,23 @@ def main():
     ap.add_argument("--workload", default="c3_full50", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="syndromes per GPU (default: the workload's)")
     ap.add_argument("--per", type=float, default=0.0, help="physical error rate (default: the workload's)")
+    ap.add_argument("--mode", default="auto", choices=["auto", "scatter", "replicas"],
+                    help="scatter (default): BASELINE config 4 as worded -- rank 0 holds the whole N x batch matrix in HBM, "
+                         "ldpcdecoders.jl_amd.sharding scatters the shards over RCCL, every rank decodes, the root gathers; "
+                         "N = 1 is the degenerate case of the same code.  replicas: every rank decodes a shard of its own, "
+                         "no exchange (round 1's mode)")
+    ap.add_argument("--verify", action="store_true",
+                    help="scatter mode: after the timed steps the root decodes every shard once more by itself and compares")
     ap.add_argument("--waves-per-tile", type=int, default=0)
     ap.add_argument("--resident-tiles", type=int, default=0)
     ap.add_argument("--kernel-variant", type=int, default=0, help="0 auto, 1 HBM-streaming, 2 LDS-resident, 3 node-parallel, 4 team")
     ap.add_argument("--defer-threshold", type=int, default=0, help="0 auto (16), -1 off (streaming kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    # rehearsal of the N>1 control flow on a box with fewer GPUs than ranks (never used by the driver):
     ap.add_argument("--prealloc-gib", type=float, default=0.0,
                     help="experiment: hold this much HBM before anything else is allocated (shifts physical placement)")
+    # rehearsal of the N>1 control flow on a box with fewer GPUs than ranks (never used by the driver):
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
-                    help="all ranks share cuda:0 and synchronise over gloo instead of RCCL")
+                    help="all ranks share cuda:0; the exchange runs over gloo with the shards staged through the host instead of RCCL")
     args = ap.parse_args()
 
     import torch
@@ -145,6 +182,7 @@ def main():
             dist.init_process_group("nccl", device_id=device)   # RCCL over xGMI
 
     import ldpcdecoders_jl_amd as ldpc
+    from ldpcdecoders_jl_amd import sharding
 
     hold = torch.empty(int(args.prealloc_gib * (1 << 30)), dtype=torch.uint8, device=device) if args.prealloc_gib > 0 else None
     n, wr, wc, batch, per, max_iters = WORKLOADS[args.workload]
@@ -152,7 +190,13 @@ def main():
         batch = args.batch
     if args.per > 0:
         per = args.per
-    if args.workload == "c5_bb72_bposd":
+    bposd_workload = args.workload == "c5_bb72_bposd"
+    mode = args.mode
+    if mode == "auto":
+        mode = "replicas" if bposd_workload else "scatter"
+    if bposd_workload and mode == "scatter":
+        raise SystemExit("the BP+OSD workload has a host step per rank: use --mode replicas")
+    if bposd_workload:
         import scipy.sparse as sp
 
         H = sp.csc_matrix(ldpc.codes.bivariate_bicycle_72_12_6()[0])
@@ -160,19 +204,35 @@ def main():
     else:
         H = ldpc.codes.parity_check_csc(n, wr, wc)
     nnz = int(H.nnz)
+    s_checks = int(H.shape[0])
     dec = ldpc.BeliefPropagationDecoder(H, per, max_iters, device=local_rank,
                                         waves_per_tile=args.waves_per_tile, resident_tiles=args.resident_tiles,
                                         kernel_variant=args.kernel_variant, defer_threshold=args.defer_threshold)
-    syn = make_syndromes(torch, H.tocsr(), n, batch, per, seed=1234 + rank, device=device)
-    err = torch.empty((batch, n), dtype=torch.uint8, device=device)
-    conv = torch.empty(batch, dtype=torch.uint8, device=device)
-    iters = torch.empty(batch, dtype=torch.int32, device=device)
+    # Synthetic data: shard g of the job is Bernoulli(per) errors from seed 1234 + g.  scatter mode: the root holds
+    # all N shards as ONE caller-owned matrix (belief_propagation.jl:220: one `syndromes`, columns independent).
+    Hcsr = H.tocsr()
+    if mode == "scatter":
+        syn = None
+        if rank == 0:
+            syn = torch.empty((batch * world, s_checks), dtype=torch.uint8, device=device)
+            for g in range(world):
+                syn[g * batch:(g + 1) * batch] = make_syndromes(torch, Hcsr, n, batch, per, seed=1234 + g, device=device)
+        err = conv = iters = None
+    else:
+        syn = make_syndromes(torch, Hcsr, n, batch, per, seed=1234 + rank, device=device)
+        err = torch.empty((batch, n), dtype=torch.uint8, device=device)
+        conv = torch.empty(batch, dtype=torch.uint8, device=device)
+        iters = torch.empty(batch, dtype=torch.int32, device=device)
 
     osd_sent = [0]
     device_calls = [0]   # library calls made by the timed steps (1 per step unless noted)
-    if args.workload == "c5_bb72_bposd":
+    phases = []          # scatter mode: per timed step {scatter_ms, decode_ms, gather_ms} of this rank
+    result = [None]
+    bposd = None
+    if bposd_workload:
         bposd = ldpc.BeliefPropagationOSDDecoder(H, per, max_iters, osd_order=0, device=local_rank,
                                                  waves_per_tile=args.waves_per_tile, kernel_variant=args.kernel_variant)
+        dec.close()
         dec = bposd.bp_decoder
 
         def step():
@@ -181,6 +241,15 @@ def main():
             conv.copy_(c)
             osd_sent[0] = k
             device_calls[0] += 2 if k else 1   # BP for all, then the unconverged ones once more with LLRs
+    elif mode == "scatter":
+        decode_fn = sharding.gpu_decode_fn(dec)
+        comm = torch.device("cpu") if (args.rehearse_on_one_gpu and world > 1) else None
+
+        def step():
+            tm = {}
+            result[0] = sharding.batchdecode_sharded(decode_fn, syn, s_checks, n, root=0, device=device,
+                                                     comm_device=comm, timing=tm)
+            phases.append(tm)
     else:
         def step():
             dec.decode_batch_device(syn, err, conv, None, iters)
@@ -195,6 +264,7 @@ def main():
         step()
     fence()
     device_calls[0] = 0
+    del phases[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -209,16 +279,46 @@ def main():
     sweep_ms = sum(t[0] for t in per_call) / k
     total_ms = sum(t[1] for t in per_call) / k
     sum_iters = sum(t[2] for t in per_call[:cps])
+    ph = {key: (sum(p[key] for p in phases) / len(phases) if phases else 0.0) for key in ("scatter_ms", "decode_ms", "gather_ms")}
+    decode_ms_max = ph["decode_ms"]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else device)
+        cdev = "cpu" if args.rehearse_on_one_gpu else device
+        t = torch.tensor([elapsed, ph["decode_ms"]], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, decode_ms_max = float(t[0].item()), float(t[1].item())
+
+    verified = None
+    if mode == "scatter" and args.verify and rank == 0:
+        # the root decodes every shard by itself and compares with what came back from the ranks
+        g_err, g_conv, g_it = result[0]
+        e1 = torch.empty((batch, n), dtype=torch.uint8, device=device)
+        c1 = torch.empty(batch, dtype=torch.uint8, device=device)
+        i1 = torch.empty(batch, dtype=torch.int32, device=device)
+        verified = True
+        for g in range(world):
+            dec.decode_batch_device(syn[g * batch:(g + 1) * batch], e1, c1, None, i1)
+            torch.cuda.synchronize()
+            sl = slice(g * batch, (g + 1) * batch)
+            verified = verified and bool(torch.equal(e1, g_err[sl])) and bool(torch.equal(c1, g_conv[sl])) and bool(torch.equal(i1, g_it[sl]))
 
     if rank == 0:
+        if mode == "scatter":
+            err, conv, iters = (t[:batch] for t in result[0])   # the root's own shard (seed 1234)
+            syn0 = syn[:batch]
+        else:
+            syn0 = syn
         total_syndromes = batch * world * args.steps
         value = total_syndromes / elapsed
         alg_bytes = float(sum_iters) * 32.0 * nnz        # 32*nnz B per syndrome*iteration
         achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+        if mode == "scatter":
+            par = (f"one root-held {batch * world} x {s_checks} syndrome matrix -> contiguous shards scattered from rank 0 "
+                   f"({'gloo via host staging, all ranks on one GPU (rehearsal)' if args.rehearse_on_one_gpu and world > 1 else 'RCCL send/recv groups over xGMI'}) "
+                   f"-> {world} x HIP decode -> hard decisions / flags / iteration counts gathered on rank 0"
+                   if world > 1 else
+                   "sharding.batchdecode_sharded at world size 1 (degenerate case: no exchange, decode straight into the result arrays)")
+        else:
+            par = f"replicas x{world}: every rank decodes a shard of its own (independent syndromes, no exchange)"
         out = {
             "metric": "decoded syndromes/sec (batchdecode!, 50 iters) + achieved HBM GB/s fraction",
             "value": value,
@@ -233,11 +333,12 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.workload}: Gallager ({wc},{wr})-regular LDPC n={n} m={H.shape[0]} nnz={nnz}, "
+                "workload": f"{args.workload}: Gallager ({wc},{wr})-regular LDPC n={n} m={s_checks} nnz={nnz}, "
                             f"batch={batch}/GPU, per={per}, max_iters={max_iters}, HBM-resident uint8 syndromes in, "
                             f"uint8 hard decisions + converged + iteration counts out",
                 "global_batch": batch * world,
-                "parallelism": f"batch-sharded x{world} (independent syndromes, no data-path collective)",
+                "mode": mode,
+                "parallelism": par,
                 "mean_iters": sum_iters / batch,
                 "converged_frac": float(conv.float().mean().item()),
                 "osd_postprocessed_per_step": osd_sent[0],
@@ -252,7 +353,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(args.workload)[0] if (not args.batch and not args.per and world == 1) else None,
+                # NOT measured in this run: bench.py cannot collect PMC counters; this is the committed rocprofv3
+                # figure (profiles/*_traffic.json) of the same workload, named in traffic_source
+                "traffic": pmc_traffic(args.workload)[0] if (not args.batch and not args.per) else None,
                 "traffic_source": pmc_traffic(args.workload)[1],
                 "alg_bytes_per_launch": alg_bytes,
                 "kernel_ms": sweep_ms,
@@ -260,21 +363,39 @@ def main():
                 "phase_share_check_var_conv": [round(t / max(sum(dec.phase_ticks(0)), 1), 4) for t in dec.phase_ticks(0)],
             },
         }
-        if not args.no_cpu_baseline and world == 1 and args.workload != "c5_bb72_bposd":
-            k = 64
-            cps, done, ok = cpu_baseline(H, per, max_iters, syn[:k].cpu().numpy(), err[:k].cpu().numpy(),
-                                         conv[:k].cpu().numpy())
+        if mode == "scatter":
+            out["exchange"] = {"scatter_ms": ph["scatter_ms"], "decode_ms_max_rank": decode_ms_max, "gather_ms": ph["gather_ms"],
+                               "scatter_bytes_per_peer": batch * s_checks if world > 1 else 0,
+                               "gather_bytes_per_peer": batch * (n + 1 + 4) if world > 1 else 0,
+                               "sharded_matches_local": verified}
+        if not args.no_cpu_baseline and world == 1 and not bposd_workload:
+            cores = max(1, min(len(os.sched_getaffinity(0)), 16))   # a one-GPU box grants 16 cores
+            k_edge = min(batch, 2048)
+            h_syn, h_err, h_conv, h_it = (t[:k_edge].cpu().numpy() for t in (syn0, err, conv, iters))
+            e_rate, e_done, e_ok = cpu_baseline_edge_list(H, per, max_iters, h_syn, h_err, h_conv, h_it, cores)
+            k_dense = min(batch, 64)
+            d_rate, d_done, d_ok = cpu_baseline_dense(H, per, max_iters, h_syn[:k_dense], h_err[:k_dense], h_conv[:k_dense])
             out["cpu_baseline"] = {
-                "value": cps, "unit": "syndromes/s", "cores": 1, "kind": "port",
-                "sample": f"first {done} syndromes of the same batch, C oracle in reference-faithful dense mode "
-                          f"(2 dense {H.shape[0]}x{n} Float64 matrices, full reset! per decode), 1 thread; "
+                "value": e_rate, "unit": "syndromes/s", "cores": cores, "kind": "port",
+                "sample": f"first {e_done} syndromes of the same batch, C oracle on edge lists (the reference's arithmetic on the "
+                          f"structural non-zeros only), one decoder per thread on {cores} host threads; "
                           f"the Julia reference itself cannot run here (no Julia runtime)",
-                "gpu_matches_oracle_on_sample": ok,
+                "gpu_matches_oracle_on_sample": bool(e_ok and d_ok),
+                "reference_faithful_1_thread": {
+                    "value": d_rate, "unit": "syndromes/s", "cores": 1,
+                    "sample": f"first {d_done} syndromes, C oracle in reference-faithful dense mode (2 dense {s_checks}x{n} Float64 "
+                              f"matrices, full reset! per decode: the cost structure of belief_propagation.jl:83-91,121-188), "
+                              f"1 thread like the reference",
+                },
             }
         print(json.dumps(out), flush=True)
-    # explicit teardown, in this order, before the interpreter starts dismantling modules: the decoder handle
+    # explicit teardown, in this order, before the interpreter starts dismantling modules: the decoder handles
     # (hipDeviceSynchronize + frees), then the process group
+    result[0] = None
+    if bposd is not None and hasattr(bposd, "close"):
+        bposd.close()
     dec.close()
+    del hold
     if world > 1:
         dist.destroy_process_group()
 

@@ -308,10 +308,23 @@ def test_lost_team_is_reported_or_repaired_never_silent(ldpc, gpu, monkeypatch):
     d_conv = torch.empty(700, dtype=torch.uint8, device="cuda")
     dec.decode_batch_device(d_syn, d_err, d_conv)                            # asynchronous: cannot know yet
     torch.cuda.synchronize()
-    with pytest.raises(ldpc.LdpcError, match="lost a workgroup"):
-        dec.decode_batch_device(d_syn, d_err, d_conv)
-    monkeypatch.delenv("LDPC_TEAM_INJECT_FAULT")
-    dec.decode_batch_device(d_syn, d_err, d_conv)                            # the fault is cleared once reported
+    with pytest.raises(ldpc.LdpcError, match="call #1 on this decoder lost a workgroup"):
+        dec.decode_batch_device(d_syn, d_err, d_conv)                        # refused: enqueues nothing
+    dec.decode_batch_device(d_syn, d_err, d_conv)                            # reported once; teams are off now
     torch.cuda.synchronize()
+    assert dec.info().last_kernel == 1
     assert np.array_equal(d_err.cpu().numpy(), oerr) and np.array_equal(d_conv.cpu().numpy(), oconv)
     dec.close()
+    # ldpc_bp_last_status: the asynchronous caller asks instead of waiting for the next call to tell
+    dec = ldpc.BeliefPropagationDecoder(H, 0.03, 30, kernel_variant=4)
+    dec.last_status()                                                        # nothing enqueued yet: fine
+    d_err.fill_(7)
+    dec.decode_batch_device(d_syn, d_err, d_conv)
+    with pytest.raises(ldpc.LdpcError, match=r"call #1 on this decoder lost a workgroup.*up to call #1"):
+        dec.last_status()                                                    # (synchronises the handle itself)
+    dec.last_status()                                                        # reported exactly once
+    dec.decode_batch_device(d_syn, d_err, d_conv)
+    dec.last_status()
+    assert np.array_equal(d_err.cpu().numpy(), oerr) and np.array_equal(d_conv.cpu().numpy(), oconv)
+    dec.close()
+    monkeypatch.delenv("LDPC_TEAM_INJECT_FAULT")
