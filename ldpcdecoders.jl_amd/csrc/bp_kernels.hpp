@@ -100,18 +100,26 @@ struct BPParams {
     u64 *sum_iters;       // accumulated iterations executed
     u64 *phase_ticks;     // [3] 100 MHz ticks spent in check sweep / variable sweep / convergence test,
                           //     summed over workgroups (wave 0 of each; diagnostics for DESIGN.md)
-    // Straggler hand-off (DESIGN.md "early exit"): a tile whose active lanes have dwindled to
-    // <= defer_thresh gives those syndromes up; they are appended to defer_list and decoded again
-    // from scratch, densely packed, by a second pass (index / count_dev describe that pass).
-    int defer_thresh;           // 0 = never give up (second pass, or feature off)
-    int defer_min_iter;         // do not give up before this many iterations
-    int defer_max_iter;         // ... nor after this many: the second pass starts from scratch, so handing off a
-                                // syndrome that has already run long doubles its work (waterfall workloads)
-    int *defer_list;            // [<= ntiles*defer_thresh] batch positions handed to the second pass
-    unsigned int *defer_count;  // number of entries in defer_list
-    const int *index;           // second pass: batch position of compact syndrome q (nullptr in the first pass)
-    const unsigned int *count_dev;  // second pass: number of compact syndromes (device word; nullptr = p.batch)
-    unsigned int count_skip;    // second pass: do nothing while *count_dev <= count_skip (bp_node_kernels.hpp takes those)
+    // Straggler hand-off (DESIGN.md "early exit"): a tile whose active lanes have dwindled to <= defer_thresh
+    // gives those syndromes up WITH their message state: the lanes' columns of the tile's message rows are copied
+    // into packed tiles of the next LEVEL (next_state, tile layout again: syndrome q of the level sits in lane
+    // q % 64 of packed tile q / 64), their batch positions and iteration counts are appended to defer_list /
+    // defer_it, and a later pass resumes them at the iteration they had reached -- nothing is decoded twice.
+    int defer_thresh;           // 0 = never give up (last level, or feature off)
+    int defer_min_iter;         // do not give up before this many iterations of this pass
+    int *defer_list;            // [next_cap] batch positions handed to the next level
+    int *defer_it;              // [next_cap] iterations those syndromes have run
+    unsigned int *defer_count;  // number of entries in defer_list (reserved by compare-and-swap: never beyond next_cap)
+    double *next_state;         // [next_cap / 64][next_stride] packed message tiles of the next level
+    long long next_stride;      // doubles between two packed tiles (>= nnz * 64)
+    unsigned int next_cap;      // syndromes the next level can take; a tile that finds no room carries on by itself
+    // A pass over a packed level (index != nullptr):
+    const int *index;           // batch position of compact syndrome q
+    const int *it0;             // iterations compact syndrome q has already run (its messages are in its packed tile)
+    const unsigned int *count_dev;  // number of compact syndromes (device word; nullptr = p.batch)
+    unsigned int count_skip;    // do nothing while *count_dev <= count_skip (bp_node_kernels.hpp takes those)
+    int slot_by_tile;           // 1: tile t works IN PLACE in msg + t * slot_stride (packed levels); 0: the workgroup's
+                                //    own slot msg + blockIdx.x * slot_stride (fresh tiles)
 };
 
 __device__ __forceinline__ u64 wave_or(u64 v)
@@ -276,6 +284,43 @@ __device__ __forceinline__ double bit_update(double *Mt, const int *__restrict__
 }
 
 // ---------------------------------------------------------------------------
+// Straggler hand-off helpers (shared with bp_team_kernels.hpp).
+// ---------------------------------------------------------------------------
+// Room for cnt more syndromes in the next level?  Returns the first position, or ~0u when the level is full
+// (compare-and-swap, so the count never runs past the capacity and a refused tile leaves no trace).
+__device__ __forceinline__ unsigned int defer_reserve(unsigned int *count, unsigned int cnt, unsigned int cap)
+{
+    unsigned int old = __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        if (old + cnt > cap || old + cnt < old) return ~0u;
+        const unsigned int prev = atomicCAS(count, old, old + cnt);
+        if (prev == old) return old;
+        old = prev;
+    }
+}
+
+// Copy this lane's column of the message rows first, first + step, ... (< nnz) of a tile into its place in the
+// next level's packed tile (dst = packed tile base + lane-in-packed-tile; only lanes with `mine` store).  Whole
+// 512-byte rows are read (the active lanes are scattered over the row), at most 16 x 8 contiguous bytes written.
+__device__ __forceinline__ void defer_copy_rows(const double *Mt, double *dst, bool mine, int nnz, int first, int step)
+{
+    int e = first;
+    for (; e + 7 * step < nnz; e += 8 * step) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = Mt[(size_t)(e + k * step) * kTile];
+        if (mine) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dst[(size_t)(e + k * step) * kTile] = v[k];
+        }
+    }
+    for (; e < nnz; e += step) {
+        const double v = Mt[(size_t)e * kTile];
+        if (mine) dst[(size_t)e * kTile] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // The message-passing kernel: persistent workgroups, one tile at a time.
 // ---------------------------------------------------------------------------
 // The Tanner graph (int32, device resident, read-only for the whole launch) and the
@@ -286,8 +331,10 @@ __device__ __forceinline__ double bit_update(double *Mt, const int *__restrict__
 //   col_ptr  [n+1]  CSC (bit-major) edge ranges
 //   csc2csr  [nnz]  CSR position of every CSC edge, checks ascending inside a bit
 //   synmask  [ntiles][s], nevermask [ntiles] (lanes holding a syndrome entry other than 0/1)
-// SECOND = the straggler pass (same code; a distinct instantiation only so that profilers list the
-// two passes as two kernels instead of averaging a ~1 s launch with a ~5 us one).
+// SECOND = a pass over a packed level of handed-off syndromes (same code; a distinct instantiation only so that
+// profilers list the passes as separate kernels instead of averaging a ~1 s launch with a ~5 us one).
+// A lane of such a pass has already run it0 iterations; its messages are in its packed tile, and it counts on
+// from there: every lane carries its own iteration total and retires (unconverged) when that reaches max_iters.
 template <int DC, int DV, bool WANT_LLR, int THREADS, bool SECOND>
 __global__ void
 __launch_bounds__(THREADS, (min_waves_per_simd<DC, DV, THREADS>()))
@@ -296,6 +343,7 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
                const u64 *__restrict__ synmask, const u64 *__restrict__ nevermask)
 {
     __shared__ int sh_tile;
+    __shared__ unsigned int sh_base;
     __shared__ u64 sh_mism[THREADS / 64];
     const int lane = threadIdx.x & 63;
     // the wave index is wave-uniform; telling the compiler so turns every per-node index read
@@ -304,7 +352,6 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
     constexpr int W = THREADS / 64;
     const int s = p.s, n = p.n;
     const double r = p.r;
-    double *const Mt = p.msg + (size_t)blockIdx.x * (size_t)p.slot_stride + lane;
 #if LDPC_ROTATE
     const int rot_c = s > 0 ? (int)((blockIdx.x * 2654435761u) % (unsigned)s) : 0;
     const int rot_v = n > 0 ? (int)((blockIdx.x * 2246822519u) % (unsigned)n) : 0;
@@ -324,6 +371,7 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
         const int tile = sh_tile;
         if (tile >= ntiles) break;  // every wave of every workgroup reaches this
 
+        double *const Mt = p.msg + (size_t)(p.slot_by_tile ? (unsigned)tile : blockIdx.x) * (size_t)p.slot_stride + lane;
         const u64 *syn = synmask + (size_t)tile * s;
         u64 *em = p.errmask + (size_t)tile * n;
         const long long b0 = (long long)tile * kTile;
@@ -332,14 +380,17 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
         const u64 valid = left >= kTile ? ~0ull : ((1ull << left) - 1ull);
         const u64 never = nevermask[tile];
         u64 active = valid;
+        // iterations this lane's syndrome has behind it (a resumed syndrome: its messages are already in Mt)
+        const int it0 = (SECOND && p.it0 && ((valid >> lane) & 1ull)) ? p.it0[b0 + lane] : 0;
+        const bool resumed = SECOND && p.it0 != nullptr;
         int my_iters = 0;
         int my_conv = 0;
         int it = 0;
         u64 tk_check = 0, tk_var = 0, tk_conv = 0;
 
-        while (active != 0 && it < p.max_iters) {
+        while (active != 0) {   // (every lane retires at the latest when its total reaches max_iters)
             ++it;
-            const bool first = (it == 1);
+            const bool first = (it == 1) && !resumed;
             const u64 t0 = wall_clock64();
             // ---- check-node sweep  (:135-150)
             for (int i0 = w; i0 < s; i0 += W) {
@@ -406,26 +457,36 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
             u64 U = never;
 #pragma unroll
             for (int q = 0; q < W; ++q) U |= sh_mism[q];
+            const int total = it0 + it;                      // iterations of this lane's syndrome so far
             const u64 newly = active & ~U;
-            if ((newly >> lane) & 1ull) { my_iters = it; my_conv = 1; }
+            if ((newly >> lane) & 1ull) { my_iters = total; my_conv = 1; }
             active &= U;
+            // out of iterations (belief_propagation.jl:134): the lane retires unconverged with the decisions /
+            // LLRs of this, its last, iteration
+            const u64 spent = __ballot(total >= p.max_iters) & active;
+            if ((spent >> lane) & 1ull) { my_iters = total; my_conv = 0; }
+            active &= ~spent;
             const u64 t3 = wall_clock64();
             tk_check += t1 - t0; tk_var += t2 - t1; tk_conv += t3 - t2;
-            // few stragglers left: hand them to the second pass instead of sweeping a nearly empty tile
-            if (p.defer_thresh != 0 && active != 0 && it >= p.defer_min_iter && it <= p.defer_max_iter && it < p.max_iters &&
-                (int)__popcll(active) <= p.defer_thresh) {
-                if (w == 0) {
-                    unsigned base = 0;
-                    if (lane == 0) base = atomicAdd(p.defer_count, (unsigned)__popcll(active));
-                    base = __shfl(base, 0, 64);
-                    if ((active >> lane) & 1ull)
-                        p.defer_list[base + __popcll(active & ((1ull << lane) - 1ull))] = (int)(b0 + lane);
+            // few stragglers left: hand them -- with their messages -- to the next level instead of sweeping a
+            // nearly empty tile (uniform over the workgroup: active and it are)
+            if (p.defer_thresh != 0 && active != 0 && it >= p.defer_min_iter && (int)__popcll(active) <= p.defer_thresh) {
+                if (threadIdx.x == 0) sh_base = defer_reserve(p.defer_count, (unsigned)__popcll(active), p.next_cap);
+                __syncthreads();
+                const unsigned base = sh_base;
+                if (base != ~0u) {
+                    const bool mine = (active >> lane) & 1ull;
+                    const unsigned q = base + (unsigned)__popcll(active & ((1ull << lane) - 1ull));
+                    defer_copy_rows(Mt, p.next_state + (size_t)(q >> 6) * (size_t)p.next_stride + (q & 63u), mine, p.nnz, w, W);
+                    if (w == 0 && mine) {
+                        p.defer_list[q] = p.index ? p.index[b0 + lane] : (int)(b0 + lane);
+                        p.defer_it[q] = total;
+                    }
+                    deferred = active;
+                    active = 0;
                 }
-                deferred = active;
-                active = 0;
             }
         }
-        if ((active >> lane) & 1ull) { my_iters = it; my_conv = 0; }
         if (w == 0) {
             if (((valid & ~deferred) >> lane) & 1ull) {
                 const long long ob = p.index ? (long long)p.index[b0 + lane] : b0 + lane;
@@ -434,7 +495,8 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
             } else {
                 my_iters = 0;
             }
-            // sum of iterations executed, for the algorithmic byte count
+            // sum of iterations executed, for the algorithmic byte count (a handed-off syndrome is counted by the
+            // pass that finishes it, with its total: every iteration is executed, and counted, once)
             int tot = my_iters;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);

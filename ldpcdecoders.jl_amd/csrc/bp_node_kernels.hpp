@@ -35,11 +35,16 @@ struct NodeParams {
     long long slot_stride;      // doubles per workgroup slot (>= nnz)
     unsigned int *queue;
     u64 *sum_iters;
-    // as the second pass of the tile kernel's straggler hand-off: syndrome q of this launch is syndrome
-    // index[q] of the batch, there are *count_dev of them, and above count_max the tile kernel takes them
+    // as the last pass of the straggler hand-off (bp_kernels.hpp): syndrome q of this launch is syndrome index[q]
+    // of the batch, there are *count_dev of them, and above count_max the tile / team kernels take them.  It has
+    // it0[q] iterations behind it, and its messages wait in lane q % 64 of packed tile q / 64 of `state`
+    // (tile layout msg[edge][64]): the workgroup gathers that column into its own message array and counts on.
     const int *index;
     const unsigned int *count_dev;
     unsigned int count_max;
+    const int *it0;
+    const double *state;
+    long long state_stride;     // doubles between two packed tiles
     u64 *next_ctrl;             // see LdsParams
     // latency mode (see LdsParams): queue == nullptr, workgroup g decodes syndrome g only
     unsigned int *done_count;
@@ -116,6 +121,7 @@ bp_node_kernel(NodeParams p, const int *__restrict__ row_ptr, const int *__restr
     unsigned char *sbit = node_lds;           // [s] syndrome entry parity
     unsigned char *ebit = node_lds + p.s;     // [n] hard decisions
     __shared__ long long sh_b;
+    __shared__ long long sh_q;
     const int s = p.s, n = p.n;
     const int tid = threadIdx.x;
     const double r = p.r;
@@ -140,11 +146,25 @@ bp_node_kernel(NodeParams p, const int *__restrict__ row_ptr, const int *__restr
             if (tid == 0) {
                 const long long q = (long long)atomicAdd(p.queue, 1u);
                 sh_b = q >= batch ? -1 : (p.index ? (long long)p.index[q] : q);
+                sh_q = q;
             }
             __syncthreads();
             b = sh_b;
         }
         if (b < 0) break;                      // every wave of every workgroup reaches this
+        // ---- a handed-off syndrome: its messages out of the packed tile (one 8-byte word per 512-byte row)
+        const bool resumed = p.state != nullptr;
+        int it = 0;
+        if (resumed) {
+            const long long q = sh_q;
+            const double *src = p.state + (size_t)(q >> 6) * (size_t)p.state_stride + (size_t)(q & 63);
+            for (int e = tid; e < p.nnz; e += THREADS) {
+                const double v = src[(size_t)e * kTile];
+                if (MSG == 2) { if (e < split_edge) Ml[e] = v; else Mg[e - split_edge] = v; }
+                else M[e] = v;
+            }
+            it = p.it0[q];
+        }
         // ---- syndrome in (:136: entries > 1 can never be matched by a parity bit)
         int bad = 0;
         for (int i = tid; i < s; i += THREADS) {
@@ -154,10 +174,10 @@ bp_node_kernel(NodeParams p, const int *__restrict__ row_ptr, const int *__restr
         }
         const int never = __syncthreads_or(bad);   // also orders sbit[] before the sweeps
 
-        int it = 0, converged = 0;
+        int converged = 0;
         while (it < p.max_iters) {
             ++it;
-            const bool first = (it == 1);
+            const bool first = (it == 1) && !resumed;
             // ---- check sweep: one thread per check, its messages are contiguous
             for (int i = tid; i < s; i += THREADS) {
                 const int e0 = row_ptr[i];

@@ -155,12 +155,15 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     const u64 valid = left >= kTile ? ~0ull : ((1ull << left) - 1ull);
     const u64 never = nevermask[tile];
     u64 active = valid;                                        // identical in every member: same inputs, same words
+    // a pass over a packed level: every lane has it0 iterations behind it and its messages in the packed tile
+    const bool resumed = p.it0 != nullptr;
+    const int it0 = (resumed && ((valid >> lane) & 1ull)) ? p.it0[b0 + lane] : 0;
     int my_iters = 0, my_conv = 0, it = 0;
     u64 tk_check = 0, tk_var = 0, tk_rest = 0;   // this wave's own sweep time / everything else (waiting included)
 
-    while (active != 0 && it < p.max_iters) {
+    while (active != 0) {   // (every lane retires at the latest when its total reaches max_iters)
         ++it;
-        const bool first = (it == 1);
+        const bool first = (it == 1) && !resumed;
         const u64 t0 = wall_clock64();
         // ---- check-node sweep  (:135-150)
         for (int i = gw; i < s; i += GW) {
@@ -226,26 +229,38 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
         }
         if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd)) return;
         const u64 U = never | __hip_atomic_load(&mw[it - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int total = it0 + it;                            // iterations of this lane's syndrome so far
         const u64 newly = active & ~U;
-        if ((newly >> lane) & 1ull) { my_iters = it; my_conv = 1; }
+        if ((newly >> lane) & 1ull) { my_iters = total; my_conv = 1; }
         active &= U;
+        const u64 spent = __ballot(total >= p.max_iters) & active;   // out of iterations: retires unconverged
+        if ((spent >> lane) & 1ull) { my_iters = total; my_conv = 0; }
+        active &= ~spent;
         const u64 t4 = wall_clock64();
         tk_check += t1 - t0; tk_var += t3 - t2; tk_rest += (t2 - t1) + (t4 - t3);   // rest = barriers + test
-        // few stragglers left: hand them to the second pass (decided alike by every member; rank 0 files them)
-        if (p.defer_thresh != 0 && active != 0 && it >= p.defer_min_iter && it <= p.defer_max_iter && it < p.max_iters &&
-            (int)__popcll(active) <= p.defer_thresh) {
-            if (rank == 0 && w == 0) {
-                unsigned base = 0;
-                if (lane == 0) base = atomicAdd(p.defer_count, (unsigned)__popcll(active));
-                base = __shfl(base, 0, 64);
-                if ((active >> lane) & 1ull)
-                    p.defer_list[base + __popcll(active & ((1ull << lane) - 1ull))] = (int)(b0 + lane);
+        // few stragglers left: hand them, with their messages, to the next level (decided alike by every member;
+        // rank 0 reserves the room and tells the others through the tile's control block, then all copy)
+        if (p.defer_thresh != 0 && active != 0 && it >= p.defer_min_iter && (int)__popcll(active) <= p.defer_thresh) {
+            if (rank == 0 && threadIdx.x == 0)
+                __hip_atomic_store(ctr + 33, defer_reserve(p.defer_count, (unsigned)__popcll(active), p.next_cap) + 1u,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // base + 1; a full level (~0u) is told as 0
+            if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd)) return;
+            const unsigned told = __hip_atomic_load(ctr + 33, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd)) return;   // everyone has read it: the word may be rewritten
+            if (told != 0u) {                                  // (0 = ~0u + 1: the next level is full, carry on)
+                const unsigned base = told - 1u;
+                const bool mine = (active >> lane) & 1ull;
+                const unsigned q = base + (unsigned)__popcll(active & ((1ull << lane) - 1ull));
+                defer_copy_rows(Mt, p.next_state + (size_t)(q >> 6) * (size_t)p.next_stride + (q & 63u), mine, p.nnz, gw, GW);
+                if (rank == 0 && w == 0 && mine) {
+                    p.defer_list[q] = p.index ? p.index[b0 + lane] : (int)(b0 + lane);
+                    p.defer_it[q] = total;
+                }
+                deferred = active;
+                active = 0;
             }
-            deferred = active;
-            active = 0;
         }
     }
-    if ((active >> lane) & 1ull) { my_iters = it; my_conv = 0; }
     if (rank == 0 && w == 0) {
         if (((valid & ~deferred) >> lane) & 1ull) {
             const long long ob = p.index ? (long long)p.index[b0 + lane] : b0 + lane;

@@ -45,3 +45,6 @@ def test_bench_json_contract(gpu):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "traffic" in r
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "syndromes/s" and c["sample"]
+    assert c["gpu_matches_oracle_on_sample"] is True and c["reference_faithful_1_thread"]["cores"] == 1
+    # N = 1 runs the multi-GPU path's own code (sharding.batchdecode_sharded) in its degenerate form
+    assert d["config"]["mode"] == "scatter" and d["exchange"]["scatter_bytes_per_peer"] == 0

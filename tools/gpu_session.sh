@@ -12,5 +12,6 @@ while [ $# -ge 2 ]; do
     rc=$?
     echo "[$TAG step $k] exit $rc"; tail -3 gpurun_out/${TAG}_$k.log
     if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "[$TAG] step $k timed out: stopping"; exit 1; fi
+    if grep -q "Memory access fault" gpurun_out/${TAG}_$k.log; then echo "[$TAG] step $k faulted on the GPU: stopping"; exit 1; fi
 done
 exit 0
