@@ -83,6 +83,33 @@ __device__ __forceinline__ void stm(double *p, double v)
 #endif
 }
 
+// Parameters a pass touches once per tile (or once per hand-off).  They live in DEVICE memory (the host stores a
+// block per pass with store_cold_kernel) and are read where they are needed: as by-value kernel arguments they
+// were all loaded in the prologue and kept live through the sweeps, and the scalar registers that cost pushed the
+// hot instantiation over its 80-VGPR budget (spilled SGPRs are parked in VGPR lanes).
+struct BPCold {
+    int *iters;                 // [batch] or nullptr
+    unsigned char *conv;        // [batch]
+    u64 *sum_iters;             // accumulated iterations executed
+    u64 *phase_ticks;           // [3] 100 MHz ticks spent in check sweep / variable sweep / convergence test,
+                                //     summed over workgroups (wave 0 of each; diagnostics for DESIGN.md)
+    // Straggler hand-off (DESIGN.md "early exit"): a tile whose active lanes have dwindled to <= defer_thresh
+    // gives those syndromes up WITH their message state: the lanes' columns of the tile's message rows are copied
+    // into packed tiles of the next LEVEL (next_state, tile layout again: syndrome q of the level sits in lane
+    // q % 64 of packed tile q / 64), their batch positions and iteration counts are appended to defer_list /
+    // defer_it, and a later pass resumes them at the iteration they had reached -- nothing is decoded twice.
+    int *defer_list;            // [next_cap] batch positions handed to the next level
+    int *defer_it;              // [next_cap] iterations those syndromes have run
+    unsigned int *defer_count;  // number of entries in defer_list (reserved by compare-and-swap: never beyond next_cap)
+    double *next_state;         // [next_cap / 64][next_stride] packed message tiles of the next level
+    long long next_stride;      // doubles between two packed tiles (>= nnz * 64)
+    unsigned int next_cap;      // syndromes the next level can take; a tile that finds no room carries on by itself
+    unsigned int next_mult, next_mod;   // placement of the next level's packed tiles (see slot_mult)
+    // A pass over a packed level (index != nullptr):
+    const int *index;           // batch position of compact syndrome q
+    const int *it0;             // iterations compact syndrome q has already run (its messages are in its packed tile)
+};
+
 struct BPParams {
     int s, n, nnz;
     int max_iters;
@@ -90,36 +117,25 @@ struct BPParams {
     long long batch;
     double r;  // channel odds per/(1-per)   (belief_propagation.jl:129,153)
     // per-launch buffers
-    double *msg;          // [slots][nnz][64]   workspace, slot = blockIdx.x
+    double *msg;          // [slots][slot_stride]   workspace (fresh tiles) or the packed tiles of a level
     long long slot_stride;  // doubles between consecutive slots (>= nnz*64)
     u64 *errmask;         // [ntiles][n]
     double *llr;          // [ntiles][n][64] or nullptr
-    int *iters;           // [batch] or nullptr
-    unsigned char *conv;  // [batch]
     unsigned int *queue;  // tile queue head
-    u64 *sum_iters;       // accumulated iterations executed
-    u64 *phase_ticks;     // [3] 100 MHz ticks spent in check sweep / variable sweep / convergence test,
-                          //     summed over workgroups (wave 0 of each; diagnostics for DESIGN.md)
-    // Straggler hand-off (DESIGN.md "early exit"): a tile whose active lanes have dwindled to <= defer_thresh
-    // gives those syndromes up WITH their message state: the lanes' columns of the tile's message rows are copied
-    // into packed tiles of the next LEVEL (next_state, tile layout again: syndrome q of the level sits in lane
-    // q % 64 of packed tile q / 64), their batch positions and iteration counts are appended to defer_list /
-    // defer_it, and a later pass resumes them at the iteration they had reached -- nothing is decoded twice.
-    int defer_thresh;           // 0 = never give up (last level, or feature off)
+    const BPCold *cold;   // everything touched once per tile (device memory)
+    int defer_thresh;           // hand stragglers on once at most this many lanes are active; 0 = never (last level, or feature off)
     int defer_min_iter;         // do not give up before this many iterations of this pass
-    int *defer_list;            // [next_cap] batch positions handed to the next level
-    int *defer_it;              // [next_cap] iterations those syndromes have run
-    unsigned int *defer_count;  // number of entries in defer_list (reserved by compare-and-swap: never beyond next_cap)
-    double *next_state;         // [next_cap / 64][next_stride] packed message tiles of the next level
-    long long next_stride;      // doubles between two packed tiles (>= nnz * 64)
-    unsigned int next_cap;      // syndromes the next level can take; a tile that finds no room carries on by itself
-    // A pass over a packed level (index != nullptr):
-    const int *index;           // batch position of compact syndrome q
-    const int *it0;             // iterations compact syndrome q has already run (its messages are in its packed tile)
-    const unsigned int *count_dev;  // number of compact syndromes (device word; nullptr = p.batch)
-    unsigned int count_skip;    // do nothing while *count_dev <= count_skip (bp_node_kernels.hpp takes those)
-    int slot_by_tile;           // 1: tile t works IN PLACE in msg + t * slot_stride (packed levels); 0: the workgroup's
-                                //    own slot msg + blockIdx.x * slot_stride (fresh tiles)
+    const unsigned int *count_dev;  // a pass over a packed level: number of compact syndromes (device word; nullptr = p.batch)
+    unsigned int count_skip;    // ... do nothing while *count_dev <= count_skip (bp_node_kernels.hpp takes those)
+    int resumed;                // 1: a pass over a packed level (cold->index / cold->it0 are set, messages are in the packed tiles)
+    // Slot placement: index x -> slot (x * slot_mult) % slot_mod (32-bit arithmetic; x = blockIdx.x for the tile
+    // kernel on fresh tiles, where a workgroup keeps its slot for the launch; x = the tile for the team kernel and
+    // for passes over a packed level, which work IN PLACE in the level's packed tiles).  Workgroups that are
+    // dispatched together (consecutive blockIdx: they run at the same pace for the whole launch) must NOT sweep
+    // adjacent slots: with slot = blockIdx the sweeps ran 5.2-5.5 TB/s and their speed depended on where the
+    // allocation happened to land, with any permutation that separates neighbours 6.0 TB/s on every allocation
+    // (tools/vmm_probe5.hip; DESIGN.md "Workspace placement").  The same map places the packed tiles of a level.
+    unsigned int slot_mult, slot_mod;
 };
 
 __device__ __forceinline__ u64 wave_or(u64 v)
@@ -357,6 +373,8 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
     const int rot_v = n > 0 ? (int)((blockIdx.x * 2246822519u) % (unsigned)n) : 0;
 #endif
 
+    const unsigned slot0 = (blockIdx.x * p.slot_mult) % p.slot_mod;   // (see BPParams::slot_mult)
+
     long long batch_ = p.batch;
     if (p.count_dev) {
         batch_ = (long long)*p.count_dev;
@@ -371,7 +389,9 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
         const int tile = sh_tile;
         if (tile >= ntiles) break;  // every wave of every workgroup reaches this
 
-        double *const Mt = p.msg + (size_t)(p.slot_by_tile ? (unsigned)tile : blockIdx.x) * (size_t)p.slot_stride + lane;
+        // fresh tiles: the workgroup's own slot; a packed level (SECOND): the tile's packed tile, in place
+        const unsigned myslot = SECOND ? ((unsigned)tile * p.slot_mult) % p.slot_mod : slot0;
+        double *const Mt = p.msg + (size_t)myslot * (size_t)p.slot_stride + lane;
         const u64 *syn = synmask + (size_t)tile * s;
         u64 *em = p.errmask + (size_t)tile * n;
         const long long b0 = (long long)tile * kTile;
@@ -381,8 +401,8 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
         const u64 never = nevermask[tile];
         u64 active = valid;
         // iterations this lane's syndrome has behind it (a resumed syndrome: its messages are already in Mt)
-        const int it0 = (SECOND && p.it0 && ((valid >> lane) & 1ull)) ? p.it0[b0 + lane] : 0;
-        const bool resumed = SECOND && p.it0 != nullptr;
+        const bool resumed = SECOND && p.resumed;
+        const int it0 = (resumed && ((valid >> lane) & 1ull)) ? p.cold->it0[b0 + lane] : 0;
         int my_iters = 0;
         int my_conv = 0;
         int it = 0;
@@ -471,16 +491,18 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
             // few stragglers left: hand them -- with their messages -- to the next level instead of sweeping a
             // nearly empty tile (uniform over the workgroup: active and it are)
             if (p.defer_thresh != 0 && active != 0 && it >= p.defer_min_iter && (int)__popcll(active) <= p.defer_thresh) {
-                if (threadIdx.x == 0) sh_base = defer_reserve(p.defer_count, (unsigned)__popcll(active), p.next_cap);
+                const BPCold *const cd = p.cold;
+                if (threadIdx.x == 0) sh_base = defer_reserve(cd->defer_count, (unsigned)__popcll(active), cd->next_cap);
                 __syncthreads();
                 const unsigned base = sh_base;
                 if (base != ~0u) {
                     const bool mine = (active >> lane) & 1ull;
                     const unsigned q = base + (unsigned)__popcll(active & ((1ull << lane) - 1ull));
-                    defer_copy_rows(Mt, p.next_state + (size_t)(q >> 6) * (size_t)p.next_stride + (q & 63u), mine, p.nnz, w, W);
+                    defer_copy_rows(Mt, cd->next_state + (size_t)(((u64)(q >> 6) * cd->next_mult) % cd->next_mod) * (size_t)cd->next_stride + (q & 63u),
+                                    mine, p.nnz, w, W);
                     if (w == 0 && mine) {
-                        p.defer_list[q] = p.index ? p.index[b0 + lane] : (int)(b0 + lane);
-                        p.defer_it[q] = total;
+                        cd->defer_list[q] = resumed ? cd->index[b0 + lane] : (int)(b0 + lane);
+                        cd->defer_it[q] = total;
                     }
                     deferred = active;
                     active = 0;
@@ -488,10 +510,12 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
             }
         }
         if (w == 0) {
+            const BPCold *const cd = p.cold;
             if (((valid & ~deferred) >> lane) & 1ull) {
-                const long long ob = p.index ? (long long)p.index[b0 + lane] : b0 + lane;
-                p.conv[ob] = (unsigned char)my_conv;
-                if (p.iters) p.iters[ob] = my_iters;
+                const long long ob = resumed ? (long long)cd->index[b0 + lane] : b0 + lane;
+                cd->conv[ob] = (unsigned char)my_conv;
+                int *const iters = cd->iters;
+                if (iters) iters[ob] = my_iters;
             } else {
                 my_iters = 0;
             }
@@ -501,10 +525,11 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
             if (lane == 0) {
-                atomicAdd(p.sum_iters, (u64)tot);
-                atomicAdd(&p.phase_ticks[0], tk_check);
-                atomicAdd(&p.phase_ticks[1], tk_var);
-                atomicAdd(&p.phase_ticks[2], tk_conv);
+                atomicAdd(cd->sum_iters, (u64)tot);
+                u64 *const ticks = cd->phase_ticks;
+                atomicAdd(&ticks[0], tk_check);
+                atomicAdd(&ticks[1], tk_var);
+                atomicAdd(&ticks[2], tk_conv);
             }
         }
         __syncthreads();
@@ -512,6 +537,12 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
 }
 
 #ifdef LDPC_AUX_KERNELS   // the small non-template kernels: only the host translation unit (ldpc_mi355x.hip) defines them
+// the per-pass BPCold blocks of one call: by-value kernel arguments -> device memory, in stream order
+__global__ void __launch_bounds__(64) store_cold_kernel(BPCold c0, BPCold c1, BPCold c2, BPCold *dst)
+{
+    if (threadIdx.x == 0) { dst[0] = c0; dst[1] = c1; dst[2] = c2; }
+}
+
 // ---------------------------------------------------------------------------
 // placement probe: the variable sweep's access pattern on a candidate workspace -- every wave of a
 // slot's workgroup gathers 4 pseudo-random rows of the slot and writes them back.  The host times it

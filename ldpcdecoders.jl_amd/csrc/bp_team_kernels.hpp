@@ -134,7 +134,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     const int rank = tp.scatter ? (int)(blockIdx.x % (unsigned)G) : bq % G;
     if (tile >= ntiles || (p.count_dev && bq >= G * ((ntiles + 7) / 8))) return;   // whole teams only: nobody waits for these
     const int gw = rank * W + w, GW = G * W;                   // this wave among the team's waves
-    double *const Mt = p.msg + (size_t)tile * (size_t)p.slot_stride + lane;
+    double *const Mt = p.msg + (size_t)(((unsigned)tile * p.slot_mult) % p.slot_mod) * (size_t)p.slot_stride + lane;
     unsigned int *const ctr = tp.ctl + (size_t)tile * kTeamCtlWords;
     unsigned int *const xccs = ctr + 32;
     u64 *const mw = tp.mism + (size_t)tile * (size_t)tp.mism_stride;
@@ -156,8 +156,9 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     const u64 never = nevermask[tile];
     u64 active = valid;                                        // identical in every member: same inputs, same words
     // a pass over a packed level: every lane has it0 iterations behind it and its messages in the packed tile
-    const bool resumed = p.it0 != nullptr;
-    const int it0 = (resumed && ((valid >> lane) & 1ull)) ? p.it0[b0 + lane] : 0;
+    const bool resumed = p.resumed != 0;
+    const BPCold *const cd = p.cold;
+    const int it0 = (resumed && ((valid >> lane) & 1ull)) ? cd->it0[b0 + lane] : 0;
     int my_iters = 0, my_conv = 0, it = 0;
     u64 tk_check = 0, tk_var = 0, tk_rest = 0;   // this wave's own sweep time / everything else (waiting included)
 
@@ -242,7 +243,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
         // rank 0 reserves the room and tells the others through the tile's control block, then all copy)
         if (p.defer_thresh != 0 && active != 0 && it >= p.defer_min_iter && (int)__popcll(active) <= p.defer_thresh) {
             if (rank == 0 && threadIdx.x == 0)
-                __hip_atomic_store(ctr + 33, defer_reserve(p.defer_count, (unsigned)__popcll(active), p.next_cap) + 1u,
+                __hip_atomic_store(ctr + 33, defer_reserve(cd->defer_count, (unsigned)__popcll(active), cd->next_cap) + 1u,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // base + 1; a full level (~0u) is told as 0
             if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd)) return;
             const unsigned told = __hip_atomic_load(ctr + 33, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -251,10 +252,11 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
                 const unsigned base = told - 1u;
                 const bool mine = (active >> lane) & 1ull;
                 const unsigned q = base + (unsigned)__popcll(active & ((1ull << lane) - 1ull));
-                defer_copy_rows(Mt, p.next_state + (size_t)(q >> 6) * (size_t)p.next_stride + (q & 63u), mine, p.nnz, gw, GW);
+                defer_copy_rows(Mt, cd->next_state + (size_t)(((u64)(q >> 6) * cd->next_mult) % cd->next_mod) * (size_t)cd->next_stride + (q & 63u),
+                                mine, p.nnz, gw, GW);
                 if (rank == 0 && w == 0 && mine) {
-                    p.defer_list[q] = p.index ? p.index[b0 + lane] : (int)(b0 + lane);
-                    p.defer_it[q] = total;
+                    cd->defer_list[q] = resumed ? cd->index[b0 + lane] : (int)(b0 + lane);
+                    cd->defer_it[q] = total;
                 }
                 deferred = active;
                 active = 0;
@@ -263,9 +265,9 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     }
     if (rank == 0 && w == 0) {
         if (((valid & ~deferred) >> lane) & 1ull) {
-            const long long ob = p.index ? (long long)p.index[b0 + lane] : b0 + lane;
-            p.conv[ob] = (unsigned char)my_conv;
-            if (p.iters) p.iters[ob] = my_iters;
+            const long long ob = resumed ? (long long)cd->index[b0 + lane] : b0 + lane;
+            cd->conv[ob] = (unsigned char)my_conv;
+            if (cd->iters) cd->iters[ob] = my_iters;
         } else {
             my_iters = 0;
         }
@@ -273,10 +275,10 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
         if (lane == 0) {
-            atomicAdd(p.sum_iters, (u64)tot);
-            atomicAdd(&p.phase_ticks[0], tk_check);
-            atomicAdd(&p.phase_ticks[1], tk_var);
-            atomicAdd(&p.phase_ticks[2], tk_rest);
+            atomicAdd(cd->sum_iters, (u64)tot);
+            atomicAdd(&cd->phase_ticks[0], tk_check);
+            atomicAdd(&cd->phase_ticks[1], tk_var);
+            atomicAdd(&cd->phase_ticks[2], tk_rest);
         }
     }
 }

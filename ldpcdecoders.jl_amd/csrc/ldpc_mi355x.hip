@@ -124,7 +124,7 @@ struct ldpc_bp_decoder {
     int64_t node_take_max = 0;    // most stragglers the node-parallel kernel takes as the second pass of the hand-off
     DevBuf node_msg;          // [workgroups][nnz] double, the node-parallel kernel's message slots
     // team kernel (bp_team_kernels.hpp): arrival counters + mismatch words, and the host-mapped fault word
-    DevBuf team_ws, team_ws2;   // control blocks of the first-pass / second-pass team kernel
+    DevBuf team_ws, team_ws_lvl[2];   // control blocks of the team kernel: level 0 / the passes over the packed levels
     unsigned int *team_fault = nullptr, *team_fault_dev = nullptr;
     int team_max = 32;        // workgroups per tile at most (LDPC_TEAM_MAX; 1 = team kernel off)
     bool team_max_set = false;   // ... given by the environment: no automatic 64 for batches of <= 4 tiles
@@ -144,12 +144,15 @@ struct ldpc_bp_decoder {
     // workspace
     DevBuf msg;               // [resident_tiles][nnz][64] double
     DevBuf ctrl;              // queue (u32) + sum_iters (u64), 64 B
+    DevBuf cold;              // BPCold blocks of the passes of the call in flight (bp_kernels.hpp)
     // per-batch buffers (grow only)
     DevBuf synmask, nevermask, errmask, llr_t;
-    // second pass of the straggler hand-off
-    DevBuf defer_list, synmask2, nevermask2, errmask2, llr_t2;
+    // packed levels of the straggler hand-off (decode_device_impl): message tiles, batch positions, iteration
+    // counts, and the per-level images of the per-batch buffers above
+    DevBuf lvl_state[2], lvl_list[2], lvl_it[2], lvl_syn[2], lvl_never[2], lvl_err[2], lvl_llr[2];
     int defer_thresh = 0;     // 0 auto (16 lanes), -1 off, else the lane count at which a tile gives up
-    int defer_max_iter = 8;   // tiles hand off only up to this iteration (LDPC_DEFER_MAX_ITER, read at create)
+    int defer_t0 = 16, defer_t1 = 16;   // lanes at which a fresh tile / a packed tile of level 1 hands off (LDPC_DEFER_T0 / _T1 at create; T1 0 = one level)
+    int lvl_cap_force = 0;    // tests (LDPC_DEFER_CAP_TILES at create): packed tiles per level, so that full levels are exercised
     float placement_ms = 0.f; // probe time of the chosen workspace allocation (0 = no probing happened)
     int placement_candidates = 0;
     // staging for the host-pointer entry
@@ -182,9 +185,10 @@ struct ldpc_bp_decoder {
     ~ldpc_bp_decoder()
     {
         DevBuf *all[] = {&row_ptr, &edge_bit, &col_ptr, &csc2csr, &msg, &ctrl, &synmask, &nevermask,
-                         &errmask, &llr_t, &st_all, &node_msg, &done_ctr, &team_ws, &team_ws2,
-                         &defer_list, &synmask2, &nevermask2, &errmask2, &llr_t2};
+                         &errmask, &llr_t, &st_all, &node_msg, &done_ctr, &team_ws, &team_ws_lvl[0], &team_ws_lvl[1], &cold};
         for (DevBuf *b : all) b->release();
+        for (int l = 0; l < 2; ++l)
+            for (DevBuf *b : {&lvl_state[l], &lvl_list[l], &lvl_it[l], &lvl_syn[l], &lvl_never[l], &lvl_err[l], &lvl_llr[l]}) b->release();
         if (pin) (void)hipHostFree(pin);
         if (lat_pin) (void)hipHostFree(lat_pin);
         if (team_fault) (void)hipHostFree(team_fault);
@@ -251,6 +255,20 @@ static size_t slot_pad_bytes()
     return v;
 }
 
+// Slot placement (BPParams::slot_mult): index x -> slot (x * m) % mod with m coprime to mod, so that workgroups
+// dispatched together do not sweep adjacent slots (tools/vmm_probe5.hip: identity 5.2-5.5 TB/s, any of these
+// multipliers 6.0 TB/s, on every allocation).  Tiny grids keep the identity.
+static unsigned slot_multiplier(unsigned mod)
+{
+    static const int forced = [] { const char *e = std::getenv("LDPC_SLOT_MULT"); return e ? std::atoi(e) : 0; }();
+    auto gcd = [](unsigned a, unsigned b) { while (b) { const unsigned t = a % b; a = b; b = t; } return a; };
+    if (forced > 0 && gcd((unsigned)forced, mod) == 1) return (unsigned)forced % std::max(mod, 1u);
+    if (mod < 24) return 1;
+    for (unsigned m : {37u, 101u, 331u, 41u, 43u, 47u, 53u, 59u, 61u, 67u, 71u, 73u, 79u, 83u, 89u, 97u, 13u, 11u})
+        if (m < mod && gcd(m, mod) == 1) return m;
+    return 1;
+}
+
 // Workspace placement: where in HBM the message workspace lands changes what the sweeps can
 // stream by up to 15 % (tools/placement_probe.hip: the same kernels on eight simultaneously held
 // 24.8 GiB allocations ran 4.88 ... 5.62 TB/s, reproducibly per allocation; across processes the same
@@ -263,7 +281,7 @@ static ldpc_status ensure_workspace(ldpc_bp_decoder *d, size_t bytes, int grid, 
 {
     if (bytes <= d->msg.cap) return LDPC_OK;
     d->msg.release();
-    int want = 12;
+    int want = 1;   // (the search is off since the slot permutation made every allocation fast; LDPC_PLACEMENT_CANDIDATES=12 brings it back)
     if (const char *e = std::getenv("LDPC_PLACEMENT_CANDIDATES")) want = std::max(1, std::atoi(e));
     const bool verbose = std::getenv("LDPC_PLACEMENT_VERBOSE") != nullptr;
     if (want < 2 || bytes < ((size_t)1 << 30) || d->nnz < 4) return d->msg.ensure(bytes);
@@ -522,7 +540,9 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     // (measured crossovers in DESIGN.md); LDPC_NODE_MAX_BATCH overrides for experiments.
     d->node_max_batch = (int64_t)d->num_cus * 8;
     if (const char *e = std::getenv("LDPC_NODE_MAX_BATCH")) d->node_max_batch = std::atoll(e);
-    if (const char *e = std::getenv("LDPC_DEFER_MAX_ITER")) d->defer_max_iter = std::max(2, std::atoi(e));
+    if (const char *e = std::getenv("LDPC_DEFER_T0")) d->defer_t0 = std::max(1, std::min(48, std::atoi(e)));
+    if (const char *e = std::getenv("LDPC_DEFER_T1")) d->defer_t1 = std::max(0, std::min(48, std::atoi(e)));
+    if (const char *e = std::getenv("LDPC_DEFER_CAP_TILES")) d->lvl_cap_force = std::max(0, std::atoi(e));
     d->node_take_max = (int64_t)d->num_cus * 8;
     if (const char *e = std::getenv("LDPC_NODE_TAKE_MAX")) d->node_take_max = std::atoll(e);
     // keep the workspace inside a sane share of HBM (slots are nnz*512 B each)
@@ -570,8 +590,10 @@ ldpc_status ldpc_bp_get_info(const ldpc_bp_decoder *d, ldpc_bp_info *info)
     info->device = d->device; info->tile_syndromes = kTile; info->waves_per_tile = d->last_threads / 64;
     info->resident_tiles = d->last_grid;
     const DevBuf *all[] = {&d->row_ptr, &d->edge_bit, &d->col_ptr, &d->csc2csr, &d->msg, &d->ctrl, &d->synmask,
-                           &d->nevermask, &d->errmask, &d->llr_t, &d->st_all, &d->defer_list, &d->synmask2,
-                           &d->nevermask2, &d->errmask2, &d->llr_t2, &d->node_msg, &d->pipe_dev[0], &d->pipe_dev[1], &d->pipe_dev[2]};
+                           &d->nevermask, &d->errmask, &d->llr_t, &d->st_all, &d->node_msg, &d->pipe_dev[0], &d->pipe_dev[1], &d->pipe_dev[2],
+                           &d->lvl_state[0], &d->lvl_state[1], &d->lvl_list[0], &d->lvl_list[1], &d->lvl_it[0], &d->lvl_it[1],
+                           &d->lvl_syn[0], &d->lvl_syn[1], &d->lvl_never[0], &d->lvl_never[1], &d->lvl_err[0], &d->lvl_err[1],
+                           &d->lvl_llr[0], &d->lvl_llr[1]};
     for (const DevBuf *b : all) info->workspace_bytes += (int64_t)b->cap;
     info->last_kernel = d->last_kernel;
     info->last_team_size = d->last_team;
@@ -769,7 +791,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         const int64_t ngroups64 = (batch + (1ll << logS) - 1) >> logS;
         if (ngroups64 > (1ll << 30)) return fail(LDPC_ERR_UNSUPPORTED, "batch too large for one call");
         d->last_kernel = 2; d->last_team = 1;
-        LdsParams lp;
+        LdsParams lp{};
         lp.s = (int)s; lp.n = (int)n; lp.nnz = (int)d->nnz; lp.max_iters = (int)d->max_iters;
         lp.logS = logS; lp.ngroups = (int)ngroups64; lp.batch = batch;
         lp.r = d->per / (1 - d->per);
@@ -837,7 +859,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         ldpc_status nst = d->node_msg.ensure(mlds ? 64 : (size_t)ngrid * stride * sizeof(double));
         if (nst != LDPC_OK) return nst;
         d->last_kernel = 3; d->last_team = 1;
-        NodeParams np;
+        NodeParams np{};
         np.s = (int)s; np.n = (int)n; np.nnz = (int)d->nnz; np.max_iters = (int)d->max_iters;
         np.batch = batch; np.r = d->per / (1 - d->per);
         np.syn = d_syn; np.err = d_err; np.conv = d_conv; np.iters = d_iters; np.llr = d_llr;
@@ -932,29 +954,65 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     if ((st = ensure_workspace(d, (size_t)grid * slot_stride_bytes, grid, slot_stride_bytes, stream)) != LDPC_OK)
         return st;
 
-    // Straggler hand-off (two passes): in the first pass a tile gives up the syndromes that are
-    // still unconverged once at most `thresh` of its 64 lanes are active; the second pass decodes
-    // them again from scratch, densely packed (same arithmetic => same results), instead of
-    // sweeping nearly empty tiles for the remaining iterations.  Everything stays on the stream:
-    // the second pass reads its syndrome count from device memory.
-    const int thresh = (d->defer_thresh < 0 || d->max_iters < 4 || ntiles < 2) ? 0 : (d->defer_thresh ? d->defer_thresh : 16);
-    const int ntiles2 = thresh ? (int)(((int64_t)ntiles * thresh + kTile - 1) / kTile) + 1 : 0;
-    if (thresh) {
-        if ((st = d->defer_list.ensure((size_t)ntiles2 * kTile * sizeof(int))) != LDPC_OK) return st;
-        if ((st = d->synmask2.ensure(std::max<size_t>((size_t)ntiles2 * s, 1) * sizeof(u64))) != LDPC_OK) return st;
-        if ((st = d->nevermask2.ensure((size_t)ntiles2 * sizeof(u64))) != LDPC_OK) return st;
-        if ((st = d->errmask2.ensure(std::max<size_t>((size_t)ntiles2 * n, 1) * sizeof(u64))) != LDPC_OK) return st;
-        if (want_llr && (st = d->llr_t2.ensure(std::max<size_t>((size_t)ntiles2 * n, 1) * kTile * sizeof(double))) != LDPC_OK)
-            return st;
-        HIP_TRY(hipMemsetAsync(d->nevermask2.p, 0, (size_t)ntiles2 * sizeof(u64), stream));
+    // Straggler hand-off in LEVELS: a tile whose active lanes have dwindled to <= T0 gives those syndromes up
+    // together with their message columns (bp_kernels.hpp: packed tiles of level 1); a pass over level 1 resumes
+    // them where they stood, densely packed again, and may itself hand its stragglers (<= T1 lanes) on to level 2,
+    // whose pass runs them to the end.  Nothing is decoded twice, results are those of an undisturbed run
+    // (the decoder is deterministic per syndrome).  Everything stays on the stream: every pass reads its syndrome
+    // count from device memory, grids are sized for the level's capacity and blocks past the count return at once.
+    // A level that is full refuses further tiles (they carry on by themselves), so capacities are a memory
+    // budget, not a correctness bound.
+    const int T0 = (d->defer_thresh < 0 || d->max_iters < 4 || ntiles < 2) ? 0
+                   : (d->defer_thresh ? d->defer_thresh : d->defer_t0);
+    struct Level {
+        int thresh_in = 0;        // lanes at which the level below hands off into this one
+        int cap_tiles = 0;        // packed tiles it can hold
+        unsigned mult = 1;        // placement of its packed tiles (BPParams::slot_mult)
+        unsigned int *count = nullptr;   // device word: syndromes handed in
+        unsigned int *tile_queue = nullptr, *node_queue = nullptr;
+        unsigned node_take = 0;   // up to this many syndromes: the node-parallel kernel finishes them
+        unsigned team_cap = 0;    // above node_take up to this many: teams of workgroups on the packed tiles
+        int t_per_xcd = 0, t_gcap = 0;
+    } lv[3];
+    int nlevels = 0;
+    if (T0 > 0) {
+        lv[1].thresh_in = T0;
+        const int worst1 = (int)(((int64_t)ntiles * T0 + kTile - 1) / kTile) + 1;
+        lv[1].cap_tiles = d->lvl_cap_force > 0 ? d->lvl_cap_force : std::min(worst1, std::max(8, grid / 3));
+        nlevels = 1;
+        const int T1 = d->defer_t1;
+        if (T1 > 0 && (lv[1].cap_tiles >= 8 || d->lvl_cap_force > 0)) {
+            lv[2].thresh_in = T1;
+            const int worst2 = (int)(((int64_t)lv[1].cap_tiles * T1 + kTile - 1) / kTile) + 1;
+            lv[2].cap_tiles = d->lvl_cap_force > 0 ? d->lvl_cap_force : std::min(worst2, std::max(4, lv[1].cap_tiles / 4));
+            nlevels = 2;
+        }
     }
-    unsigned int *defer_count = (unsigned int *)(ctrl + 4);
-    // Few stragglers (the usual case): the second pass is the node-parallel kernel, one workgroup per
-    // syndrome straight from / into the caller's arrays, instead of a handful of tiles that each sweep
-    // the whole graph with one or two lanes alive.  Decided on the device: the launches of the path not
-    // taken find *defer_count on the wrong side of node_take and return at once.
-    const unsigned node_take = (thresh && d->node_ok && d->variant == 0 && d->node_take_max > 0)
-                                   ? (unsigned)std::min<int64_t>(d->node_take_max, (int64_t)ntiles * thresh) : 0u;
+    lv[1].count = (unsigned int *)(ctrl + 4);   lv[1].tile_queue = (unsigned int *)(ctrl + 40); lv[1].node_queue = (unsigned int *)(ctrl + 48);
+    lv[2].count = (unsigned int *)(ctrl + 56);  lv[2].tile_queue = (unsigned int *)(ctrl + 44); lv[2].node_queue = (unsigned int *)(ctrl + 52);
+    for (int l = 1; l <= nlevels; ++l) {
+        Level &L = lv[l];
+        const size_t ct = (size_t)L.cap_tiles;
+        L.mult = slot_multiplier((unsigned)L.cap_tiles);
+        if ((st = d->lvl_state[l - 1].ensure(ct * slot_stride_bytes)) != LDPC_OK) return st;
+        if ((st = d->lvl_list[l - 1].ensure(ct * kTile * sizeof(int))) != LDPC_OK) return st;
+        if ((st = d->lvl_it[l - 1].ensure(ct * kTile * sizeof(int))) != LDPC_OK) return st;
+        if ((st = d->lvl_syn[l - 1].ensure(std::max<size_t>(ct * s, 1) * sizeof(u64))) != LDPC_OK) return st;
+        if ((st = d->lvl_never[l - 1].ensure(ct * sizeof(u64))) != LDPC_OK) return st;
+        if ((st = d->lvl_err[l - 1].ensure(std::max<size_t>(ct * n, 1) * sizeof(u64))) != LDPC_OK) return st;
+        if (want_llr && (st = d->lvl_llr[l - 1].ensure(std::max<size_t>(ct * n, 1) * kTile * sizeof(double))) != LDPC_OK) return st;
+        HIP_TRY(hipMemsetAsync(d->lvl_never[l - 1].p, 0, ct * sizeof(u64), stream));
+        // Few stragglers (the usual case): the node-parallel kernel finishes them, one workgroup per syndrome
+        // straight from / into the caller's arrays, instead of a handful of tiles that each sweep the whole
+        // graph with a few lanes alive.  Decided on the device: the launches of the paths not taken find the
+        // level's count on the wrong side of node_take / team_cap and return at once.
+        L.node_take = (d->node_ok && d->variant == 0 && d->node_take_max > 0)
+                          ? (unsigned)std::min<int64_t>(d->node_take_max, (int64_t)L.cap_tiles * kTile) : 0u;
+        if (L.node_take && d->max_iters <= 4096 && team_geometry(d, want_llr, &L.t_per_xcd, &L.t_gcap) && L.t_gcap >= 3) {
+            const int tiles_max = std::min(8 * (L.t_per_xcd / 3), L.cap_tiles);   // >= 3 members per tile
+            if ((unsigned)tiles_max * kTile > L.node_take) L.team_cap = (unsigned)tiles_max * kTile;
+        }
+    }
 
     HIP_TRY(hipMemsetAsync(ctrl, 0, 64, stream));
     d->ctrl_clean[slot] = false;
@@ -967,7 +1025,27 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
                            (const unsigned int *)nullptr, 0u);
         HIP_TRY(hipGetLastError());
     }
-    BPParams p;
+    const int *a_row = (const int *)d->row_ptr.p, *a_eb = (const int *)d->edge_bit.p, *a_col = (const int *)d->col_ptr.p,
+              *a_c2r = (const int *)d->csc2csr.p;
+    const unsigned ticket = (unsigned)(d->ncalls & 0x7fffffffu) ? (unsigned)(d->ncalls & 0x7fffffffu) : 0x7fffffffu;
+    // per pass: the hot parameters travel by value (BPParams), the rest in a BPCold block in device memory
+    BPCold cold[3] = {};
+    auto hand_off_into = [&](BPParams &q, BPCold &c, int l) {   // the pass (q, c) hands its stragglers to level l (0 = to nobody)
+        if (l < 1 || l > nlevels) { q.defer_thresh = 0; c.defer_list = nullptr; c.defer_it = nullptr; c.defer_count = nullptr;
+                                    c.next_state = nullptr; c.next_stride = 0; c.next_cap = 0; c.next_mult = 1; c.next_mod = 1; return; }
+        q.defer_thresh = lv[l].thresh_in;
+        c.defer_list = (int *)d->lvl_list[l - 1].p;
+        c.defer_it = (int *)d->lvl_it[l - 1].p;
+        c.defer_count = lv[l].count;
+        c.next_state = (double *)d->lvl_state[l - 1].p;
+        c.next_stride = (long long)(slot_stride_bytes / sizeof(double));
+        c.next_cap = (unsigned)lv[l].cap_tiles * kTile;
+        c.next_mult = lv[l].mult;
+        c.next_mod = (unsigned)lv[l].cap_tiles;
+    };
+    if ((st = d->cold.ensure(3 * sizeof(BPCold))) != LDPC_OK) return st;
+    BPCold *const d_cold = (BPCold *)d->cold.p;
+    BPParams p{};
     p.s = (int)s; p.n = (int)n; p.nnz = (int)d->nnz; p.max_iters = (int)d->max_iters;
     p.ntiles = ntiles; p.batch = batch;
     p.r = d->per / (1 - d->per);  // belief_propagation.jl:129,153 (IEEE double division, same on host)
@@ -975,43 +1053,58 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     p.slot_stride = (long long)(slot_stride_bytes / sizeof(double));
     p.errmask = (u64 *)d->errmask.p;
     p.llr = want_llr ? (double *)d->llr_t.p : nullptr;
-    p.iters = d_iters;
-    p.conv = d_conv;
     p.queue = (unsigned int *)ctrl;
-    p.sum_iters = (u64 *)(ctrl + 8);
-    p.phase_ticks = (u64 *)(ctrl + 16);
-    p.defer_thresh = thresh;
+    p.cold = d_cold + 0;
     p.defer_min_iter = 2;
-    p.defer_max_iter = d->defer_max_iter;
-    p.defer_list = (int *)d->defer_list.p;
-    p.defer_count = defer_count;
-    p.index = nullptr;
     p.count_dev = nullptr;
     p.count_skip = 0;
+    p.resumed = 0;
+    for (BPCold &c : cold) {
+        c.iters = d_iters;
+        c.conv = d_conv;
+        c.sum_iters = (u64 *)(ctrl + 8);
+        c.phase_ticks = (u64 *)(ctrl + 16);
+    }
+    hand_off_into(p, cold[0], 1);
+    for (int l = 1; l <= nlevels; ++l) {
+        BPParams unused{};
+        cold[l].index = (const int *)d->lvl_list[l - 1].p;
+        cold[l].it0 = (const int *)d->lvl_it[l - 1].p;
+        hand_off_into(unused, cold[l], l + 1);
+    }
+    hipLaunchKernelGGL(store_cold_kernel, dim3(1), dim3(64), 0, stream, cold[0], cold[1], cold[2], d_cold);
+    HIP_TRY(hipGetLastError());
+    p.slot_mod = (unsigned)grid;                 // workspace slots: one per workgroup (tile kernel) / per tile (team kernel)
+    p.slot_mult = slot_multiplier((unsigned)grid);
     bp_kernel_t kfn = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, threads);
-    bool team_ran = team > 1;
-    if (team > 1) {
-        const size_t ctl_bytes = (size_t)ntiles * kTeamCtlWords * sizeof(unsigned int);
+    static const int always_release = std::getenv("LDPC_TEAM_ALWAYS_RELEASE") ? 1 : 0;
+    auto team_params = [&](DevBuf &wsbuf, int tiles, TeamParams &tp) -> ldpc_status {
+        const size_t ctl_bytes = (size_t)tiles * kTeamCtlWords * sizeof(unsigned int);
         const size_t mism_stride = ((size_t)d->max_iters + 31) & ~(size_t)31;
-        const size_t ws_bytes = ctl_bytes + (size_t)ntiles * mism_stride * sizeof(u64);
-        if ((st = d->team_ws.ensure(ws_bytes)) != LDPC_OK) return st;
-        HIP_TRY(hipMemsetAsync(d->team_ws.p, 0, ws_bytes, stream));
-        TeamParams tp;
-        tp.G = team;
-        tp.ctl = (unsigned int *)d->team_ws.p;
-        tp.mism = (u64 *)((char *)d->team_ws.p + ctl_bytes);
+        const size_t ws_bytes = ctl_bytes + (size_t)tiles * mism_stride * sizeof(u64);
+        ldpc_status r = wsbuf.ensure(ws_bytes);
+        if (r != LDPC_OK) return r;
+        HIP_TRY(hipMemsetAsync(wsbuf.p, 0, ws_bytes, stream));
+        tp.ctl = (unsigned int *)wsbuf.p;
+        tp.mism = (u64 *)((char *)wsbuf.p + ctl_bytes);
         tp.mism_stride = (int)mism_stride;
         tp.fault = d->team_fault_dev;
-        static const int always_release = std::getenv("LDPC_TEAM_ALWAYS_RELEASE") ? 1 : 0;
         tp.always_release = always_release;
-        tp.scatter = team_scatter ? 1 : 0;
+        tp.scatter = 0;
         tp.count_max = 0;
+        tp.inject_fault = 0;
+        tp.ticket = ticket;
+        return LDPC_OK;
+    };
+    bool team_ran = team > 1;
+    HIP_TRY(hipEventRecord(ev[1], stream));
+    if (team > 1) {
+        TeamParams tp{};
+        if ((st = team_params(d->team_ws, ntiles, tp)) != LDPC_OK) return st;
+        tp.G = team;
+        tp.scatter = team_scatter ? 1 : 0;
         tp.inject_fault = d->inject_fault ? 1 : 0;   // (tests)
-        tp.ticket = (unsigned)(d->ncalls & 0x7fffffffu) ? (unsigned)(d->ncalls & 0x7fffffffu) : 0x7fffffffu;
         team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr);
-        HIP_TRY(hipEventRecord(ev[1], stream));
-        const int *a_row = (const int *)d->row_ptr.p, *a_eb = (const int *)d->edge_bit.p, *a_col = (const int *)d->col_ptr.p,
-                  *a_c2r = (const int *)d->csc2csr.p;
         const u64 *a_syn = (const u64 *)d->synmask.p, *a_nev = (const u64 *)d->nevermask.p;
         void *args[] = {&p, &tp, &a_row, &a_eb, &a_col, &a_c2r, &a_syn, &a_nev};
         const hipError_t te = launch_team_grid(d, tk, team_grid, args, stream);
@@ -1023,7 +1116,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             d->last_kernel = 1; d->last_team = 1; d->last_grid = grid;
             team_ran = false;
         }
-        if (std::getenv("LDPC_TEAM_DEBUG")) {   // diagnostics: which XCDs did the teams land on?
+        if (team_ran && std::getenv("LDPC_TEAM_DEBUG")) {   // diagnostics: which XCDs did the teams land on?
             std::vector<unsigned> xm((size_t)ntiles);
             (void)hipStreamSynchronize(stream);
             for (int t = 0; t < ntiles; ++t)
@@ -1035,73 +1128,54 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         }
     }
     if (!team_ran) {
-        if (team <= 1) HIP_TRY(hipEventRecord(ev[1], stream));
-        hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3((unsigned)threads), 0, stream, p,
-                           (const int *)d->row_ptr.p, (const int *)d->edge_bit.p, (const int *)d->col_ptr.p,
-                           (const int *)d->csc2csr.p, (const u64 *)d->synmask.p, (const u64 *)d->nevermask.p);
+        hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3((unsigned)threads), 0, stream, p, a_row, a_eb, a_col, a_c2r,
+                           (const u64 *)d->synmask.p, (const u64 *)d->nevermask.p);
         HIP_TRY(hipGetLastError());
     }
-    if (thresh) {
-        // second pass over the handed-off syndromes (grids sized for the worst case, blocks past the
-        // device-side count return at once)
+    // ---- passes over the packed levels (tile kernel in place / teams on packed tiles; the node kernel comes last)
+    bp_kernel_t kfn2 = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, threads, true);
+    int occ2 = 1;
+    if (nlevels && (st = d->prepare_kernel((const void *)kfn2, threads, 0, &occ2)) != LDPC_OK) return st;
+    for (int l = 1; l <= nlevels; ++l) {
+        Level &L = lv[l];
+        const u64 *l_syn = (const u64 *)d->lvl_syn[l - 1].p, *l_nev = (const u64 *)d->lvl_never[l - 1].p;
         if (s > 0) {
-            dim3 g((unsigned)((s + 63) / 64), (unsigned)ntiles2);
+            dim3 g((unsigned)((s + 63) / 64), (unsigned)L.cap_tiles);
             hipLaunchKernelGGL(pack_syndromes_kernel, g, dim3(64), 0, stream, d_syn, (long long)0, (int)s,
-                               (u64 *)d->synmask2.p, (u64 *)d->nevermask2.p, (const int *)d->defer_list.p,
-                               (const unsigned int *)defer_count, node_take);
+                               (u64 *)d->lvl_syn[l - 1].p, (u64 *)d->lvl_never[l - 1].p, (const int *)d->lvl_list[l - 1].p,
+                               (const unsigned int *)L.count, L.node_take);
             HIP_TRY(hipGetLastError());
         }
-        // Three regimes for the second pass, told apart on the device by the hand-off count: up to node_take
-        // syndromes the node kernel (below), up to team2_cap teams of workgroups on packed tiles, beyond
-        // that one workgroup per packed tile.
-        unsigned team2_cap = 0;
-        int t2_per_xcd = 0, t2_gcap = 0;
-        if (node_take && d->max_iters <= 4096 && team_geometry(d, want_llr, &t2_per_xcd, &t2_gcap) && t2_gcap >= 3) {
-            const int tiles_max = std::min(std::min(8 * (t2_per_xcd / 3), ntiles2), grid);   // >= 3 members per tile
-            if ((unsigned)tiles_max * kTile > node_take) team2_cap = (unsigned)tiles_max * kTile;
-        }
-        BPParams p2 = p;
-        p2.errmask = (u64 *)d->errmask2.p;
-        p2.llr = want_llr ? (double *)d->llr_t2.p : nullptr;
-        p2.queue = (unsigned int *)(ctrl + 40);
-        p2.defer_thresh = 0;
-        p2.index = (const int *)d->defer_list.p;
-        p2.count_dev = defer_count;
-        p2.count_skip = std::max(node_take, team2_cap);
-        bp_kernel_t kfn2 = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, threads, true);
-        hipLaunchKernelGGL(kfn2, dim3((unsigned)std::min(grid, ntiles2)), dim3((unsigned)threads), 0, stream, p2,
-                           (const int *)d->row_ptr.p, (const int *)d->edge_bit.p, (const int *)d->col_ptr.p,
-                           (const int *)d->csc2csr.p, (const u64 *)d->synmask2.p, (const u64 *)d->nevermask2.p);
+        BPParams q = p;
+        q.msg = (double *)d->lvl_state[l - 1].p;
+        q.errmask = (u64 *)d->lvl_err[l - 1].p;
+        q.llr = want_llr ? (double *)d->lvl_llr[l - 1].p : nullptr;
+        q.queue = L.tile_queue;
+        q.cold = d_cold + l;
+        q.resumed = 1;
+        q.count_dev = L.count;
+        q.count_skip = std::max(L.node_take, L.team_cap);
+        q.slot_mult = L.mult;
+        q.slot_mod = (unsigned)L.cap_tiles;
+        q.defer_min_iter = 1;
+        hand_off_into(q, cold[l], l + 1);   // (sets q.defer_thresh too)
+        const int g2 = std::max(1, std::min(occ2 * d->num_cus, L.cap_tiles));
+        hipLaunchKernelGGL(kfn2, dim3((unsigned)g2), dim3((unsigned)threads), 0, stream, q, a_row, a_eb, a_col, a_c2r, l_syn, l_nev);
         HIP_TRY(hipGetLastError());
-        if (team2_cap) {
-            const int tiles_max = (int)(team2_cap / kTile);
-            const size_t ctl_bytes = (size_t)tiles_max * kTeamCtlWords * sizeof(unsigned int);
-            const size_t mism_stride = ((size_t)d->max_iters + 31) & ~(size_t)31;
-            const size_t ws2 = ctl_bytes + (size_t)tiles_max * mism_stride * sizeof(u64);
-            if ((st = d->team_ws2.ensure(ws2)) != LDPC_OK) return st;
-            HIP_TRY(hipMemsetAsync(d->team_ws2.p, 0, ws2, stream));
-            BPParams p3 = p2;
-            p3.count_skip = node_take;
-            TeamParams tp;
-            tp.G = t2_gcap;
-            tp.ctl = (unsigned int *)d->team_ws2.p;
-            tp.mism = (u64 *)((char *)d->team_ws2.p + ctl_bytes);
-            tp.mism_stride = (int)mism_stride;
-            tp.fault = d->team_fault_dev;
-            tp.always_release = 0;
-            tp.scatter = 0;
-            tp.count_max = team2_cap;
-            tp.inject_fault = 0;
-            tp.ticket = (unsigned)(d->ncalls & 0x7fffffffu) ? (unsigned)(d->ncalls & 0x7fffffffu) : 0x7fffffffu;
+        if (L.team_cap) {
+            BPParams q3 = q;
+            q3.count_skip = L.node_take;
+            TeamParams tp{};
+            if ((st = team_params(d->team_ws_lvl[l - 1], (int)(L.team_cap / kTile), tp)) != LDPC_OK) return st;
+            tp.G = L.t_gcap;
+            tp.count_max = L.team_cap;
             team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr);
-            const int *a_row = (const int *)d->row_ptr.p, *a_eb = (const int *)d->edge_bit.p, *a_col = (const int *)d->col_ptr.p,
-                      *a_c2r = (const int *)d->csc2csr.p;
-            const u64 *a_syn = (const u64 *)d->synmask2.p, *a_nev = (const u64 *)d->nevermask2.p;
-            void *args[] = {&p3, &tp, &a_row, &a_eb, &a_col, &a_c2r, &a_syn, &a_nev};
-            HIP_TRY(launch_team_grid(d, tk, 8 * t2_per_xcd, args, stream));
+            void *args[] = {&q3, &tp, &a_row, &a_eb, &a_col, &a_c2r, &l_syn, &l_nev};
+            HIP_TRY(launch_team_grid(d, tk, 8 * L.t_per_xcd, args, stream));
         }
     }
     HIP_TRY(hipEventRecord(ev[2], stream));
+    // ---- results out: level 0 first, then every level over the rows its lower levels gave up
     if (n > 0) {
         dim3 g((unsigned)((n + 63) / 64), (unsigned)ntiles);
         hipLaunchKernelGGL(unpack_errors_kernel, g, dim3(64), 0, stream, (const u64 *)d->errmask.p,
@@ -1112,21 +1186,24 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
                                (long long)batch, (int)n, d_llr, (const int *)nullptr, (const unsigned int *)nullptr, 0u);
             HIP_TRY(hipGetLastError());
         }
-        if (thresh) {   // the second pass overwrites the rows the first pass gave up
-            dim3 g2((unsigned)((n + 63) / 64), (unsigned)ntiles2);
-            hipLaunchKernelGGL(unpack_errors_kernel, g2, dim3(64), 0, stream, (const u64 *)d->errmask2.p,
-                               (long long)0, (int)n, d_err, (const int *)d->defer_list.p,
-                               (const unsigned int *)defer_count, node_take);
+        for (int l = 1; l <= nlevels; ++l) {
+            dim3 g2((unsigned)((n + 63) / 64), (unsigned)lv[l].cap_tiles);
+            hipLaunchKernelGGL(unpack_errors_kernel, g2, dim3(64), 0, stream, (const u64 *)d->lvl_err[l - 1].p,
+                               (long long)0, (int)n, d_err, (const int *)d->lvl_list[l - 1].p,
+                               (const unsigned int *)lv[l].count, lv[l].node_take);
             HIP_TRY(hipGetLastError());
             if (want_llr) {
-                hipLaunchKernelGGL(unpack_llr_kernel, g2, dim3(256), 0, stream, (const double *)d->llr_t2.p,
-                                   (long long)0, (int)n, d_llr, (const int *)d->defer_list.p,
-                                   (const unsigned int *)defer_count, node_take);
+                hipLaunchKernelGGL(unpack_llr_kernel, g2, dim3(256), 0, stream, (const double *)d->lvl_llr[l - 1].p,
+                                   (long long)0, (int)n, d_llr, (const int *)d->lvl_list[l - 1].p,
+                                   (const unsigned int *)lv[l].count, lv[l].node_take);
                 HIP_TRY(hipGetLastError());
             }
         }
     }
-    if (node_take) {
+    // ---- levels that hold only a few syndromes: the node-parallel kernel resumes each from its packed column
+    for (int l = 1; l <= nlevels; ++l) {
+        Level &L = lv[l];
+        if (!L.node_take) continue;
         const bool mlds = d->node_msg_lds;
         const int msg_mode = mlds ? 1 : (d->node_split_check > 0 ? 2 : 0);
         const int nthreads = msg_mode ? 1024 : 512;   // (global slots: 1024 x 1 per CU measured the same as 512 x 2)
@@ -1135,22 +1212,24 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         node_kernel_t nk = pick_node_kernel(d->max_cdeg, d->max_bdeg, want_llr, nthreads, msg_mode);
         int per_cu_unused = 0;
         if ((st = d->prepare_kernel((const void *)nk, nthreads, nlds, &per_cu_unused)) != LDPC_OK) return st;
-        const int ngrid = (int)std::min<int64_t>((int64_t)node_take, (int64_t)(msg_mode ? 1 : 2) * d->num_cus);
+        const int ngrid = (int)std::min<int64_t>((int64_t)L.node_take, (int64_t)(msg_mode ? 1 : 2) * d->num_cus);
         const size_t stride = (std::max<size_t>((size_t)d->nnz, 1) + 63) & ~(size_t)63;
         if ((st = d->node_msg.ensure(mlds ? 64 : (size_t)ngrid * stride * sizeof(double))) != LDPC_OK) return st;
-        NodeParams np;
+        NodeParams np{};
         np.s = (int)s; np.n = (int)n; np.nnz = (int)d->nnz; np.max_iters = (int)d->max_iters;
         np.batch = 0; np.r = p.r;
         np.syn = d_syn; np.err = d_err; np.conv = d_conv; np.iters = d_iters; np.llr = d_llr;
         np.msg = (double *)d->node_msg.p; np.slot_stride = (long long)stride;
-        np.queue = (unsigned int *)(ctrl + 48);
+        np.queue = L.node_queue;
         np.sum_iters = (u64 *)(ctrl + 8);
-        np.index = (const int *)d->defer_list.p; np.count_dev = defer_count; np.count_max = node_take;
+        np.index = (const int *)d->lvl_list[l - 1].p; np.count_dev = L.count; np.count_max = L.node_take;
+        np.it0 = (const int *)d->lvl_it[l - 1].p;
+        np.state = (const double *)d->lvl_state[l - 1].p;
+        np.state_stride = (long long)(slot_stride_bytes / sizeof(double));
+        np.state_mult = L.mult; np.state_mod = (unsigned)L.cap_tiles;
         np.done_count = nullptr; np.done_flag = nullptr; np.done_ticket = 0; np.next_ctrl = nullptr;
         np.split_check = d->node_split_check; np.split_edge = d->node_split_edge;
-        hipLaunchKernelGGL(nk, dim3((unsigned)ngrid), dim3((unsigned)nthreads), nlds, stream, np,
-                           (const int *)d->row_ptr.p, (const int *)d->edge_bit.p, (const int *)d->col_ptr.p,
-                           (const int *)d->csc2csr.p);
+        hipLaunchKernelGGL(nk, dim3((unsigned)ngrid), dim3((unsigned)nthreads), nlds, stream, np, a_row, a_eb, a_col, a_c2r);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(ev[3], stream));

@@ -57,7 +57,7 @@ def _oracle_subset(H, per, syn_np, threads=12):
             np.concatenate([r[3] for r in res]))
 
 
-@pytest.mark.parametrize("per,subset", [(0.02, 4096), (0.10, 384)])
+@pytest.mark.parametrize("per,subset", [(0.02, 4096), (0.06, 4096), (0.10, 4096)])
 def test_c3_full_batch(ldpc, gpu, per, subset):
     H = ldpc.codes.parity_check_csc(N, WR, WC)
     syn, cols = _device_syndromes(H, per, seed=int(per * 1000))
@@ -74,14 +74,16 @@ def test_c3_full_batch(ldpc, gpu, per, subset):
         assert not bool(conv_b.any())              # above threshold: the full-50 roofline workload
     else:
         assert conv_b.float().mean().item() > 0.99
+    if per == 0.06:                                # the waterfall: thousands of syndromes travel through the packed levels
+        assert 7.5 < its.float().mean().item() < 10
     # (3) geometry / position independence: another waves-per-tile + fewer workspace slots, and a
     #     permuted batch, must give identical per-syndrome results
     perm = torch.randperm(B, device=syn.device, generator=torch.Generator(device=syn.device).manual_seed(1))[:8192]
     e2, c2, i2 = _decode(ldpc, H, per, syn[perm].contiguous(), waves_per_tile=16, resident_tiles=100)
     assert torch.equal(e2, err[perm]) and torch.equal(c2, conv[perm]) and torch.equal(i2, its[perm])
-    # (3b) path independence on the WHOLE batch: auto (tile kernel, stragglers re-decoded by the
-    #      node-parallel kernel) against the forced all-tile path (stragglers re-decoded in packed tiles)
-    e3, c3, i3 = _decode(ldpc, H, per, syn, kernel_variant=1)
+    # (3b) path independence on the WHOLE batch: auto (stragglers handed through the packed levels, finished by
+    #      the node-parallel kernel where few) against the forced all-tile path WITHOUT any hand-off
+    e3, c3, i3 = _decode(ldpc, H, per, syn, kernel_variant=1, defer_threshold=-1)
     assert torch.equal(e3, err) and torch.equal(c3, conv) and torch.equal(i3, its)
     del e3, c3, i3
     # (4) the oracle on a random subset

@@ -153,18 +153,24 @@ def test_c3_code_n16384_small_batch(ldpc, gpu):
             assert not conv.any() and (its == 50).all()
 
 
-@pytest.mark.parametrize("take,team_max", [("8", None), ("8", "1"), ("256", None), (None, None)])
-def test_straggler_handoff_second_pass_kinds(ldpc, gpu, take, team_max, monkeypatch):
-    """A medium batch on a code beyond the LDS, broad iteration distribution: tiles hand their stragglers
-    to a second pass -- decided on the device from their number: the node-parallel kernel up to
-    LDPC_NODE_TAKE_MAX of them, teams of workgroups on packed tiles above that, one workgroup per packed
-    tile where teams are off (LDPC_TEAM_MAX=1) or the stragglers too many.  (take 8: teams / packed
-    tiles; 256 and default: node kernel.)  Every syndrome against the oracle, LLRs included."""
-    if take is not None:
-        monkeypatch.setenv("LDPC_NODE_TAKE_MAX", take)
-    if team_max is not None:
-        monkeypatch.setenv("LDPC_TEAM_MAX", team_max)
-    monkeypatch.setenv("LDPC_DEFER_MAX_ITER", "30")      # the default (8) rarely hands off at this error rate
+@pytest.mark.parametrize("take,team_max,t0,t1,cap", [("8", None, None, None, None), ("8", "1", None, None, None),
+                                                      ("256", None, None, None, None), (None, None, None, None, None),
+                                                      ("8", "1", "40", "40", None), ("8", None, "40", "30", None),
+                                                      ("8", "1", "40", "40", "2"), ("4", "1", "32", "0", None)])
+def test_straggler_handoff_levels_and_pass_kinds(ldpc, gpu, take, team_max, t0, t1, cap, monkeypatch):
+    """A medium batch on a code beyond the LDS, broad iteration distribution: tiles hand their stragglers -- with
+    their message columns -- to packed level 1, whose pass resumes them where they stood and hands ITS stragglers
+    on to level 2.  Which kernel finishes a level is decided on the device from its count: the node-parallel
+    kernel up to LDPC_NODE_TAKE_MAX syndromes, teams of workgroups on the packed tiles above that, one workgroup
+    per packed tile where teams are off (LDPC_TEAM_MAX=1) or the stragglers too many.  (take 8: teams / packed
+    tiles; 256 and default: node kernel.)  t0 / t1: hand-off thresholds of fresh / level-1 tiles (40: most
+    syndromes travel through both levels; t1 = 0: a single level); cap: packed tiles per level, so small that
+    levels fill up and tiles must carry on by themselves.  Every syndrome against the oracle, LLRs and
+    iteration counts included: a resumed syndrome must come out exactly as if nobody had touched it."""
+    for k, v in (("LDPC_NODE_TAKE_MAX", take), ("LDPC_TEAM_MAX", team_max), ("LDPC_DEFER_T0", t0), ("LDPC_DEFER_T1", t1),
+                 ("LDPC_DEFER_CAP_TILES", cap)):
+        if v is not None:
+            monkeypatch.setenv(k, v)
     monkeypatch.setenv("LDPC_NODE_MSG_LDS", "0")         # (by default this code's messages live in LDS and no batch
                                                          # of it ever reaches the tile / team kernels)
     n = 4096
@@ -174,6 +180,8 @@ def test_straggler_handoff_second_pass_kinds(ldpc, gpu, take, team_max, monkeypa
     syn = ldpc.codes.syndromes_of(H, e)
     err, conv, its = assert_parity(ldpc, H, 0.065, 40, syn, kernel_variant=0)
     assert 0.2 < conv.mean() and len(np.unique(its)) > 8   # the hand-off has something to do
+    # the same through the forced tile kernel (fresh tiles by one workgroup each, whatever the batch size)
+    assert_parity(ldpc, H, 0.065, 40, syn[:700], kernel_variant=1)
 
 
 @pytest.mark.parametrize("B,per,scatter", [(640, 0.02, False), (4160, 0.065, False), (3000, 0.10, False),
