@@ -104,7 +104,6 @@ struct BPCold {
     double *next_state;         // [next_cap / 64][next_stride] packed message tiles of the next level
     long long next_stride;      // doubles between two packed tiles (>= nnz * 64)
     unsigned int next_cap;      // syndromes the next level can take; a tile that finds no room carries on by itself
-    unsigned int next_mult, next_mod;   // placement of the next level's packed tiles (see slot_mult)
     // A pass over a packed level (index != nullptr):
     const int *index;           // batch position of compact syndrome q
     const int *it0;             // iterations compact syndrome q has already run (its messages are in its packed tile)
@@ -128,14 +127,6 @@ struct BPParams {
     const unsigned int *count_dev;  // a pass over a packed level: number of compact syndromes (device word; nullptr = p.batch)
     unsigned int count_skip;    // ... do nothing while *count_dev <= count_skip (bp_node_kernels.hpp takes those)
     int resumed;                // 1: a pass over a packed level (cold->index / cold->it0 are set, messages are in the packed tiles)
-    // Slot placement: index x -> slot (x * slot_mult) % slot_mod (32-bit arithmetic; x = blockIdx.x for the tile
-    // kernel on fresh tiles, where a workgroup keeps its slot for the launch; x = the tile for the team kernel and
-    // for passes over a packed level, which work IN PLACE in the level's packed tiles).  Workgroups that are
-    // dispatched together (consecutive blockIdx: they run at the same pace for the whole launch) must NOT sweep
-    // adjacent slots: with slot = blockIdx the sweeps ran 5.2-5.5 TB/s and their speed depended on where the
-    // allocation happened to land, with any permutation that separates neighbours 6.0 TB/s on every allocation
-    // (tools/vmm_probe5.hip; DESIGN.md "Workspace placement").  The same map places the packed tiles of a level.
-    unsigned int slot_mult, slot_mod;
 };
 
 __device__ __forceinline__ u64 wave_or(u64 v)
@@ -373,8 +364,6 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
     const int rot_v = n > 0 ? (int)((blockIdx.x * 2246822519u) % (unsigned)n) : 0;
 #endif
 
-    const unsigned slot0 = (blockIdx.x * p.slot_mult) % p.slot_mod;   // (see BPParams::slot_mult)
-
     long long batch_ = p.batch;
     if (p.count_dev) {
         batch_ = (long long)*p.count_dev;
@@ -390,8 +379,7 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
         if (tile >= ntiles) break;  // every wave of every workgroup reaches this
 
         // fresh tiles: the workgroup's own slot; a packed level (SECOND): the tile's packed tile, in place
-        const unsigned myslot = SECOND ? ((unsigned)tile * p.slot_mult) % p.slot_mod : slot0;
-        double *const Mt = p.msg + (size_t)myslot * (size_t)p.slot_stride + lane;
+        double *const Mt = p.msg + (size_t)(SECOND ? (unsigned)tile : blockIdx.x) * (size_t)p.slot_stride + lane;
         const u64 *syn = synmask + (size_t)tile * s;
         u64 *em = p.errmask + (size_t)tile * n;
         const long long b0 = (long long)tile * kTile;
@@ -498,8 +486,7 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
                 if (base != ~0u) {
                     const bool mine = (active >> lane) & 1ull;
                     const unsigned q = base + (unsigned)__popcll(active & ((1ull << lane) - 1ull));
-                    defer_copy_rows(Mt, cd->next_state + (size_t)(((u64)(q >> 6) * cd->next_mult) % cd->next_mod) * (size_t)cd->next_stride + (q & 63u),
-                                    mine, p.nnz, w, W);
+                    defer_copy_rows(Mt, cd->next_state + (size_t)(q >> 6) * (size_t)cd->next_stride + (q & 63u), mine, p.nnz, w, W);
                     if (w == 0 && mine) {
                         cd->defer_list[q] = resumed ? cd->index[b0 + lane] : (int)(b0 + lane);
                         cd->defer_it[q] = total;

@@ -45,7 +45,6 @@ struct NodeParams {
     const int *it0;
     const double *state;
     long long state_stride;     // doubles between two packed tiles
-    unsigned int state_mult, state_mod;   // packed tile t sits in slot (t * state_mult) % state_mod (BPParams::slot_mult)
     u64 *next_ctrl;             // see LdsParams
     // latency mode (see LdsParams): queue == nullptr, workgroup g decodes syndrome g only
     unsigned int *done_count;
@@ -158,7 +157,7 @@ bp_node_kernel(NodeParams p, const int *__restrict__ row_ptr, const int *__restr
         int it = 0;
         if (resumed) {
             const long long q = sh_q;
-            const double *src = p.state + (size_t)(((u64)(q >> 6) * p.state_mult) % p.state_mod) * (size_t)p.state_stride + (size_t)(q & 63);
+            const double *src = p.state + (size_t)(q >> 6) * (size_t)p.state_stride + (size_t)(q & 63);
             for (int e = tid; e < p.nnz; e += THREADS) {
                 const double v = src[(size_t)e * kTile];
                 if (MSG == 2) { if (e < split_edge) Ml[e] = v; else Mg[e - split_edge] = v; }

@@ -134,7 +134,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     const int rank = tp.scatter ? (int)(blockIdx.x % (unsigned)G) : bq % G;
     if (tile >= ntiles || (p.count_dev && bq >= G * ((ntiles + 7) / 8))) return;   // whole teams only: nobody waits for these
     const int gw = rank * W + w, GW = G * W;                   // this wave among the team's waves
-    double *const Mt = p.msg + (size_t)(((unsigned)tile * p.slot_mult) % p.slot_mod) * (size_t)p.slot_stride + lane;
+    double *const Mt = p.msg + (size_t)tile * (size_t)p.slot_stride + lane;
     unsigned int *const ctr = tp.ctl + (size_t)tile * kTeamCtlWords;
     unsigned int *const xccs = ctr + 32;
     u64 *const mw = tp.mism + (size_t)tile * (size_t)tp.mism_stride;
@@ -252,8 +252,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
                 const unsigned base = told - 1u;
                 const bool mine = (active >> lane) & 1ull;
                 const unsigned q = base + (unsigned)__popcll(active & ((1ull << lane) - 1ull));
-                defer_copy_rows(Mt, cd->next_state + (size_t)(((u64)(q >> 6) * cd->next_mult) % cd->next_mod) * (size_t)cd->next_stride + (q & 63u),
-                                mine, p.nnz, gw, GW);
+                defer_copy_rows(Mt, cd->next_state + (size_t)(q >> 6) * (size_t)cd->next_stride + (q & 63u), mine, p.nnz, gw, GW);
                 if (rank == 0 && w == 0 && mine) {
                     cd->defer_list[q] = resumed ? cd->index[b0 + lane] : (int)(b0 + lane);
                     cd->defer_it[q] = total;

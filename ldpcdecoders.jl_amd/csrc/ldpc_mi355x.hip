@@ -62,10 +62,14 @@ namespace {
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    // virtual-memory backing (ensure_chunked): physical chunks mapped side by side into one reservation
+    std::vector<hipMemGenericAllocationHandle_t> vh;
+    void *vresv = nullptr;
+    size_t vresv_size = 0, vchunk = 0, vmapped = 0;
     ldpc_status ensure(size_t bytes)
     {
         if (bytes <= cap) return LDPC_OK;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        release();
         hipError_t e = hipMalloc(&p, bytes);
         if (e != hipSuccess) {
             (void)hipGetLastError();
@@ -75,9 +79,70 @@ struct DevBuf {
         cap = bytes;
         return LDPC_OK;
     }
+    // The same through the virtual-memory API: physical chunks of `chunk` bytes (hipMemCreate), mapped -- each by
+    // ONE hipMemMap, once, for the life of the buffer -- at a base aligned to `align` inside a reservation of its
+    // own; `shuffle` maps them in a scrambled order.  (How the workspace is backed changes what the sweeps can
+    // stream: DESIGN.md "Workspace placement".)
+    ldpc_status ensure_chunked(size_t bytes, size_t chunk, size_t align, bool shuffle, int device)
+    {
+        if (bytes <= cap) return LDPC_OK;
+        release();
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = device;
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        const size_t n = (bytes + chunk - 1) / chunk;
+        auto bail = [&](const char *what, hipError_t e) {
+            (void)hipGetLastError();
+            release();
+            return fail(e == hipErrorOutOfMemory ? LDPC_ERR_OUT_OF_MEMORY : LDPC_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+        };
+        hipError_t e = hipMemAddressReserve(&vresv, n * chunk + align, 0, nullptr, 0);
+        if (e != hipSuccess) { vresv = nullptr; return bail("hipMemAddressReserve", e); }
+        vresv_size = n * chunk + align;
+        vchunk = chunk;
+        char *base = (char *)(((uintptr_t)vresv + align - 1) / align * align);
+        for (size_t k = 0; k < n; ++k) {
+            hipMemGenericAllocationHandle_t h;
+            if ((e = hipMemCreate(&h, chunk, &prop, 0)) != hipSuccess) return bail("hipMemCreate", e);
+            vh.push_back(h);
+        }
+        std::vector<size_t> order(n);
+        for (size_t k = 0; k < n; ++k) order[k] = k;
+        if (shuffle) {
+            unsigned long long sd = 88172645463325252ull;
+            for (size_t i = n - 1; i > 0; --i) { sd ^= sd << 13; sd ^= sd >> 7; sd ^= sd << 17; std::swap(order[i], order[sd % (i + 1)]); }
+        }
+        p = base;
+        for (size_t k = 0; k < n; ++k) {
+            if ((e = hipMemMap(base + k * chunk, chunk, 0, vh[order[k]], 0)) != hipSuccess) return bail("hipMemMap", e);
+            vmapped = k + 1;
+        }
+        if ((e = hipMemSetAccess(base, n * chunk, &acc, 1)) != hipSuccess) return bail("hipMemSetAccess", e);
+        cap = n * chunk;
+        return LDPC_OK;
+    }
+    void swap(DevBuf &o)
+    {
+        std::swap(p, o.p); std::swap(cap, o.cap); vh.swap(o.vh); std::swap(vresv, o.vresv);
+        std::swap(vresv_size, o.vresv_size); std::swap(vchunk, o.vchunk); std::swap(vmapped, o.vmapped);
+    }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (vresv) {
+            for (size_t k = 0; k < vmapped; ++k) (void)hipMemUnmap((char *)p + k * vchunk, vchunk);   // one unmap per map
+            for (auto h : vh) (void)hipMemRelease(h);
+            (void)hipMemAddressFree(vresv, vresv_size);
+            (void)hipGetLastError();
+            vh.clear();
+            vresv = nullptr;
+            vresv_size = vchunk = vmapped = 0;
+        } else if (p) {
+            (void)hipFree(p);
+        }
         p = nullptr;
         cap = 0;
     }
@@ -255,43 +320,69 @@ static size_t slot_pad_bytes()
     return v;
 }
 
-// Slot placement (BPParams::slot_mult): index x -> slot (x * m) % mod with m coprime to mod, so that workgroups
-// dispatched together do not sweep adjacent slots (tools/vmm_probe5.hip: identity 5.2-5.5 TB/s, any of these
-// multipliers 6.0 TB/s, on every allocation).  Tiny grids keep the identity.
-static unsigned slot_multiplier(unsigned mod)
+// Backing of the big message arrays (the workspace of the tile / team kernels, the packed tiles of the hand-off
+// levels).  C3 full-50, same binary, one process each (tools/ws_alloc_matrix.sh): a plain hipMalloc of the 24.75 GiB
+// workspace runs 1.19 s or 1.42 s per launch depending on what the allocator hands out (the "placement classes" of
+// round 1); the same bytes as 1 GiB hipMemCreate chunks mapped at a 1 GiB-aligned virtual base 1.163 s in every
+// run (shuffled chunk order the same; 64 MiB chunks 1.170-1.179 s, 256 MiB 1.203 s, one 32 GiB handle 1.180 s).
+// What differs is the translation, not the memory: the driver can only use large page-table fragments where the
+// virtual and the physical address are aligned alike, and the sweeps keep ~12,000 distinct 2 MiB pages hot (768
+// slots x 16 rows in flight).  Returns LDPC_ERR_UNSUPPORTED when the request is small (or LDPC_WS_ALLOC=malloc):
+// the caller then uses hipMalloc.
+static ldpc_status big_alloc(DevBuf &b, size_t bytes, int device)
 {
-    static const int forced = [] { const char *e = std::getenv("LDPC_SLOT_MULT"); return e ? std::atoi(e) : 0; }();
-    auto gcd = [](unsigned a, unsigned b) { while (b) { const unsigned t = a % b; a = b; b = t; } return a; };
-    if (forced > 0 && gcd((unsigned)forced, mod) == 1) return (unsigned)forced % std::max(mod, 1u);
-    if (mod < 24) return 1;
-    for (unsigned m : {37u, 101u, 331u, 41u, 43u, 47u, 53u, 59u, 61u, 67u, 71u, 73u, 79u, 83u, 89u, 97u, 13u, 11u})
-        if (m < mod && gcd(m, mod) == 1) return m;
-    return 1;
+    static const std::string ws_alloc = [] { const char *e = std::getenv("LDPC_WS_ALLOC"); return std::string(e ? e : ""); }();
+    if (ws_alloc == "malloc" || bytes < ((size_t)1 << 30)) return LDPC_ERR_UNSUPPORTED;
+    size_t chunk = (size_t)1 << 30;
+    bool shuffle = false;
+    if (ws_alloc.rfind("vmm:", 0) == 0) {
+        chunk = (size_t)std::max(2, std::atoi(ws_alloc.c_str() + 4)) << 20;
+        shuffle = ws_alloc.find(":shuffle") != std::string::npos;
+    }
+    if (bytes <= b.cap) return LDPC_OK;
+    const ldpc_status st = b.ensure_chunked(bytes, chunk, std::max<size_t>(chunk, (size_t)1 << 30), shuffle, device);
+    if (st == LDPC_OK || st == LDPC_ERR_OUT_OF_MEMORY) return st;
+    return LDPC_ERR_UNSUPPORTED;   // the virtual-memory API failed for another reason: fall back to hipMalloc
 }
 
-// Workspace placement: where in HBM the message workspace lands changes what the sweeps can
-// stream by up to 15 % (tools/placement_probe.hip: the same kernels on eight simultaneously held
-// 24.8 GiB allocations ran 4.88 ... 5.62 TB/s, reproducibly per allocation; across processes the same
-// binary measured 1.18 s ... 1.41 s per C3 launch depending on what the allocator handed out).  So a
-// large workspace is chosen among several candidate allocations by a short probe of the variable
-// sweep's access pattern; the others are freed again.  One-time cost at the first big batch:
-// ~25 ms per candidate.  LDPC_PLACEMENT_CANDIDATES=1 turns it off.
+// Workspace placement.  What the sweeps can stream from a C3-size workspace (768 slots x 33 MiB) depends on the
+// PHYSICAL memory behind it, in classes: ~6.0 / ~5.7 / ~5.1 TB/s on the variable sweep's pattern, launches of
+// 1.16 / 1.20 / 1.42 s.  Round 2's probes (tools/vmm_probe*.hip, profiles/README.md) narrowed it down:
+//   * not the virtual address (one physical allocation mapped at 40 bases: identical speed), as long as the base is
+//     aligned like the physical chunks (1 GiB): a base that is only 2 / 4 MiB-aligned costs 3-8 %;
+//   * a property of the physical chunks that stays with them wherever and in whatever order they are mapped, shared
+//     by chunks allocated one after the other (tools/vmm_probe7.hip: group A 5.07, group B 5.72 TB/s; the 25 best
+//     of the 50 = B, the 25 worst = A, each as fast as its group), the same in every slot of the workspace
+//     (tools/vmm_probe6.hip) -- so a search has to look at groups of chunks, not at single ones;
+//   * plain hipMalloc gets the slow class most of the time in a fresh process (5 of 6), 1 GiB chunks at a 1 GiB-
+//     aligned base the fast one most of the time (22 of 26 bench runs on three boxes; never on a fourth).
+// So: the workspace is a group of 1 GiB chunks; it is probed with the variable sweep's pattern (one untimed
+// first-touch pass, one timed pass, ~25 ms); if it is not of the fast class another group is allocated WHILE the
+// candidates so far are held (freed memory would come straight back) and probed, up to LDPC_PLACEMENT_ROUNDS
+// groups (default 4; 1 = take the first) and never beyond half of the free HBM; the best is kept, the others are
+// released.  Transient HBM: 1x when the first group is fast, at most rounds x.  First-call cost 0.1 s per group.
 static ldpc_status ensure_workspace(ldpc_bp_decoder *d, size_t bytes, int grid, size_t slot_stride_bytes,
                                     hipStream_t stream)
 {
     if (bytes <= d->msg.cap) return LDPC_OK;
     d->msg.release();
-    int want = 1;   // (the search is off since the slot permutation made every allocation fast; LDPC_PLACEMENT_CANDIDATES=12 brings it back)
-    if (const char *e = std::getenv("LDPC_PLACEMENT_CANDIDATES")) want = std::max(1, std::atoi(e));
     const bool verbose = std::getenv("LDPC_PLACEMENT_VERBOSE") != nullptr;
-    if (want < 2 || bytes < ((size_t)1 << 30) || d->nnz < 4) return d->msg.ensure(bytes);
+    static const int max_rounds = [] { const char *e = std::getenv("LDPC_PLACEMENT_ROUNDS"); return e ? std::max(1, std::min(8, std::atoi(e))) : 4; }();
+    d->placement_ms = 0.f;
+    d->placement_candidates = 0;
+    DevBuf first;
+    ldpc_status st = big_alloc(first, bytes, d->device);
+    if (st == LDPC_ERR_UNSUPPORTED) return d->msg.ensure(bytes);   // small, or LDPC_WS_ALLOC=malloc
+    if (st != LDPC_OK) return st;
     hipEvent_t ea = nullptr, eb = nullptr;
-    if (hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess) {
+    if (max_rounds < 2 || d->nnz < 4 || grid < 64 || hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess) {
         (void)hipGetLastError();
         if (ea) (void)hipEventDestroy(ea);
-        return d->msg.ensure(bytes);
+        d->msg.swap(first);
+        return LDPC_OK;
     }
     const long long stride = (long long)(slot_stride_bytes / sizeof(double));
+    const double probe_bytes = 2.0 * (double)grid * (double)d->nnz * 512.0;
     auto probe = [&](void *q) -> float {   // ms of one timed pass (after an untimed first-touch pass); <0 on error
         hipLaunchKernelGGL(placement_probe_kernel, dim3((unsigned)grid), dim3(512), 0, stream, (double *)q, stride, (int)d->nnz);
         if (hipEventRecord(ea, stream) != hipSuccess) return -1.f;
@@ -302,71 +393,40 @@ static ldpc_status ensure_workspace(ldpc_bp_decoder *d, size_t bytes, int grid, 
             return -1.f;
         return ms;
     };
-    void *keep = nullptr;      // best allocation so far (held across rounds)
-    float keep_ms = 0.f;
-    int probed = 0;
-    // Round 0 probes as many candidates as fit.  Measured classes on C3: ~8.6 ms (fast, 6.0 TB/s of probe
-    // traffic), ~9.4 ms (5.5), ~10.1 ms (5.1) per probe pass, and a round of nine often holds no fast one
-    // (one box's best was 8.97 ms, "clearly better than the slowest", and the launches took 1.27 s instead
-    // of 1.17 s); so unless the best reaches the fast class in absolute terms (>= 5.95 TB/s: 8.66 ms at C3), further
-    // rounds repeat behind a shim of 1/2, then 1/4 workspace so that the windows fall on other addresses.
-    static const int max_rounds = [] { const char *e = std::getenv("LDPC_PLACEMENT_ROUNDS"); return e ? std::max(1, std::min(8, std::atoi(e))) : 6; }();
-    for (int round = 0; round < max_rounds; ++round) {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); break; }
-        void *shim = nullptr;
-        // shims of 1/2, 1/4, 3/4, 1/8, 3/8, ... workspace move the candidate windows to other addresses
-        static const int shim_eighths[8] = {0, 4, 2, 6, 1, 3, 5, 7};
-        const size_t shim_bytes = bytes / 8 * (size_t)shim_eighths[round & 7];
-        if (shim_bytes && hipMalloc(&shim, shim_bytes) != hipSuccess) { (void)hipGetLastError(); shim = nullptr; }
-        const size_t budget = free_b / 10 * 8 > shim_bytes ? free_b / 10 * 8 - shim_bytes : 0;
-        const int K = std::min<int>(want, (int)(budget / std::max<size_t>(bytes, 1)));
-        std::vector<void *> cand;
-        std::vector<float> ms;
-        for (int k = 0; k < K; ++k) {
-            void *q = nullptr;
-            if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
-            cand.push_back(q);
+    // the fast class in absolute terms (what 512+ streaming workgroups reach: >= 5.95 TB/s of probe traffic; a
+    // smaller grid -- the team kernel's medium batches -- cannot be judged that way and takes the first group)
+    auto fast = [&](float ms) { return ms > 0 && probe_bytes / ((double)ms * 1e-3) >= 5.95e12; };
+    std::vector<DevBuf> held;
+    held.emplace_back();
+    held.back().swap(first);
+    std::vector<float> ms;
+    ms.push_back(probe(held[0].p));
+    if (verbose) std::fprintf(stderr, "[ldpc] workspace group 0 @%p: probe %.3f ms (%.2f TB/s)\n", held[0].p, ms[0], ms[0] > 0 ? probe_bytes / (ms[0] * 1e-3) / 1e12 : 0.0);
+    size_t best = 0;
+    if (grid >= 512) {
+        for (int r = 1; r < max_rounds && !fast(ms[best]); ++r) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); break; }
+            if (bytes > free_b / 2) break;
+            DevBuf cand;
+            if (big_alloc(cand, bytes, d->device) != LDPC_OK) break;
+            held.emplace_back();
+            held.back().swap(cand);
+            ms.push_back(probe(held.back().p));
+            if (verbose) std::fprintf(stderr, "[ldpc] workspace group %d @%p: probe %.3f ms (%.2f TB/s)\n", r, held.back().p, ms.back(),
+                                      ms.back() > 0 ? probe_bytes / (ms.back() * 1e-3) / 1e12 : 0.0);
+            if (ms.back() > 0 && (ms[best] <= 0 || ms.back() < ms[best])) best = held.size() - 1;
         }
-        for (void *q : cand) {
-            const float t = probe(q);
-            ms.push_back(t);
-            if (verbose)
-                std::fprintf(stderr, "[ldpc] workspace round %d candidate @%p: probe %.3f ms (%.2f TB/s)\n", round, q, t,
-                             t > 0 ? 2.0 * (double)grid * (double)d->nnz * 512.0 / (t * 1e-3) / 1e12 : 0.0);
-        }
-        (void)hipStreamSynchronize(stream);
-        int best = -1;
-        for (size_t k = 0; k < cand.size(); ++k)
-            if (ms[k] > 0 && (best < 0 || ms[k] < ms[(size_t)best])) best = (int)k;
-        bool standout = true;
-        if (best >= 0) {
-            if (!keep || ms[(size_t)best] < keep_ms) {
-                if (keep) (void)hipFree(keep);
-                keep = cand[(size_t)best];
-                keep_ms = ms[(size_t)best];
-                cand[(size_t)best] = nullptr;
-            }
-            const double probe_bytes = 2.0 * (double)grid * (double)d->nnz * 512.0;
-            // (the absolute mark is what 512+ streaming workgroups reach; a smaller grid -- the team kernel's
-            // medium batches -- takes the best of two rounds)
-            standout = grid >= 512 ? probe_bytes / ((double)keep_ms * 1e-3) >= 5.95e12 : round >= 1;
-        }
-        probed += (int)cand.size();
-        for (void *q : cand)
-            if (q) (void)hipFree(q);
-        if (shim) (void)hipFree(shim);
-        if (standout || cand.empty()) break;
     }
+    (void)hipStreamSynchronize(stream);
     (void)hipGetLastError();
     (void)hipEventDestroy(ea);
     (void)hipEventDestroy(eb);
-    if (!keep) return d->msg.ensure(bytes);
-    d->msg.p = keep;
-    d->msg.cap = bytes;
-    d->placement_ms = keep_ms;
-    d->placement_candidates = probed;
-    if (verbose) std::fprintf(stderr, "[ldpc] workspace: kept @%p (%.3f ms) out of %d probed\n", keep, keep_ms, probed);
+    d->msg.swap(held[best]);
+    d->placement_ms = ms[best] > 0 ? ms[best] : 0.f;
+    d->placement_candidates = (int)held.size();
+    for (DevBuf &b : held) b.release();
+    if (verbose) std::fprintf(stderr, "[ldpc] workspace: kept group %zu (%.3f ms) out of %zu probed\n", best, d->placement_ms, ms.size());
     return LDPC_OK;
 }
 
@@ -967,7 +1027,6 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     struct Level {
         int thresh_in = 0;        // lanes at which the level below hands off into this one
         int cap_tiles = 0;        // packed tiles it can hold
-        unsigned mult = 1;        // placement of its packed tiles (BPParams::slot_mult)
         unsigned int *count = nullptr;   // device word: syndromes handed in
         unsigned int *tile_queue = nullptr, *node_queue = nullptr;
         unsigned node_take = 0;   // up to this many syndromes: the node-parallel kernel finishes them
@@ -993,8 +1052,9 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     for (int l = 1; l <= nlevels; ++l) {
         Level &L = lv[l];
         const size_t ct = (size_t)L.cap_tiles;
-        L.mult = slot_multiplier((unsigned)L.cap_tiles);
-        if ((st = d->lvl_state[l - 1].ensure(ct * slot_stride_bytes)) != LDPC_OK) return st;
+        if ((st = big_alloc(d->lvl_state[l - 1], ct * slot_stride_bytes, d->device)) == LDPC_ERR_UNSUPPORTED)
+            st = d->lvl_state[l - 1].ensure(ct * slot_stride_bytes);
+        if (st != LDPC_OK) return st;
         if ((st = d->lvl_list[l - 1].ensure(ct * kTile * sizeof(int))) != LDPC_OK) return st;
         if ((st = d->lvl_it[l - 1].ensure(ct * kTile * sizeof(int))) != LDPC_OK) return st;
         if ((st = d->lvl_syn[l - 1].ensure(std::max<size_t>(ct * s, 1) * sizeof(u64))) != LDPC_OK) return st;
@@ -1032,7 +1092,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     BPCold cold[3] = {};
     auto hand_off_into = [&](BPParams &q, BPCold &c, int l) {   // the pass (q, c) hands its stragglers to level l (0 = to nobody)
         if (l < 1 || l > nlevels) { q.defer_thresh = 0; c.defer_list = nullptr; c.defer_it = nullptr; c.defer_count = nullptr;
-                                    c.next_state = nullptr; c.next_stride = 0; c.next_cap = 0; c.next_mult = 1; c.next_mod = 1; return; }
+                                    c.next_state = nullptr; c.next_stride = 0; c.next_cap = 0; return; }
         q.defer_thresh = lv[l].thresh_in;
         c.defer_list = (int *)d->lvl_list[l - 1].p;
         c.defer_it = (int *)d->lvl_it[l - 1].p;
@@ -1040,8 +1100,6 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         c.next_state = (double *)d->lvl_state[l - 1].p;
         c.next_stride = (long long)(slot_stride_bytes / sizeof(double));
         c.next_cap = (unsigned)lv[l].cap_tiles * kTile;
-        c.next_mult = lv[l].mult;
-        c.next_mod = (unsigned)lv[l].cap_tiles;
     };
     if ((st = d->cold.ensure(3 * sizeof(BPCold))) != LDPC_OK) return st;
     BPCold *const d_cold = (BPCold *)d->cold.p;
@@ -1074,8 +1132,6 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     }
     hipLaunchKernelGGL(store_cold_kernel, dim3(1), dim3(64), 0, stream, cold[0], cold[1], cold[2], d_cold);
     HIP_TRY(hipGetLastError());
-    p.slot_mod = (unsigned)grid;                 // workspace slots: one per workgroup (tile kernel) / per tile (team kernel)
-    p.slot_mult = slot_multiplier((unsigned)grid);
     bp_kernel_t kfn = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, threads);
     static const int always_release = std::getenv("LDPC_TEAM_ALWAYS_RELEASE") ? 1 : 0;
     auto team_params = [&](DevBuf &wsbuf, int tiles, TeamParams &tp) -> ldpc_status {
@@ -1155,8 +1211,6 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         q.resumed = 1;
         q.count_dev = L.count;
         q.count_skip = std::max(L.node_take, L.team_cap);
-        q.slot_mult = L.mult;
-        q.slot_mod = (unsigned)L.cap_tiles;
         q.defer_min_iter = 1;
         hand_off_into(q, cold[l], l + 1);   // (sets q.defer_thresh too)
         const int g2 = std::max(1, std::min(occ2 * d->num_cus, L.cap_tiles));
@@ -1226,7 +1280,6 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         np.it0 = (const int *)d->lvl_it[l - 1].p;
         np.state = (const double *)d->lvl_state[l - 1].p;
         np.state_stride = (long long)(slot_stride_bytes / sizeof(double));
-        np.state_mult = L.mult; np.state_mod = (unsigned)L.cap_tiles;
         np.done_count = nullptr; np.done_flag = nullptr; np.done_ticket = 0; np.next_ctrl = nullptr;
         np.split_check = d->node_split_check; np.split_edge = d->node_split_edge;
         hipLaunchKernelGGL(nk, dim3((unsigned)ngrid), dim3((unsigned)nthreads), nlds, stream, np, a_row, a_eb, a_col, a_c2r);
