@@ -102,3 +102,35 @@ def test_device_resident_bposd_pipeline(ldpc, gpu):
         assert np.array_equal(err.cpu().numpy(), ref.T)
         assert np.array_equal(conv.cpu().numpy().astype(bool), rconv)
         assert sent == (20000 if order else int((~rconv).sum()))
+
+
+def test_config5_full_size_bb72_batch_2_pow_20(ldpc, gpu):
+    """BASELINE configs[4] at its stated size: BB [[72,12,6]] H_X, per 0.005, batch 2**20, BP on the GPU + OSD-0 on
+    the host through the device-resident pipeline.  Size-independent properties on the WHOLE batch -- every output
+    reproduces its syndrome (test/test_bposd_decoder.jl:37-47,59-61: OSD always does), `sent` is exactly the number
+    of syndromes BP left unconverged -- and the oracle chain (BP oracle + dense OSD oracle) on a 20,000 subset."""
+    import torch
+
+    B = 1 << 20
+    HX, _ = ldpc.codes.bivariate_bicycle_72_12_6()
+    E = ldpc.codes.random_errors(72, B, 0.005, seed=2026)
+    syn = ldpc.codes.syndromes_of(HX, E)
+    d_syn = torch.from_numpy(syn).to("cuda:0")
+    dec = ldpc.BeliefPropagationOSDDecoder(HX, 0.005, 50, osd_order=0)
+    err, conv, sent = dec.batchdecode_device(d_syn)
+    torch.cuda.synchronize()
+    err = err.cpu().numpy()
+    conv = conv.cpu().numpy()
+    assert sent == int((conv == 0).sum()) and 0 < sent < B // 1000
+    assert np.array_equal(ldpc.codes.syndromes_of(HX, err), syn), "an output does not reproduce its syndrome"
+    # oracle chain on a subset that contains EVERY syndrome BP left unconverged plus random converged ones
+    rng = np.random.default_rng(5)
+    idx = np.unique(np.concatenate([np.nonzero(conv == 0)[0], rng.choice(B, 20000, replace=False)]))
+    M = sp.csc_matrix(HX)
+    oc = BPOracle(csc=(M.indptr, M.indices), shape=M.shape, per=0.005, max_iters=50)
+    oerr, oconv, ollr, _ = oc.batchdecode(syn[idx])
+    assert np.array_equal(conv[idx], oconv)
+    Hd = HX.astype(np.uint8)
+    for k, b in enumerate(idx):
+        ref = oerr[k] if oconv[k] else osd_oracle_postprocess(Hd, syn[b], oerr[k], ollr[k], 0)
+        assert np.array_equal(err[b], ref), f"syndrome {b} differs from the oracle chain"

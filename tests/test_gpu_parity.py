@@ -336,3 +336,63 @@ def test_lost_team_is_reported_or_repaired_never_silent(ldpc, gpu, monkeypatch):
     assert np.array_equal(d_err.cpu().numpy(), oerr) and np.array_equal(d_conv.cpu().numpy(), oconv)
     dec.close()
     monkeypatch.delenv("LDPC_TEAM_INJECT_FAULT")
+
+
+@pytest.mark.parametrize("n,wr,wc", [(16000, 10, 5), (24000, 24, 3)])
+def test_wide_degree_buckets_on_large_codes_small_batches(ldpc, gpu, n, wr, wc):
+    """Codes beyond the LDS whose nodes need the wide register buckets (check degree 10 / bit degree 5: the 16-wide
+    instantiations, 131-167 VGPRs; check degree 24: the 32-wide one, 256 VGPRs -- ONE 8-wave workgroup per CU), nnz >
+    64k, at the batch sizes where the cost model picks teams: a team grid must never be larger than what those
+    instantiations keep resident (round 1 launched 8 x team workgroups for <= 4 tiles and the cooperative launch
+    refused it: a plain decode! failed with LDPC_ERR_HIP).  Batch 1, 64 and 256 against the oracle."""
+    H = ldpc.codes.parity_check_csc(n, wr, wc)
+    assert H.nnz > 64000
+    E = ldpc.codes.random_errors(n, 256, 0.02, seed=n)
+    syn = ldpc.codes.syndromes_of(H, E)
+    for B in (1, 64, 256):
+        for variant in (0, 4):
+            assert_parity(ldpc, H, 0.02, 12, syn[:B], kernel_variant=variant)
+    dec = ldpc.BeliefPropagationDecoder(H, 0.02, 12, kernel_variant=4)
+    dec.decode_batch_host(syn[:64])
+    info = dec.info()
+    assert info.last_kernel == 4 and info.last_team_size >= 3 and info.resident_tiles <= 256   # really a team grid, and resident
+    dec.close()
+
+
+def test_one_handle_driven_from_two_streams_alternately(ldpc, gpu):
+    """Calls on one handle execute in call order whatever streams they are given (include/ldpc_mi355x.h): two
+    non-blocking torch streams alternate on ONE decoder without any host synchronisation in between -- the
+    single-kernel paths rely on the kernel of call N having zeroed the control slot of call N+1, and every path
+    shares the handle's workspace.  LDS kernel (n = 1008), node kernel (n = 16384, 40 syndromes) and team / tile
+    kernel (n = 16384, 700 syndromes): every call's outputs must equal the reference decode."""
+    import torch
+
+    for n, wr, wc, B, per in [(1008, 6, 3, 3000, 0.02), (16384, 8, 4, 40, 0.03), (16384, 8, 4, 700, 0.03)]:
+        H = ldpc.codes.parity_check_csc(n, wr, wc)
+        S = torch.from_numpy(ldpc.codes.syndromes_of(H, ldpc.codes.random_errors(n, 2 * B, per, seed=B))).cuda()
+        dec = ldpc.BeliefPropagationDecoder(H, per, 30)
+        refs = []
+        for half in range(2):
+            e = torch.empty((B, n), dtype=torch.uint8, device="cuda")
+            c = torch.empty(B, dtype=torch.uint8, device="cuda")
+            i = torch.empty(B, dtype=torch.int32, device="cuda")
+            dec.decode_batch_device(S[half * B:(half + 1) * B], e, c, None, i)
+            torch.cuda.synchronize()
+            refs.append((e, c, i))
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        outs = []
+        torch.cuda.synchronize()
+        for k in range(24):
+            half = k % 2 if k % 3 else (k // 3) % 2          # an irregular alternation of inputs ...
+            st = streams[k % 2]                               # ... and a strict alternation of streams
+            e = torch.full((B, n), 9, dtype=torch.uint8, device="cuda")
+            c = torch.full((B,), 9, dtype=torch.uint8, device="cuda")
+            i = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+            st.wait_stream(torch.cuda.current_stream())       # (the fills above ran on the current stream)
+            dec.decode_batch_device(S[half * B:(half + 1) * B], e, c, None, i, stream=st.cuda_stream)
+            outs.append((half, e, c, i))
+        dec.last_status()                                     # waits for the last call, hence for all of them
+        torch.cuda.synchronize()
+        for k, (half, e, c, i) in enumerate(outs):
+            assert torch.equal(e, refs[half][0]) and torch.equal(c, refs[half][1]) and torch.equal(i, refs[half][2]), (n, B, k)
+        dec.close()

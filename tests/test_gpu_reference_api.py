@@ -270,3 +270,76 @@ def test_two_handles_from_two_threads(ldpc, gpu):
     for t in ts:
         t.join()
     assert not errors, errors[:3]
+
+
+def test_two_c3_size_handles_from_two_threads(ldpc, gpu):
+    """Two decoders of the C3 code (n = 16384), each with a full-size batch of its own -- 65,536 syndromes, so each
+    allocates the 24.75 GiB message workspace, the packed hand-off levels, and may run its placement search (up to
+    four 1 GiB-chunk groups held at once, never beyond half of the free HBM) -- created and driven concurrently from
+    two host threads on two streams.  Neither may starve the other of memory, and both must produce what a lone
+    decoder produces."""
+    import threading
+
+    import torch
+
+    n, B = 16384, 65536
+    H = ldpc.codes.parity_check_csc(n, 8, 4)
+    csr = H.tocsr()
+    dev = torch.device("cuda:0")
+    cols = torch.from_numpy(csr.indices.astype(np.int64)).to(dev)
+
+    def make(seed):
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        syn = torch.empty((B, H.shape[0]), dtype=torch.uint8, device=dev)
+        for b0 in range(0, B, 4096):
+            e = (torch.rand((4096, n), generator=g, device=dev) < 0.02).to(torch.uint8)
+            syn[b0:b0 + 4096] = e[:, cols].view(4096, H.shape[0], 8).sum(dim=2, dtype=torch.int32).remainder(2).to(torch.uint8)
+        return syn
+
+    syns = [make(101), make(202)]
+    lone = []
+    for syn in syns:                                   # the reference: one decoder at a time
+        dec = ldpc.BeliefPropagationDecoder(H, 0.02, 50)
+        e = torch.empty((B, n), dtype=torch.uint8, device=dev)
+        c = torch.empty(B, dtype=torch.uint8, device=dev)
+        i = torch.empty(B, dtype=torch.int32, device=dev)
+        dec.decode_batch_device(syn, e, c, None, i)
+        torch.cuda.synchronize()
+        lone.append((c.clone(), i.clone(), e.sum(dim=1, dtype=torch.int32)))
+        del e
+        dec.close()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    errors, results = [], [None, None]
+
+    def worker(k):
+        try:
+            torch.cuda.set_device(0)
+            st = torch.cuda.Stream()
+            dec = ldpc.BeliefPropagationDecoder(H, 0.02, 50)
+            e = torch.empty((B, n), dtype=torch.uint8, device=dev)
+            c = torch.empty(B, dtype=torch.uint8, device=dev)
+            i = torch.empty(B, dtype=torch.int32, device=dev)
+            st.wait_stream(torch.cuda.current_stream())
+            for _ in range(2):
+                dec.decode_batch_device(syns[k], e, c, None, i, stream=st.cuda_stream)
+            dec.last_status()
+            results[k] = (c, i, e.sum(dim=1, dtype=torch.int32))
+            assert dec.info().workspace_bytes > 24 * (1 << 30)
+            dec.close()
+        except Exception as ex:   # noqa: BLE001
+            errors.append(repr(ex))
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for k in range(2):
+        assert all(torch.equal(a, b) for a, b in zip(results[k], lone[k])), k
+    del results, lone
+    torch.cuda.empty_cache()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (2 << 30)     # every group, level and candidate was given back
