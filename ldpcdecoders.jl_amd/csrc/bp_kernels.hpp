@@ -118,7 +118,9 @@ struct BPParams {
     // per-launch buffers
     double *msg;          // [slots][slot_stride]   workspace (fresh tiles) or the packed tiles of a level
     long long slot_stride;  // doubles between consecutive slots (>= nnz*64)
-    u64 *errmask;         // [ntiles][n]
+    u64 *errmask;         // [ntiles][n]  hard decisions of the current iteration, every lane (bit l = syndrome 64*tile + l)
+    u64 *finmask;         // [ntiles][n]  ... of the iteration at which each lane stopped (converged / out of iterations):
+                          //              what the caller gets.  Captured from errmask when a lane stops.
     double *llr;          // [ntiles][n][64] or nullptr
     unsigned int *queue;  // tile queue head
     const BPCold *cold;   // everything touched once per tile (device memory)
@@ -128,6 +130,12 @@ struct BPParams {
     unsigned int count_skip;    // ... do nothing while *count_dev <= count_skip (bp_node_kernels.hpp takes those)
     int resumed;                // 1: a pass over a packed level (cold->index / cold->it0 are set, messages are in the packed tiles)
 };
+
+// a value known to be the same in every lane -> scalar registers
+__device__ __forceinline__ u64 uniform64(u64 v)
+{
+    return ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffu));
+}
 
 __device__ __forceinline__ u64 wave_or(u64 v)
 {
@@ -382,6 +390,7 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
         double *const Mt = p.msg + (size_t)(SECOND ? (unsigned)tile : blockIdx.x) * (size_t)p.slot_stride + lane;
         const u64 *syn = synmask + (size_t)tile * s;
         u64 *em = p.errmask + (size_t)tile * n;
+        u64 *fin = p.finmask + (size_t)tile * n;
         const long long b0 = (long long)tile * kTile;
         const long long left = batch - b0;
         u64 deferred = 0;
@@ -422,18 +431,21 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
                     if ((active >> lane) & 1ull)
                         p.llr[((size_t)tile * n + j) * kTile + lane] = log(1.0 / T);  // :163
                 }
-                if (lane == 0) {
-                    u64 v = dec;
-                    if (active != ~0ull) v = (em[j] & ~active) | (dec & active);  // frozen lanes keep theirs
-                    em[j] = v;
-                }
+                if (lane == 0) em[j] = dec;   // every lane, also the stopped ones: theirs were captured when they stopped
             };
-            for (int j0 = w; j0 < n; j0 += W) {
+            auto rotated_bit = [&](int j0) {
 #if LDPC_ROTATE
-                const int j = (j0 + rot_v >= n) ? j0 + rot_v - n : j0 + rot_v;
+                return (j0 + rot_v >= n) ? j0 + rot_v - n : j0 + rot_v;
 #else
-                const int j = j0;
+                return j0;
 #endif
+            };
+            // (requesting the rows of the NEXT bit before this one is finished -- 8 rows in flight per wave instead of
+            // 4 behind two scalar index loads -- was built and measured in round 2: the variable sweep's share fell
+            // from 59 % to 49 %, the check sweep's rose by as much, and the launch took 1156 instead of 1158 ms: the
+            // three workgroups of a CU sit in different phases and the memory system is what they share.  Removed.)
+            for (int j0 = w; j0 < n; j0 += W) {
+                const int j = rotated_bit(j0);
                 const int c0 = col_ptr[j];
                 const int deg = col_ptr[j + 1] - c0;
                 finish_bit(j, bit_update<DV>(Mt, csc2csr + c0, deg, r));
@@ -465,6 +477,7 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
             u64 U = never;
 #pragma unroll
             for (int q = 0; q < W; ++q) U |= sh_mism[q];
+            U = uniform64(U);   // the same in every lane: keep it, and the lane masks derived from it, in scalar registers
             const int total = it0 + it;                      // iterations of this lane's syndrome so far
             const u64 newly = active & ~U;
             if ((newly >> lane) & 1ull) { my_iters = total; my_conv = 1; }
@@ -474,6 +487,12 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
             const u64 spent = __ballot(total >= p.max_iters) & active;
             if ((spent >> lane) & 1ull) { my_iters = total; my_conv = 0; }
             active &= ~spent;
+            // the lanes that stop here keep the decisions of THIS iteration (the reference breaks at :183 / leaves the
+            // loop at :134): capture their columns (lane = bit, 64 words per wave step)
+            const u64 stopped = newly | spent;
+            if (stopped != 0) {
+                for (int j = w * 64 + lane; j < n; j += W * 64) fin[j] = (fin[j] & ~stopped) | (em[j] & stopped);
+            }
             const u64 t3 = wall_clock64();
             tk_check += t1 - t0; tk_var += t2 - t1; tk_conv += t3 - t2;
             // few stragglers left: hand them -- with their messages -- to the next level instead of sweeping a
@@ -485,7 +504,7 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
                 const unsigned base = sh_base;
                 if (base != ~0u) {
                     const bool mine = (active >> lane) & 1ull;
-                    const unsigned q = base + (unsigned)__popcll(active & ((1ull << lane) - 1ull));
+                    const unsigned q = base + __builtin_amdgcn_mbcnt_hi((unsigned)(active >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)active, 0u));   // + active lanes below this one
                     defer_copy_rows(Mt, cd->next_state + (size_t)(q >> 6) * (size_t)cd->next_stride + (q & 63u), mine, p.nnz, w, W);
                     if (w == 0 && mine) {
                         cd->defer_list[q] = resumed ? cd->index[b0 + lane] : (int)(b0 + lane);

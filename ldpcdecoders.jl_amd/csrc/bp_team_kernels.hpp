@@ -149,6 +149,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
 
     const u64 *syn = synmask + (size_t)tile * s;
     u64 *em = p.errmask + (size_t)tile * n;
+    u64 *fin = p.finmask + (size_t)tile * n;
     const long long b0 = (long long)tile * kTile;
     const long long left = batch - b0;
     u64 deferred = 0;
@@ -194,11 +195,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
             if (WANT_LLR) {
                 if ((active >> lane) & 1ull) p.llr[((size_t)tile * n + j) * kTile + lane] = log(1.0 / T);  // :163
             }
-            if (lane == 0) {
-                u64 v = dec;
-                if (active != ~0ull) v = (em[j] & ~active) | (dec & active);  // frozen lanes keep theirs (own earlier store)
-                em[j] = v;
-            }
+            if (lane == 0) em[j] = dec;   // every lane; the stopped ones' decisions were captured when they stopped
         }
         const u64 t3 = wall_clock64();
         if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd)) return;
@@ -229,7 +226,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
             if (part) __hip_atomic_fetch_or(&mw[it - 1], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd)) return;
-        const u64 U = never | __hip_atomic_load(&mw[it - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 U = uniform64(never | __hip_atomic_load(&mw[it - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         const int total = it0 + it;                            // iterations of this lane's syndrome so far
         const u64 newly = active & ~U;
         if ((newly >> lane) & 1ull) { my_iters = total; my_conv = 1; }
@@ -237,6 +234,13 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
         const u64 spent = __ballot(total >= p.max_iters) & active;   // out of iterations: retires unconverged
         if ((spent >> lane) & 1ull) { my_iters = total; my_conv = 0; }
         active &= ~spent;
+        // capture the stopping lanes' decisions of this iteration (every member its share of the bits; the decision
+        // words were made visible by the barrier before the test, and nobody rewrites them before the barrier
+        // after the next check sweep, which this member only joins when it is through here)
+        const u64 stopped = newly | spent;
+        if (stopped != 0) {
+            for (int j = gw * 64 + lane; j < n; j += GW * 64) fin[j] = (fin[j] & ~stopped) | (em[j] & stopped);
+        }
         const u64 t4 = wall_clock64();
         tk_check += t1 - t0; tk_var += t3 - t2; tk_rest += (t2 - t1) + (t4 - t3);   // rest = barriers + test
         // few stragglers left: hand them, with their messages, to the next level (decided alike by every member;
@@ -251,7 +255,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
             if (told != 0u) {                                  // (0 = ~0u + 1: the next level is full, carry on)
                 const unsigned base = told - 1u;
                 const bool mine = (active >> lane) & 1ull;
-                const unsigned q = base + (unsigned)__popcll(active & ((1ull << lane) - 1ull));
+                const unsigned q = base + __builtin_amdgcn_mbcnt_hi((unsigned)(active >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)active, 0u));   // + active lanes below this one
                 defer_copy_rows(Mt, cd->next_state + (size_t)(q >> 6) * (size_t)cd->next_stride + (q & 63u), mine, p.nnz, gw, GW);
                 if (rank == 0 && w == 0 && mine) {
                     cd->defer_list[q] = resumed ? cd->index[b0 + lane] : (int)(b0 + lane);

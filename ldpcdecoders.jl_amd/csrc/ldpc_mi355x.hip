@@ -135,7 +135,11 @@ struct DevBuf {
         if (vresv) {
             for (size_t k = 0; k < vmapped; ++k) (void)hipMemUnmap((char *)p + k * vchunk, vchunk);   // one unmap per map
             for (auto h : vh) (void)hipMemRelease(h);
-            (void)hipMemAddressFree(vresv, vresv_size);
+            // The reservation is deliberately NOT given back (hipMemAddressFree): a later reservation would be handed
+            // the same addresses, and a kernel touching a range that has been mapped, unmapped and mapped again
+            // faults now and then on ROCm 7.2 ("Memory access fault ... Reason: Unknown": tools/vmm_probe2.hip, and
+            // the GPU test suite when decoders of large codes came and went in one process).  Address space is not
+            // memory: a reservation of an unmapped range costs nothing, and 47 bits hold thousands of them.
             (void)hipGetLastError();
             vh.clear();
             vresv = nullptr;
@@ -211,10 +215,10 @@ struct ldpc_bp_decoder {
     DevBuf ctrl;              // queue (u32) + sum_iters (u64), 64 B
     DevBuf cold;              // BPCold blocks of the passes of the call in flight (bp_kernels.hpp)
     // per-batch buffers (grow only)
-    DevBuf synmask, nevermask, errmask, llr_t;
+    DevBuf synmask, nevermask, errmask, finmask, llr_t;
     // packed levels of the straggler hand-off (decode_device_impl): message tiles, batch positions, iteration
     // counts, and the per-level images of the per-batch buffers above
-    DevBuf lvl_state[2], lvl_list[2], lvl_it[2], lvl_syn[2], lvl_never[2], lvl_err[2], lvl_llr[2];
+    DevBuf lvl_state[2], lvl_list[2], lvl_it[2], lvl_syn[2], lvl_never[2], lvl_err[2], lvl_fin[2], lvl_llr[2];
     int defer_thresh = 0;     // 0 auto (16 lanes), -1 off, else the lane count at which a tile gives up
     int defer_t0 = 16, defer_t1 = 16;   // lanes at which a fresh tile / a packed tile of level 1 hands off (LDPC_DEFER_T0 / _T1 at create; T1 0 = one level)
     int lvl_cap_force = 0;    // tests (LDPC_DEFER_CAP_TILES at create): packed tiles per level, so that full levels are exercised
@@ -250,10 +254,10 @@ struct ldpc_bp_decoder {
     ~ldpc_bp_decoder()
     {
         DevBuf *all[] = {&row_ptr, &edge_bit, &col_ptr, &csc2csr, &msg, &ctrl, &synmask, &nevermask,
-                         &errmask, &llr_t, &st_all, &node_msg, &done_ctr, &team_ws, &team_ws_lvl[0], &team_ws_lvl[1], &cold};
+                         &errmask, &finmask, &llr_t, &st_all, &node_msg, &done_ctr, &team_ws, &team_ws_lvl[0], &team_ws_lvl[1], &cold};
         for (DevBuf *b : all) b->release();
         for (int l = 0; l < 2; ++l)
-            for (DevBuf *b : {&lvl_state[l], &lvl_list[l], &lvl_it[l], &lvl_syn[l], &lvl_never[l], &lvl_err[l], &lvl_llr[l]}) b->release();
+            for (DevBuf *b : {&lvl_state[l], &lvl_list[l], &lvl_it[l], &lvl_syn[l], &lvl_never[l], &lvl_err[l], &lvl_fin[l], &lvl_llr[l]}) b->release();
         if (pin) (void)hipHostFree(pin);
         if (lat_pin) (void)hipHostFree(lat_pin);
         if (team_fault) (void)hipHostFree(team_fault);
@@ -650,9 +654,9 @@ ldpc_status ldpc_bp_get_info(const ldpc_bp_decoder *d, ldpc_bp_info *info)
     info->device = d->device; info->tile_syndromes = kTile; info->waves_per_tile = d->last_threads / 64;
     info->resident_tiles = d->last_grid;
     const DevBuf *all[] = {&d->row_ptr, &d->edge_bit, &d->col_ptr, &d->csc2csr, &d->msg, &d->ctrl, &d->synmask,
-                           &d->nevermask, &d->errmask, &d->llr_t, &d->st_all, &d->node_msg, &d->pipe_dev[0], &d->pipe_dev[1], &d->pipe_dev[2],
+                           &d->nevermask, &d->errmask, &d->finmask, &d->llr_t, &d->st_all, &d->node_msg, &d->pipe_dev[0], &d->pipe_dev[1], &d->pipe_dev[2],
                            &d->lvl_state[0], &d->lvl_state[1], &d->lvl_list[0], &d->lvl_list[1], &d->lvl_it[0], &d->lvl_it[1],
-                           &d->lvl_syn[0], &d->lvl_syn[1], &d->lvl_never[0], &d->lvl_never[1], &d->lvl_err[0], &d->lvl_err[1],
+                           &d->lvl_syn[0], &d->lvl_syn[1], &d->lvl_never[0], &d->lvl_never[1], &d->lvl_err[0], &d->lvl_err[1], &d->lvl_fin[0], &d->lvl_fin[1],
                            &d->lvl_llr[0], &d->lvl_llr[1]};
     for (const DevBuf *b : all) info->workspace_bytes += (int64_t)b->cap;
     info->last_kernel = d->last_kernel;
@@ -967,6 +971,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     if ((st = d->synmask.ensure(std::max<size_t>((size_t)ntiles * s, 1) * sizeof(u64))) != LDPC_OK) return st;
     if ((st = d->nevermask.ensure((size_t)ntiles * sizeof(u64))) != LDPC_OK) return st;
     if ((st = d->errmask.ensure(std::max<size_t>((size_t)ntiles * n, 1) * sizeof(u64))) != LDPC_OK) return st;
+    if ((st = d->finmask.ensure(std::max<size_t>((size_t)ntiles * n, 1) * sizeof(u64))) != LDPC_OK) return st;
     if (want_llr && (st = d->llr_t.ensure(std::max<size_t>((size_t)ntiles * n, 1) * kTile * sizeof(double))) != LDPC_OK)
         return st;
     // Geometry of this launch: 8 waves per tile (three workgroups per CU) is the measured best
@@ -1060,6 +1065,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         if ((st = d->lvl_syn[l - 1].ensure(std::max<size_t>(ct * s, 1) * sizeof(u64))) != LDPC_OK) return st;
         if ((st = d->lvl_never[l - 1].ensure(ct * sizeof(u64))) != LDPC_OK) return st;
         if ((st = d->lvl_err[l - 1].ensure(std::max<size_t>(ct * n, 1) * sizeof(u64))) != LDPC_OK) return st;
+        if ((st = d->lvl_fin[l - 1].ensure(std::max<size_t>(ct * n, 1) * sizeof(u64))) != LDPC_OK) return st;
         if (want_llr && (st = d->lvl_llr[l - 1].ensure(std::max<size_t>(ct * n, 1) * kTile * sizeof(double))) != LDPC_OK) return st;
         HIP_TRY(hipMemsetAsync(d->lvl_never[l - 1].p, 0, ct * sizeof(u64), stream));
         // Few stragglers (the usual case): the node-parallel kernel finishes them, one workgroup per syndrome
@@ -1110,6 +1116,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     p.msg = (double *)d->msg.p;
     p.slot_stride = (long long)(slot_stride_bytes / sizeof(double));
     p.errmask = (u64 *)d->errmask.p;
+    p.finmask = (u64 *)d->finmask.p;
     p.llr = want_llr ? (double *)d->llr_t.p : nullptr;
     p.queue = (unsigned int *)ctrl;
     p.cold = d_cold + 0;
@@ -1205,6 +1212,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         BPParams q = p;
         q.msg = (double *)d->lvl_state[l - 1].p;
         q.errmask = (u64 *)d->lvl_err[l - 1].p;
+        q.finmask = (u64 *)d->lvl_fin[l - 1].p;
         q.llr = want_llr ? (double *)d->lvl_llr[l - 1].p : nullptr;
         q.queue = L.tile_queue;
         q.cold = d_cold + l;
@@ -1232,7 +1240,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     // ---- results out: level 0 first, then every level over the rows its lower levels gave up
     if (n > 0) {
         dim3 g((unsigned)((n + 63) / 64), (unsigned)ntiles);
-        hipLaunchKernelGGL(unpack_errors_kernel, g, dim3(64), 0, stream, (const u64 *)d->errmask.p,
+        hipLaunchKernelGGL(unpack_errors_kernel, g, dim3(64), 0, stream, (const u64 *)d->finmask.p,
                            (long long)batch, (int)n, d_err, (const int *)nullptr, (const unsigned int *)nullptr, 0u);
         HIP_TRY(hipGetLastError());
         if (want_llr) {
@@ -1242,7 +1250,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         }
         for (int l = 1; l <= nlevels; ++l) {
             dim3 g2((unsigned)((n + 63) / 64), (unsigned)lv[l].cap_tiles);
-            hipLaunchKernelGGL(unpack_errors_kernel, g2, dim3(64), 0, stream, (const u64 *)d->lvl_err[l - 1].p,
+            hipLaunchKernelGGL(unpack_errors_kernel, g2, dim3(64), 0, stream, (const u64 *)d->lvl_fin[l - 1].p,
                                (long long)0, (int)n, d_err, (const int *)d->lvl_list[l - 1].p,
                                (const unsigned int *)lv[l].count, lv[l].node_take);
             HIP_TRY(hipGetLastError());
