@@ -81,6 +81,16 @@ function MI355XBeliefPropagationDecoder(H, per::Float64, max_iters::Int; device:
     return d
 end
 
+"""
+    last_status(d)
+
+Waits for everything enqueued on the handle and throws if a team of workgroups lost a member in one of
+those calls (`ldpc_bp_last_status`, include/ldpc_mi355x.h).  Only callers of the asynchronous device entry
+need it; `decode!` / `batchdecode!` above use the synchronous host entry, which repairs such a call itself.
+"""
+last_status(d::MI355XBeliefPropagationDecoder) =
+    check(ccall((:ldpc_bp_last_status, libldpc), Cint, (Ptr{Cvoid},), d.handle))
+
 "`(-1)^x` only needs the parity; anything but 0/1 must never match the convergence `==` (:136,:181)."
 @inline function syndrome_byte(x)::UInt8
     v = Int(x)                      # InexactError for non-integral floats, like (-1)^2.5 -> DomainError

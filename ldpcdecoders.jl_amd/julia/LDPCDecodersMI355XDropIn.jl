@@ -1,0 +1,115 @@
+# LDPCDecodersMI355XDropIn.jl -- the SAME-NAME drop-in: after
+#
+#     using LDPCDecoders
+#     include(".../ldpcdecoders.jl_amd/julia/LDPCDecodersMI355XDropIn.jl")
+#
+# every `LDPCDecoders.BeliefPropagationDecoder` -- the reference's own type, constructed by the reference's own
+# constructor (src/decoders/belief_propagation.jl:61-67) -- decodes on the MI355X: this file OVERWRITES the two
+# methods that are the hot path,
+#
+#     decode!(::BeliefPropagationDecoder, syndrome)                          belief_propagation.jl:121-188
+#     batchdecode!(::BeliefPropagationDecoder, syndromes, errors, success)   belief_propagation.jl:220-231
+#
+# and nothing else.  Because the TYPE is untouched, everything that holds one keeps working without an edit:
+# `BeliefPropagationOSDDecoder` (its field is concretely typed, belief_propagation_osd.jl:19, and it reads
+# `bp_decoder.scratch.log_probabs`, :52 -- filled here), the generic 3-argument `batchdecode!`
+# (abstract_decoder.jl:44-48), QuantumClifford's extension.  `reset!` stays the reference's (:83-91): it clears the
+# host scratch, which decode! below refills; the device state is reset inside every call.
+#
+# NOT EXECUTED in this repository's pipeline (no Julia runtime in the image); LDPCDecodersMI355X.jl next to it is the
+# conservative alternative with types of its own.  Overwriting another module's methods is deliberate here; Julia
+# forbids it during precompilation, hence `include` at run time rather than a package (or `__precompile__(false)`).
+module LDPCDecodersMI355XDropIn
+
+using SparseArrays
+import LDPCDecoders
+import LDPCDecoders: BeliefPropagationDecoder
+
+const libldpc = get(ENV, "LDPC_MI355X_LIB", "libldpc_mi355x.so")
+
+function check(status::Cint)
+    status == 0 && return nothing
+    msg = unsafe_string(ccall((:ldpc_last_error, libldpc), Cstring, ()))
+    status == 1 && throw(ArgumentError(msg))
+    error("libldpc_mi355x: status $status: $msg")
+end
+
+mutable struct Handle
+    ptr::Ptr{Cvoid}
+    syn_u8::Vector{UInt8}
+    err_u8::Vector{UInt8}
+    conv_u8::Vector{UInt8}
+end
+
+# one library handle per reference decoder object, created at its first decode and destroyed with it
+const HANDLES = WeakKeyDict{BeliefPropagationDecoder,Handle}()
+const HANDLES_LOCK = ReentrantLock()
+
+function handle_of(d::BeliefPropagationDecoder)
+    lock(HANDLES_LOCK) do
+        get!(HANDLES, d) do
+            colptr = Int64.(d.sparse_H.colptr .- 1)          # zero-based CSC pattern of sparse(H) (:63)
+            rowval = Int64.(rowvals(d.sparse_H) .- 1)
+            h = Ref{Ptr{Cvoid}}(C_NULL)
+            check(ccall((:ldpc_bp_create, libldpc), Cint,
+                        (Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Float64, Int64, Ptr{Int32}, Ptr{Ptr{Cvoid}}),
+                        d.s, d.n, length(rowval), colptr, rowval, d.per, d.max_iters, C_NULL, h))
+            hd = Handle(h[], UInt8[], UInt8[], UInt8[])
+            finalizer(hd) do x
+                x.ptr != C_NULL && ccall((:ldpc_bp_destroy, libldpc), Cint, (Ptr{Cvoid},), x.ptr)
+                x.ptr = C_NULL
+            end
+            hd
+        end
+    end
+end
+
+@inline function syndrome_byte(x)::UInt8                      # (-1)^x needs the parity only (:136); 0/1 alone can match (:181)
+    v = Int(x)
+    (v == 0 || v == 1) ? UInt8(v) : UInt8(2 + (v & 1))
+end
+
+function LDPCDecoders.decode!(d::BeliefPropagationDecoder, syndrome::AbstractVector)       # overwrites :121-188
+    length(syndrome) == d.s || throw(BoundsError(syndrome, d.s))
+    LDPCDecoders.reset!(d)                                                                 # :122
+    h = handle_of(d)
+    resize!(h.syn_u8, d.s); resize!(h.err_u8, d.n); resize!(h.conv_u8, 1)
+    @inbounds for i in 1:d.s
+        h.syn_u8[i] = syndrome_byte(syndrome[i])
+    end
+    check(ccall((:ldpc_bp_decode_batch, libldpc), Cint,
+                (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{UInt8}, Ptr{UInt8}, Ptr{Float64}, Ptr{Int32}),
+                h.ptr, 1, h.syn_u8, h.err_u8, h.conv_u8, d.scratch.log_probabs, C_NULL))
+    @inbounds for j in 1:d.n
+        d.scratch.err[j] = h.err_u8[j]
+    end
+    return d.scratch.err, h.conv_u8[1] != 0                                                # the alias of :187
+end
+
+function LDPCDecoders.batchdecode!(d::BeliefPropagationDecoder, syndromes::AbstractMatrix,
+                                   errors::AbstractMatrix, success::AbstractVector{Bool})   # overwrites :220-231
+    @assert size(syndromes, 2) == size(errors, 2)                                          # :221
+    @assert size(syndromes, 2) == length(success)                                          # :222
+    B = size(syndromes, 2)
+    B == 0 && return errors, success
+    h = handle_of(d)
+    resize!(h.syn_u8, d.s * B); resize!(h.err_u8, d.n * B); resize!(h.conv_u8, B)
+    @inbounds for i in 1:B, r in 1:d.s
+        h.syn_u8[(i - 1) * d.s + r] = syndrome_byte(syndromes[r, i])
+    end
+    check(ccall((:ldpc_bp_decode_batch, libldpc), Cint,
+                (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{UInt8}, Ptr{UInt8}, Ptr{Float64}, Ptr{Int32}),
+                h.ptr, B, h.syn_u8, h.err_u8, h.conv_u8, C_NULL, C_NULL))
+    @inbounds for i in 1:B
+        success[i] = h.conv_u8[i] != 0                                                     # :226
+        for j in 1:d.n
+            errors[j, i] = h.err_u8[(i - 1) * d.n + j]                                     # :227
+        end
+    end
+    # the reference leaves the scratch holding the last column's state; callers that read it after a batch
+    # (none in the reference) get it from one more single decode of that column
+    LDPCDecoders.decode!(d, view(syndromes, :, B))
+    return errors, success                                                                 # :230
+end
+
+end # module
