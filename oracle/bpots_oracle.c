@@ -18,7 +18,19 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* Two builds of this one file:
+ *   libbpots_oracle.so       tanh / atanh = the portable implementations the HIP kernel uses too: CPU and GPU take
+ *                            identical data-dependent decisions, so the GPU tests can demand bit-equality;
+ *   libbpots_oracle_libm.so  (-DBPOTS_ORACLE_LIBM) tanh / atanh = the host's libm, sharing NOTHING with the product:
+ *                            the independent witness.  Julia's own tanh / atanh are a third correctly rounded-to-~1-ulp
+ *                            pair; tests/test_bpots_oracle.py measures how often the two builds reach different
+ *                            estimates on the reference's test codes -- the size of the band any such pair lives in. */
+#ifdef BPOTS_ORACLE_LIBM
+#define pm_tanh tanh
+#define pm_atanh atanh
+#else
 #include "../ldpcdecoders.jl_amd/csrc/portable_math.h"
+#endif
 
 typedef struct {
     int64_t s, n, nnz, max_iters, T;
@@ -172,8 +184,10 @@ void bpots_oracle_decode_batch(bpots_oracle *d, int64_t B, const uint8_t *syndro
     }
 }
 
+#ifndef BPOTS_ORACLE_LIBM
 /* the portable functions, exported for tests (accuracy vs libm; the Python restatement uses them too) */
 double pm_tanh_export(double x) { return pm_tanh(x); }
 double pm_atanh_export(double x) { return pm_atanh(x); }
 double pm_exp_export(double x) { return pm_exp(x); }
 double pm_log_export(double x) { return pm_log(x); }
+#endif
