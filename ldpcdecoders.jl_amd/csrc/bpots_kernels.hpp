@@ -316,4 +316,230 @@ bpots_lds_kernel(OtsParams p, const int *__restrict__ g_row_ptr, const int *__re
     if (p.done_flag) publish_done(p.done_count, p.done_flag, p.done_ticket);
 }
 
+// ---------------------------------------------------------------------------------------------
+// BP-OTS for graphs beyond the LDS: one workgroup per syndrome, one thread per Tanner-graph node (the
+// bp_node_kernels.hpp geometry).  The messages (nnz doubles, CSR order, updated in place), the LLRs and the
+// oscillation counters of the syndrome live in a private slot of a global workspace, which the workgroup's CU keeps
+// in its L2; syndrome codes, decisions and parities are bytes / words in LDS; the graph is read from global memory.
+// Statement for statement the arithmetic of bpots_lds_kernel with S = 1 (same left folds, same clamps, same
+// tie-breaks), so the two kernels -- and the oracle -- agree bit for bit.
+// ---------------------------------------------------------------------------------------------
+struct OtsNodeParams {
+    int s, n, nnz;
+    int max_iters, T;
+    long long batch;
+    double prior, C;
+    const unsigned char *syn;
+    unsigned char *err, *conv;
+    int *iters;
+    unsigned int *queue;
+    double *ws;                 // [gridDim.x][slot_doubles]: M[nnz] | LLR[n] | OSC[n] (ints, in the tail)
+    long long slot_doubles;
+};
+
+constexpr int kOtsNodeThreads = 1024;
+
+__host__ __device__ inline size_t ots_node_lds_bytes(int s, int n)
+{
+    return (((size_t)s + 3 * (size_t)n + 15) & ~(size_t)15) + 4 * (size_t)s + (size_t)kOtsNodeThreads * 28 + 64;
+}
+__host__ __device__ inline size_t ots_node_slot_doubles(int n, int nnz)
+{
+    return (((size_t)nnz + (size_t)n + ((size_t)n + 1) / 2) + 63) & ~(size_t)63;
+}
+
+template <int DC, int DV>
+__global__ void __launch_bounds__(kOtsNodeThreads)
+bpots_node_kernel(OtsNodeParams p, const int *__restrict__ row_ptr, const int *__restrict__ csc_row,
+                  const int *__restrict__ col_ptr, const int *__restrict__ csc2csr)
+{
+    constexpr int THREADS = kOtsNodeThreads;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ots_lds[];
+    const int s = p.s, n = p.n, nnz = p.nnz;
+    unsigned char *code = ots_lds;                          // [s] syndrome entry: 0, 1, or 2 (anything else)
+    unsigned char *dec = code + s;                          // [n]
+    unsigned char *prv = dec + n;                           // [n] decisions of the previous iteration
+    unsigned char *best = prv + n;                          // [n]
+    unsigned int *par = (unsigned int *)(ots_lds + (((size_t)s + 3 * (size_t)n + 15) & ~(size_t)15));   // [s]
+    double *pk1 = (double *)(par + s + ((s & 1) ? 1 : 0));  // [THREADS] |llr| of this thread's j1 candidate
+    double *pk2 = pk1 + THREADS;                            // [THREADS] |llr| of its j2 candidate
+    int *po = (int *)(pk2 + THREADS);                       // [THREADS] oscillation count of the j1 candidate
+    int *pi1 = po + THREADS;                                // [THREADS]
+    int *pi2 = pi1 + THREADS;                               // [THREADS]
+    __shared__ long long sh_b;
+    __shared__ int sh_cnt_m, sh_cnt_w, sh_best_m, sh_best_w, sh_bj1, sh_bj2, sh_flags;   // flags: 1 update best, 2 converged, 4 bias
+    double *M = p.ws + (size_t)blockIdx.x * (size_t)p.slot_doubles;
+    double *LLR = M + nnz;
+    int *OSC = (int *)(LLR + n);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const double PI0 = p.prior, NEGC = -p.C;
+    const double MAX_TANH = 0.99999, MAX_MSG = 100.0;
+
+    for (;;) {
+        if (tid == 0) {
+            const long long q = (long long)atomicAdd(p.queue, 1u);
+            sh_b = q >= p.batch ? -1 : q;
+        }
+        __syncthreads();
+        const long long b = sh_b;
+        if (b < 0) break;                                   // every wave of every workgroup reaches this
+        // ---- reset! (:142-154) and the syndrome in
+        for (int i = tid; i < s; i += THREADS) {
+            const unsigned v = p.syn[(size_t)b * s + i];
+            code[i] = (unsigned char)(v > 1u ? 2u : v);
+        }
+        for (int e = tid; e < nnz; e += THREADS) M[e] = 0.0;
+        for (int j = tid; j < n; j += THREADS) { OSC[j] = 0; prv[j] = 0; best[j] = 0; }
+        if (tid == 0) { sh_best_m = s; sh_best_w = n; sh_bj1 = -1; sh_bj2 = -1; }          // :236-237
+        __syncthreads();
+
+        int it = 0, converged = 0;
+        while (it < p.max_iters) {
+            ++it;
+            const int bj1 = sh_bj1, bj2 = sh_bj2;
+            // ---- variable -> check (:241-245, :158-172)
+            for (int j = tid; j < n; j += THREADS) {
+                const int c0 = col_ptr[j];
+                const int deg = col_ptr[j + 1] - c0;
+                const double om = (j == bj1 || j == bj2) ? NEGC : PI0;
+                double c[DV];
+                int at[DV];
+#pragma unroll
+                for (int k = 0; k < DV; ++k)
+                    if (k < deg) { at[k] = csc2csr[c0 + k]; c[k] = M[at[k]]; }
+#pragma unroll
+                for (int k = 0; k < DV; ++k)
+                    if (k < deg) {
+                        double sum = 0.0;
+#pragma unroll
+                        for (int q = 0; q < DV; ++q)
+                            if (q < deg && q != k) sum += c[q];
+                        M[at[k]] = om + sum;
+                    }
+            }
+            if (tid == 0) { sh_cnt_m = 0; sh_cnt_w = 0; sh_flags = 0; }
+            __syncthreads();
+            // ---- check -> variable (:247-251, :178-210)
+            for (int i = tid; i < s; i += THREADS) {
+                const int e0 = row_ptr[i];
+                const int deg = row_ptr[i + 1] - e0;
+                const bool flip = code[i] != 0;
+                par[i] = 0u;
+                double t[DC];
+                double *Mi = M + e0;
+#pragma unroll
+                for (int k = 0; k < DC; ++k)
+                    if (k < deg) {
+                        double tv = pm_tanh(0.5 * Mi[k]);
+                        tv = tv > MAX_TANH ? MAX_TANH : (tv < -MAX_TANH ? -MAX_TANH : tv);
+                        t[k] = tv;
+                    }
+#pragma unroll
+                for (int k = 0; k < DC; ++k)
+                    if (k < deg) {
+                        double prod = 1.0;
+#pragma unroll
+                        for (int q = 0; q < DC; ++q)
+                            if (q < deg && q != k) prod *= t[q];
+                        if (flip) prod = -prod;
+                        if (pm_fabs(prod) >= MAX_TANH) prod = prod > 0 ? MAX_TANH : -MAX_TANH;
+                        double msg = 2.0 * pm_atanh(prod);
+                        msg = msg > MAX_MSG ? MAX_MSG : (msg < -MAX_MSG ? -MAX_MSG : msg);
+                        Mi[k] = msg;
+                    }
+            }
+            __syncthreads();
+            // ---- beliefs, decisions, oscillations, parities (:120-136, :257-263), weight (:281)
+            int wcount = 0;
+            for (int j = tid; j < n; j += THREADS) {
+                const int c0 = col_ptr[j];
+                const int deg = col_ptr[j + 1] - c0;
+                double llr = (j == bj1 || j == bj2) ? NEGC : PI0;
+                for (int k = 0; k < deg; ++k) llr += M[csc2csr[c0 + k]];
+                LLR[j] = llr;
+                const unsigned char d1 = llr < 0.0 ? 1 : 0;
+                if (it > 1 && d1 != prv[j]) OSC[j] += 1;
+                dec[j] = d1;
+                prv[j] = d1;
+                if (d1) {
+                    ++wcount;
+                    for (int k = 0; k < deg; ++k) atomicXor(&par[csc_row[c0 + k]], 1u);
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) wcount += __shfl_xor(wcount, off, 64);
+            if (lane == 0 && wcount) atomicAdd(&sh_cnt_w, wcount);
+            __syncthreads();
+            // ---- mismatch (:266-279)
+            int mcount = 0;
+            for (int i = tid; i < s; i += THREADS) mcount += (code[i] > 1 || (par[i] & 1u) != (unsigned)code[i]) ? 1 : 0;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mcount += __shfl_xor(mcount, off, 64);
+            if (lane == 0 && mcount) atomicAdd(&sh_cnt_m, mcount);
+            __syncthreads();
+            // ---- best solution so far (:284-292), converged?, bias due? (:295)
+            if (tid == 0) {
+                const int m = sh_cnt_m, wgt = sh_cnt_w;
+                int f = 0;
+                if (m < sh_best_m || (m == sh_best_m && wgt < sh_best_w)) {
+                    sh_best_m = m; sh_best_w = wgt;
+                    f |= 1;
+                    if (m == 0) f |= 2;
+                }
+                if (m > 0 && (it % p.T) == 0) f |= 4;
+                sh_flags = f;
+            }
+            __syncthreads();
+            const int flags = sh_flags;
+            if (flags & 1)
+                for (int j = tid; j < n; j += THREADS) best[j] = dec[j];
+            if (flags & 2) { converged = 1; __syncthreads(); break; }
+            if (flags & 4) {
+                // ---- bias step (:297-337): Omega .= Pi, then j1 (most oscillating, then least |llr|, then lowest
+                //      index) and j2 (least |llr| overall, lowest index)
+                int bo = -1, bi = -1, bi2 = -1;
+                double bk = 0.0, bk2 = 0.0;
+                for (int j = tid; j < n; j += THREADS) {
+                    const int o = OSC[j];
+                    const double a = pm_fabs(LLR[j]);
+                    if (bi < 0 || o > bo || (o == bo && a < bk)) { bo = o; bk = a; bi = j; }
+                    if (bi2 < 0 || a < bk2) { bk2 = a; bi2 = j; }
+                }
+                po[tid] = bo; pk1[tid] = bk; pi1[tid] = bi; pk2[tid] = bk2; pi2[tid] = bi2;
+                __syncthreads();
+                if (tid == 0) {
+                    bo = -1; bi = -1; bi2 = -1; bk = 0.0; bk2 = 0.0;
+                    for (int t = 0; t < THREADS; ++t) {
+                        const int i1 = pi1[t];
+                        if (i1 >= 0) {
+                            const int o = po[t];
+                            const double a = pk1[t];
+                            if (bi < 0 || o > bo || (o == bo && (a < bk || (a == bk && i1 < bi)))) { bo = o; bk = a; bi = i1; }
+                        }
+                        const int i2 = pi2[t];
+                        if (i2 >= 0) {
+                            const double a2 = pk2[t];
+                            if (bi2 < 0 || a2 < bk2 || (a2 == bk2 && i2 < bi2)) { bk2 = a2; bi2 = i2; }
+                        }
+                    }
+                    sh_bj1 = -1; sh_bj2 = -1;                 // Omega .= Pi (:297)
+                    if (bo > 0) {                             // maximum(oscillations) > 0 (:300)
+                        OSC[bi] = 0;                          // :320
+                        sh_bj1 = bi;                          // :323
+                        sh_bj2 = bi2;                         // :336
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // ---- results out: best_decisions (:340 / :291)
+        for (int j = tid; j < n; j += THREADS) p.err[(size_t)b * n + j] = best[j];
+        if (tid == 0) {
+            p.conv[b] = (unsigned char)converged;
+            if (p.iters) p.iters[b] = it;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace ldpc

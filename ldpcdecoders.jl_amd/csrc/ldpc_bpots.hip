@@ -1,8 +1,10 @@
 // ldpc_bpots.hip -- host side of the BP-OTS decoder: the ldpc_bpots_* entry points
 // of include/ldpc_mi355x.h.  Replaces BPOTSDecoder / decode! / batchdecode! of
 // src/decoders/bpots_decoder.jl:39-115, 225-340.  Device code: bpots_kernels.hpp.
-// LDS-resident only: the graph must be small enough for one CU's LDS (every code of the reference's
-// BP-OTS tests is); larger graphs get LDPC_ERR_UNSUPPORTED.  No CPU path.
+// Two kernels: LDS-resident (S syndromes per workgroup; every code of the reference's BP-OTS tests) and, for graphs
+// whose messages do not fit a CU's LDS, node-parallel with the messages in a global slot (one workgroup per
+// syndrome).  Beyond s + 3n + 4s bytes of LDS (n ~ 30,000 for a rate-1/2 code), check degree 32 or bit degree 16:
+// LDPC_ERR_UNSUPPORTED.  No CPU path.
 #include "../../include/ldpc_mi355x.h"
 #include "bpots_kernels.hpp"
 
@@ -46,9 +48,12 @@ struct ldpc_bpots_decoder {
     unsigned lat_ticket = 0;
     bool kernel_ready = false;  // dynamic-LDS limit set, occupancy known
     int per_cu = 1;
+    bool node_mode = false;     // the graph is beyond the LDS kernel: bpots_node_kernel, messages in a global slot
+    double *node_ws = nullptr;  // [grid][slot] of the node kernel
+    size_t node_ws_cap = 0;
     ~ldpc_bpots_decoder()
     {
-        void *all[] = {row_ptr, csc_row, col_ptr, csc2csr, queue, stage, done_ctr};
+        void *all[] = {row_ptr, csc_row, col_ptr, csc2csr, queue, stage, done_ctr, node_ws};
         for (void *q : all)
             if (q) (void)hipFree(q);
         if (lat_pin) (void)hipHostFree(lat_pin);
@@ -61,6 +66,14 @@ static ots_kernel_t pick_ots(int dc, int dv)
 {
     if (dc <= 8) return dv <= 4 ? bpots_lds_kernel<8, 4> : bpots_lds_kernel<8, 16>;
     return dv <= 4 ? bpots_lds_kernel<32, 4> : bpots_lds_kernel<32, 16>;
+}
+
+typedef void (*ots_node_kernel_t)(OtsNodeParams, const int *, const int *, const int *, const int *);
+
+static ots_node_kernel_t pick_ots_node(int dc, int dv)
+{
+    if (dc <= 8) return dv <= 4 ? bpots_node_kernel<8, 4> : bpots_node_kernel<8, 16>;
+    return dv <= 4 ? bpots_node_kernel<32, 4> : bpots_node_kernel<32, 16>;
 }
 
 extern "C" {
@@ -119,19 +132,26 @@ ldpc_status ldpc_bpots_create(int64_t s, int64_t n, int64_t nnz, const int64_t *
         }
         col_ptr[(size_t)n] = (int)nnz;
     }
-    if (d->max_cdeg > 32 || d->max_bdeg > 16 || nnz >= 65535 || s >= 65535 || n >= 65535) {
+    if (d->max_cdeg > 32 || d->max_bdeg > 16 || nnz >= ((int64_t)1 << 28) || s >= ((int64_t)1 << 28) || n >= ((int64_t)1 << 28)) {
         delete d;
-        return set_error(LDPC_ERR_UNSUPPORTED, "BP-OTS kernel: check degree <= 32, bit degree <= 16 and a graph that fits the LDS");
+        return set_error(LDPC_ERR_UNSUPPORTED, "BP-OTS kernels: check degree <= 32 and bit degree <= 16");
     }
     d->logS = -1;
-    for (int l = 0; l <= 6; ++l) {
-        const size_t b = ots_lds_bytes((int)s, (int)n, (int)nnz, 1 << l) + 8192;
-        if (b <= (size_t)76 * 1024 || (d->logS < 0 && b <= (size_t)156 * 1024)) d->logS = l;
-        else if (b > (size_t)156 * 1024) break;
-    }
+    static const bool force_node = std::getenv("LDPC_BPOTS_FORCE_NODE") != nullptr;   // tests: small graphs through the node kernel
+    if (!force_node && nnz < 65535 && s < 65535 && n < 65535)   // (uint16 graph copies in LDS)
+        for (int l = 0; l <= 6; ++l) {
+            const size_t b = ots_lds_bytes((int)s, (int)n, (int)nnz, 1 << l) + 8192;
+            if (b <= (size_t)76 * 1024 || (d->logS < 0 && b <= (size_t)156 * 1024)) d->logS = l;
+            else if (b > (size_t)156 * 1024) break;
+        }
     if (d->logS < 0) {
-        delete d;
-        return set_error(LDPC_ERR_UNSUPPORTED, "BP-OTS kernel: the graph's messages do not fit the LDS");
+        // beyond the LDS kernel: one workgroup per syndrome, messages in a global slot, bytes / parities in LDS
+        if (ots_node_lds_bytes((int)s, (int)n) + 1024 > (size_t)156 * 1024) {
+            delete d;
+            return set_error(LDPC_ERR_UNSUPPORTED, "BP-OTS kernels: s + 3n bytes of decisions and 4s bytes of parities must fit a CU's LDS "
+                                                   "(about n = 30,000 for a rate-1/2 code)");
+        }
+        d->node_mode = true;
     }
     auto up = [&](int *&dst, const std::vector<int> &v) -> bool {
         if (hipMalloc((void **)&dst, std::max<size_t>(v.size(), 1) * sizeof(int)) != hipSuccess) return false;
@@ -177,6 +197,35 @@ static ldpc_status bpots_decode_impl(ldpc_bpots_decoder *d, int64_t batch, const
         if (d->n > 0) OTS_TRY(hipMemsetAsync(d_err, 0, (size_t)batch * d->n, stream));
         OTS_TRY(hipMemsetAsync(d_conv, 0, (size_t)batch, stream));
         if (d_iters) OTS_TRY(hipMemsetAsync(d_iters, 0, (size_t)batch * sizeof(int32_t), stream));
+        return LDPC_OK;
+    }
+    if (d->node_mode) {
+        if (batch > (1ll << 30)) return set_error(LDPC_ERR_UNSUPPORTED, "batch too large for one call");
+        ots_node_kernel_t nk = pick_ots_node(d->max_cdeg, d->max_bdeg);
+        const size_t nlds = ots_node_lds_bytes((int)d->s, (int)d->n);
+        if (!d->kernel_ready) {
+            OTS_TRY(hipFuncSetAttribute((const void *)nk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nlds));
+            d->kernel_ready = true;
+        }
+        const int grid = (int)std::min<int64_t>(batch, d->num_cus);
+        const size_t slot = ots_node_slot_doubles((int)d->n, (int)d->nnz);
+        if (d->node_ws_cap < (size_t)grid * slot * sizeof(double)) {
+            if (d->node_ws) { OTS_TRY(hipStreamSynchronize(stream)); (void)hipFree(d->node_ws); }
+            d->node_ws = nullptr; d->node_ws_cap = 0;
+            OTS_TRY(hipMalloc((void **)&d->node_ws, (size_t)grid * slot * sizeof(double)));
+            d->node_ws_cap = (size_t)grid * slot * sizeof(double);
+        }
+        OtsNodeParams np{};
+        np.s = (int)d->s; np.n = (int)d->n; np.nnz = (int)d->nnz; np.max_iters = (int)d->max_iters; np.T = (int)d->T;
+        np.batch = batch;
+        np.prior = std::log((1 - (2 * d->per / 3)) / (2 * d->per / 3));   // bpots_decoder.jl:231
+        np.C = d->C;
+        np.syn = d_syn; np.err = d_err; np.conv = d_conv; np.iters = d_iters; np.queue = d->queue;
+        np.ws = d->node_ws; np.slot_doubles = (long long)slot;
+        OTS_TRY(hipMemsetAsync(d->queue, 0, 64, stream));
+        hipLaunchKernelGGL(nk, dim3((unsigned)grid), dim3(kOtsNodeThreads), nlds, stream, np, (const int *)d->row_ptr,
+                           (const int *)d->csc_row, (const int *)d->col_ptr, (const int *)d->csc2csr);
+        OTS_TRY(hipGetLastError());
         return LDPC_OK;
     }
     const int64_t ngroups = (batch + (1ll << d->logS) - 1) >> d->logS;
@@ -237,8 +286,8 @@ ldpc_status ldpc_bpots_decode_batch(ldpc_bpots_decoder *d, int64_t batch, const 
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o_err = up(B * s), o_conv = o_err + up(B * n), o_it = o_conv + up(B), total = o_it + up(B * 4);
     static const bool lat_off = std::getenv("LDPC_NO_LATENCY_PATH") != nullptr;
-    const int64_t lat_groups = (batch + (1ll << d->logS) - 1) >> d->logS;
-    if (!lat_off && total <= ((size_t)256 << 10) && d->max_iters > 0 && lat_groups <= 2 * (int64_t)d->num_cus) {
+    const int64_t lat_groups = d->node_mode ? batch : (batch + (1ll << d->logS) - 1) >> d->logS;
+    if (!d->node_mode && !lat_off && total <= ((size_t)256 << 10) && d->max_iters > 0 && lat_groups <= 2 * (int64_t)d->num_cus) {
         const size_t hdr = 256;
         if (!d->lat_pin) {
             const size_t cap = hdr + ((size_t)256 << 10);

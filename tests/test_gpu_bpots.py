@@ -116,7 +116,51 @@ def test_max_iters_zero_and_unsupported(ldpc, gpu):
     H = cycle_matrix(8)
     err, conv, its = ldpc.BPOTSDecoder(H, 0.01, 0).decode_batch_host(np.zeros((3, 8), dtype=np.uint8))
     assert not err.any() and not conv.any() and not its.any()
-    big = ldpc.codes.parity_check_csc(16384, 8, 4)      # messages do not fit one CU's LDS
+    # the size limit of the BP-OTS kernels: s + 3n bytes of decisions and 4s bytes of parities in one CU's LDS
+    # (the reference's BPOTSDecoder has no limit; README / INTEGRATION state ours)
+    huge = ldpc.codes.parity_check_csc(65536, 8, 4)
     with pytest.raises(ldpc.LdpcError) as ei:
-        ldpc.BPOTSDecoder(big, 0.01, 10)
+        ldpc.BPOTSDecoder(huge, 0.01, 10)
+    assert ei.value.status == 5 and "LDS" in ei.value.message
+    wide = sp.csc_matrix(np.ones((2, 40), dtype=np.uint8))          # check degree 40 > 32
+    with pytest.raises(ldpc.LdpcError) as ei:
+        ldpc.BPOTSDecoder(wide, 0.01, 10)
     assert ei.value.status == 5
+
+
+def test_graphs_beyond_the_lds_take_the_node_kernel(ldpc, gpu):
+    """Graphs whose messages do not fit a CU's LDS (round 1: LDPC_ERR_UNSUPPORTED) are decoded by bpots_node_kernel --
+    one workgroup per syndrome, messages / LLRs / oscillation counters in a global slot.  The (4,8)-regular n = 16384
+    code of BASELINE configs 3/4 and a (3,6) n = 8190 code, below and above threshold (the bias step runs), against the
+    oracle: estimates, flags and iteration counts identical."""
+    for n, wr, wc, per, B, iters in [(16384, 8, 4, 0.03, 40, 30), (16384, 8, 4, 0.08, 24, 20), (8190, 6, 3, 0.07, 60, 40)]:
+        H = ldpc.codes.parity_check_csc(n, wr, wc)
+        syn = ldpc.codes.syndromes_of(H, ldpc.codes.random_errors(n, B, per, seed=n + B))
+        err, conv, its = assert_same_as_oracle(ldpc, H, per, iters, 9, 2.0, syn)
+        if per <= 0.03:
+            assert conv.all()
+        else:
+            assert (its >= 18).any()      # at least two bias steps somewhere
+
+
+def test_node_kernel_equals_lds_kernel_on_small_graphs(ldpc, gpu, monkeypatch):
+    """The same small graphs through both kernels (LDPC_BPOTS_FORCE_NODE sends everything to the node kernel): cycle
+    matrices, toric code, irregular graphs with empty rows / columns and non-binary syndrome entries, BB-72."""
+    monkeypatch.setenv("LDPC_BPOTS_FORCE_NODE", "1")
+    rng = np.random.default_rng(12)
+    for n in (4, 8, 16):
+        H = cycle_matrix(n)
+        S = (rng.integers(0, 2, (90, n)).astype(int) @ H.T.astype(int) % 2).astype(np.uint8)
+        assert_same_as_oracle(ldpc, H, 0.01, 100, 3, 1.0, S)
+    H = toric_x(3)
+    E = rng.integers(0, 2, (300, 18)).astype(np.uint8)
+    assert_same_as_oracle(ldpc, H, 0.05, 50, 9, 3.0, (E.astype(int) @ H.T.astype(int) % 2).astype(np.uint8))
+    for trial in range(3):
+        H = (rng.random((20, 40)) < 0.12).astype(np.uint8)
+        H[0, :] = 0
+        H[:, 1] = 0
+        syn = rng.integers(0, 2, (130, 20)).astype(np.uint8)
+        syn[3, 2] = 2
+        assert_same_as_oracle(ldpc, H, 0.03, 30, 4, 1.5, syn)
+    HX, _ = ldpc.codes.bivariate_bicycle_72_12_6()
+    assert_same_as_oracle(ldpc, HX, 0.05, 40, 5, 2.0, ldpc.codes.syndromes_of(HX, ldpc.codes.random_errors(72, 700, 0.05, seed=2)))
