@@ -44,6 +44,7 @@ EXPORTED_SYMBOLS = (
     "ldpc_osd_postprocess_batch",
     "ldpc_bpots_create",
     "ldpc_bpots_destroy",
+    "ldpc_bpots_kernel",
     "ldpc_bpots_decode_batch",
     "ldpc_bpots_decode_batch_device",
 )
@@ -149,6 +150,8 @@ def lib() -> ctypes.CDLL:
     L.ldpc_bpots_create.argtypes = [i64, i64, i64, vp, vp, f64, i64, i64, f64, i32, ctypes.POINTER(vp)]
     L.ldpc_bpots_destroy.restype = i32
     L.ldpc_bpots_destroy.argtypes = [vp]
+    L.ldpc_bpots_kernel.restype = i32
+    L.ldpc_bpots_kernel.argtypes = [vp]
     L.ldpc_bpots_decode_batch.restype = i32
     L.ldpc_bpots_decode_batch.argtypes = [vp, i64, vp, vp, vp, vp]
     L.ldpc_bpots_decode_batch_device.restype = i32

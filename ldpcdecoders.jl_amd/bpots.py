@@ -28,6 +28,11 @@ class BPOTSDecoder(AbstractDecoder):
                                                   rowval.ctypes.data, self.per, self.max_iters, self.T, self.C,
                                                   -1 if device is None else int(device), ctypes.byref(self._h)))
 
+    @property
+    def kernel(self) -> int:
+        """2 = LDS-resident kernel, 3 = node-parallel kernel with the messages in a global slot (ldpc_bpots_kernel)."""
+        return int(_capi.lib().ldpc_bpots_kernel(self._h))
+
     def close(self) -> None:
         h, self._h = getattr(self, "_h", None), None
         if h:

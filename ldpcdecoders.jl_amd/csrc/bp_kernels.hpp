@@ -46,6 +46,9 @@ constexpr int kTile = 64;  // syndromes per tile == wavefront width on gfx950
 #ifndef LDPC_ROTATE      // 1 = every workgroup starts its sweeps at a different node (de-phases the workgroups)
 #define LDPC_ROTATE 1    // together with the pad: +1.3..1.4 % on C3 full-50 (two boxes, A/B in one process each)
 #endif
+#ifndef LDPC_PHASE_TICKS // 1 = the tile kernel stamps its phases (four 100 MHz clock reads per iteration, three atomics per
+#define LDPC_PHASE_TICKS 1 // tile) for bench.py's phase shares; A/B against 0 on C3 full-50: see DESIGN.md "Measured"
+#endif
 #ifndef LDPC_SLOT_PAD    // bytes added to the workspace slot stride (breaks power-of-two slot strides)
 #define LDPC_SLOT_PAD 1053184   // 1 MiB + 4.5 KiB
 #endif
@@ -408,7 +411,7 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
         while (active != 0) {   // (every lane retires at the latest when its total reaches max_iters)
             ++it;
             const bool first = (it == 1) && !resumed;
-            const u64 t0 = wall_clock64();
+            const u64 t0 = LDPC_PHASE_TICKS ? wall_clock64() : 0;
             // ---- check-node sweep  (:135-150)
             for (int i0 = w; i0 < s; i0 += W) {
 #if LDPC_ROTATE
@@ -423,7 +426,7 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
                 else check_update<DC, false>(Mt + (size_t)e0 * kTile, deg, sigma, r);
             }
             __syncthreads();
-            const u64 t1 = wall_clock64();
+            const u64 t1 = LDPC_PHASE_TICKS ? wall_clock64() : 0;
             // ---- variable-node sweep  (:152-178)
             auto finish_bit = [&](int j, double T) {
                 const u64 dec = __ballot(T >= 1.0);                            // :164-168
@@ -451,7 +454,7 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
                 finish_bit(j, bit_update<DV>(Mt, csc2csr + c0, deg, r));
             }
             __syncthreads();
-            const u64 t2 = wall_clock64();
+            const u64 t2 = LDPC_PHASE_TICKS ? wall_clock64() : 0;
             // ---- convergence test (:180-184): lane = check, words = 64 syndromes
             u64 mism = 0;
             for (int i = w * 64 + lane; i < s; i += W * 64) {
@@ -493,7 +496,7 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
             if (stopped != 0) {
                 for (int j = w * 64 + lane; j < n; j += W * 64) fin[j] = (fin[j] & ~stopped) | (em[j] & stopped);
             }
-            const u64 t3 = wall_clock64();
+            const u64 t3 = LDPC_PHASE_TICKS ? wall_clock64() : 0;
             tk_check += t1 - t0; tk_var += t2 - t1; tk_conv += t3 - t2;
             // few stragglers left: hand them -- with their messages -- to the next level instead of sweeping a
             // nearly empty tile (uniform over the workgroup: active and it are)
@@ -532,10 +535,12 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
             for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
             if (lane == 0) {
                 atomicAdd(cd->sum_iters, (u64)tot);
-                u64 *const ticks = cd->phase_ticks;
-                atomicAdd(&ticks[0], tk_check);
-                atomicAdd(&ticks[1], tk_var);
-                atomicAdd(&ticks[2], tk_conv);
+                if (LDPC_PHASE_TICKS) {
+                    u64 *const ticks = cd->phase_ticks;
+                    atomicAdd(&ticks[0], tk_check);
+                    atomicAdd(&ticks[1], tk_var);
+                    atomicAdd(&ticks[2], tk_conv);
+                }
             }
         }
         __syncthreads();
@@ -550,22 +555,36 @@ __global__ void __launch_bounds__(64) store_cold_kernel(BPCold c0, BPCold c1, BP
 }
 
 // ---------------------------------------------------------------------------
-// placement probe: the variable sweep's access pattern on a candidate workspace -- every wave of a
-// slot's workgroup gathers 4 pseudo-random rows of the slot and writes them back.  The host times it
-// on several candidate allocations and keeps the fastest (DESIGN.md "Workspace placement").
+// placement probe: the two sweeps' access patterns on a candidate workspace, with the real kernel's geometry (one
+// 8-wave workgroup per slot, three per CU, every workgroup starting at a rotation of its own) -- every wave gathers
+// 4 pseudo-random rows of the slot and writes them back (variable sweep), then streams 8 contiguous rows in place
+// (check sweep).  The host times it on candidate chunk groups and keeps the fastest (DESIGN.md "Workspace
+// placement").  Traffic: 4 x rows x 512 B per slot.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(512) placement_probe_kernel(double *base, long long slot_stride, int rows)
+__global__ void __launch_bounds__(512, 6) placement_probe_kernel(double *base, long long slot_stride, int rows)
 {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double *M = base + (size_t)blockIdx.x * (size_t)slot_stride + lane;
-    const unsigned r = (unsigned)rows;
-    for (unsigned j = (unsigned)w; j < r / 4u; j += 8u) {
+    const unsigned r = (unsigned)rows, nb = r / 4u, nc = r / 8u;
+    const unsigned rot_v = nb ? (blockIdx.x * 2246822519u) % nb : 0u, rot_c = nc ? (blockIdx.x * 2654435761u) % nc : 0u;
+    for (unsigned j0 = (unsigned)w; j0 < nb; j0 += 8u) {
+        const unsigned j = (j0 + rot_v >= nb) ? j0 + rot_v - nb : j0 + rot_v;
         const unsigned a = (j * 2654435761u + 12345u) % r, b = (j * 2246822519u + 977u) % r,
                        c = (j * 3266489917u + 31u) % r, d = (j * 668265263u + 7u) % r;
         const double v0 = M[(size_t)a * kTile], v1 = M[(size_t)b * kTile], v2 = M[(size_t)c * kTile],
                      v3 = M[(size_t)d * kTile];
         M[(size_t)a * kTile] = v1; M[(size_t)b * kTile] = v2; M[(size_t)c * kTile] = v3; M[(size_t)d * kTile] = v0;
+    }
+    __syncthreads();
+    for (unsigned i0 = (unsigned)w; i0 < nc; i0 += 8u) {
+        const unsigned i = (i0 + rot_c >= nc) ? i0 + rot_c - nc : i0 + rot_c;
+        double *R = M + (size_t)i * 8 * kTile;
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = R[(size_t)k * kTile];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) R[(size_t)k * kTile] = v[k];
     }
 }
 

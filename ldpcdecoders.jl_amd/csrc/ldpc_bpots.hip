@@ -137,7 +137,7 @@ ldpc_status ldpc_bpots_create(int64_t s, int64_t n, int64_t nnz, const int64_t *
         return set_error(LDPC_ERR_UNSUPPORTED, "BP-OTS kernels: check degree <= 32 and bit degree <= 16");
     }
     d->logS = -1;
-    static const bool force_node = std::getenv("LDPC_BPOTS_FORCE_NODE") != nullptr;   // tests: small graphs through the node kernel
+    const bool force_node = std::getenv("LDPC_BPOTS_FORCE_NODE") != nullptr;   // tests (read at create): small graphs through the node kernel
     if (!force_node && nnz < 65535 && s < 65535 && n < 65535)   // (uint16 graph copies in LDS)
         for (int l = 0; l <= 6; ++l) {
             const size_t b = ots_lds_bytes((int)s, (int)n, (int)nnz, 1 << l) + 8192;
@@ -167,6 +167,8 @@ ldpc_status ldpc_bpots_create(int64_t s, int64_t n, int64_t nnz, const int64_t *
     *out = d;
     return LDPC_OK;
 }
+
+int32_t ldpc_bpots_kernel(const ldpc_bpots_decoder *d) { return d ? (d->node_mode ? 3 : 2) : 0; }
 
 ldpc_status ldpc_bpots_destroy(ldpc_bpots_decoder *d)
 {

@@ -360,8 +360,8 @@ static ldpc_status big_alloc(DevBuf &b, size_t bytes, int device)
 //     (tools/vmm_probe6.hip) -- so a search has to look at groups of chunks, not at single ones;
 //   * plain hipMalloc gets the slow class most of the time in a fresh process (5 of 6), 1 GiB chunks at a 1 GiB-
 //     aligned base the fast one most of the time (22 of 26 bench runs on three boxes; never on a fourth).
-// So: the workspace is a group of 1 GiB chunks; it is probed with the variable sweep's pattern (one untimed
-// first-touch pass, one timed pass, ~25 ms); if it is not of the fast class another group is allocated WHILE the
+// So: the workspace is a group of 1 GiB chunks; it is probed with both sweeps' patterns (one untimed
+// first-touch pass, one timed pass, ~35 ms); if it is not of the fast class another group is allocated WHILE the
 // candidates so far are held (freed memory would come straight back) and probed, up to LDPC_PLACEMENT_ROUNDS
 // groups (default 4; 1 = take the first) and never beyond half of the free HBM; the best is kept, the others are
 // released.  Transient HBM: 1x when the first group is fast, at most rounds x.  First-call cost 0.1 s per group.
@@ -386,7 +386,7 @@ static ldpc_status ensure_workspace(ldpc_bp_decoder *d, size_t bytes, int grid, 
         return LDPC_OK;
     }
     const long long stride = (long long)(slot_stride_bytes / sizeof(double));
-    const double probe_bytes = 2.0 * (double)grid * (double)d->nnz * 512.0;
+    const double probe_bytes = 4.0 * (double)grid * (double)d->nnz * 512.0;   // both sweeps' patterns, read + write
     auto probe = [&](void *q) -> float {   // ms of one timed pass (after an untimed first-touch pass); <0 on error
         hipLaunchKernelGGL(placement_probe_kernel, dim3((unsigned)grid), dim3(512), 0, stream, (double *)q, stride, (int)d->nnz);
         if (hipEventRecord(ea, stream) != hipSuccess) return -1.f;

@@ -219,8 +219,8 @@ function batchdecode!(d::MI355XBeliefPropagationOSDDecoder, syndromes::AbstractM
 end
 
 # ---------------------------------------------------------------------------------------------
-# BP-OTS (src/decoders/bpots_decoder.jl:39-115, 225-340) over ldpc_bpots_* (LDS-resident kernel:
-# graphs whose messages fit one CU's LDS; larger ones raise LDPCMI355XError(5, ...)).
+# BP-OTS (src/decoders/bpots_decoder.jl:39-115, 225-340) over ldpc_bpots_* (LDS-resident kernel for small graphs,
+# node-parallel kernel with the messages in global memory up to n ~ 30,000; beyond that LDPCMI355XError(5, ...)).
 # ---------------------------------------------------------------------------------------------
 mutable struct MI355XBPOTSDecoder <: AbstractDecoder
     per::Float64; max_iters::Int; s::Int; n::Int; T::Int; C::Float64

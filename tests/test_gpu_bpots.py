@@ -30,11 +30,12 @@ def toric_x(d):
     return H
 
 
-def assert_same_as_oracle(ldpc, H, per, iters, T, C, syn):
+def assert_same_as_oracle(ldpc, H, per, iters, T, C, syn, kernel=None):
     M = sp.csc_matrix(H)
     M.sort_indices()
     oerr, oconv, oits = BPOTSOracle((M.indptr, M.indices), M.shape, per, iters, T, C).batchdecode(syn)
     dec = ldpc.BPOTSDecoder(M, per, iters, T=T, C=C)
+    assert kernel is None or dec.kernel == kernel
     err, conv, its = dec.decode_batch_host(syn)
     bad = np.nonzero((err != oerr).any(axis=1) | (conv != oconv) | (its != oits))[0]
     assert bad.size == 0, f"{bad.size} of {syn.shape[0]} syndromes differ from the oracle, first {bad[:5]}"
@@ -136,7 +137,7 @@ def test_graphs_beyond_the_lds_take_the_node_kernel(ldpc, gpu):
     for n, wr, wc, per, B, iters in [(16384, 8, 4, 0.03, 40, 30), (16384, 8, 4, 0.08, 24, 20), (8190, 6, 3, 0.07, 60, 40)]:
         H = ldpc.codes.parity_check_csc(n, wr, wc)
         syn = ldpc.codes.syndromes_of(H, ldpc.codes.random_errors(n, B, per, seed=n + B))
-        err, conv, its = assert_same_as_oracle(ldpc, H, per, iters, 9, 2.0, syn)
+        err, conv, its = assert_same_as_oracle(ldpc, H, per, iters, 9, 2.0, syn, kernel=3)
         if per <= 0.03:
             assert conv.all()
         else:
@@ -151,16 +152,16 @@ def test_node_kernel_equals_lds_kernel_on_small_graphs(ldpc, gpu, monkeypatch):
     for n in (4, 8, 16):
         H = cycle_matrix(n)
         S = (rng.integers(0, 2, (90, n)).astype(int) @ H.T.astype(int) % 2).astype(np.uint8)
-        assert_same_as_oracle(ldpc, H, 0.01, 100, 3, 1.0, S)
+        assert_same_as_oracle(ldpc, H, 0.01, 100, 3, 1.0, S, kernel=3)
     H = toric_x(3)
     E = rng.integers(0, 2, (300, 18)).astype(np.uint8)
-    assert_same_as_oracle(ldpc, H, 0.05, 50, 9, 3.0, (E.astype(int) @ H.T.astype(int) % 2).astype(np.uint8))
+    assert_same_as_oracle(ldpc, H, 0.05, 50, 9, 3.0, (E.astype(int) @ H.T.astype(int) % 2).astype(np.uint8), kernel=3)
     for trial in range(3):
         H = (rng.random((20, 40)) < 0.12).astype(np.uint8)
         H[0, :] = 0
         H[:, 1] = 0
         syn = rng.integers(0, 2, (130, 20)).astype(np.uint8)
         syn[3, 2] = 2
-        assert_same_as_oracle(ldpc, H, 0.03, 30, 4, 1.5, syn)
+        assert_same_as_oracle(ldpc, H, 0.03, 30, 4, 1.5, syn, kernel=3)
     HX, _ = ldpc.codes.bivariate_bicycle_72_12_6()
-    assert_same_as_oracle(ldpc, HX, 0.05, 40, 5, 2.0, ldpc.codes.syndromes_of(HX, ldpc.codes.random_errors(72, 700, 0.05, seed=2)))
+    assert_same_as_oracle(ldpc, HX, 0.05, 40, 5, 2.0, ldpc.codes.syndromes_of(HX, ldpc.codes.random_errors(72, 700, 0.05, seed=2)), kernel=3)
