@@ -397,9 +397,9 @@ static ldpc_status ensure_workspace(ldpc_bp_decoder *d, size_t bytes, int grid, 
             return -1.f;
         return ms;
     };
-    // the fast class in absolute terms (what 512+ streaming workgroups reach: >= 5.95 TB/s of probe traffic; a
+    // the fast class in absolute terms (what 512+ streaming workgroups reach: >= 6.0 TB/s of probe traffic; a
     // smaller grid -- the team kernel's medium batches -- cannot be judged that way and takes the first group)
-    auto fast = [&](float ms) { return ms > 0 && probe_bytes / ((double)ms * 1e-3) >= 5.95e12; };
+    auto fast = [&](float ms) { return ms > 0 && probe_bytes / ((double)ms * 1e-3) >= 6.0e12; };
     std::vector<DevBuf> held;
     held.emplace_back();
     held.back().swap(first);
