@@ -63,6 +63,17 @@ while time.time() - t0 < budget:
             os.environ["LDPC_NODE_LDS_ROOM"] = str(int(rng.integers(8, max(9, 8 * H.nnz))))
         if place == 2:
             os.environ["LDPC_NODE_HYBRID"] = "0"
+        # hand-off levels (read at create): thresholds of fresh / level-1 tiles, tiny level capacities (levels fill
+        # up and tiles must carry on), how many stragglers the node kernel finishes
+        for k in ("LDPC_DEFER_T0", "LDPC_DEFER_T1", "LDPC_DEFER_CAP_TILES", "LDPC_NODE_TAKE_MAX"):
+            os.environ.pop(k, None)
+        if rng.random() < 0.7:
+            os.environ["LDPC_DEFER_T0"] = str(int(rng.choice([4, 16, 32, 48])))
+            os.environ["LDPC_DEFER_T1"] = str(int(rng.choice([0, 8, 16, 40])))
+        if rng.random() < 0.3:
+            os.environ["LDPC_DEFER_CAP_TILES"] = str(int(rng.choice([1, 2, 5])))
+        if rng.random() < 0.5:
+            os.environ["LDPC_NODE_TAKE_MAX"] = str(int(rng.choice([0, 3, 40, 100000])))
         kw = dict(kernel_variant=variant, waves_per_tile=0 if variant == 4 else int(rng.choice([0, 4, 8, 16])),
                   defer_threshold=int(rng.choice([0, -1, 4, 40])))
         if variant != 4 and rng.random() < 0.3:
@@ -85,6 +96,9 @@ while time.time() - t0 < budget:
         T, C = int(rng.choice([2, 3, 9])), float(rng.choice([1.0, 2.0, 3.0]))
         pp = max(per, 1e-3) if per < 0.9 else 0.3
         oe, ocv, oi = BPOTSOracle((H.indptr, H.indices), H.shape, pp, iters, T, C).batchdecode(syn)
+        os.environ.pop("LDPC_BPOTS_FORCE_NODE", None)
+        if rng.random() < 0.5:
+            os.environ["LDPC_BPOTS_FORCE_NODE"] = "1"      # the node-parallel kernel (graphs beyond the LDS) on a small graph
         d2 = ldpc.BPOTSDecoder(H, pp, iters, T=T, C=C)
         e2, c2, i2 = d2.decode_batch_host(syn)
         if not (np.array_equal(e2, oe) and np.array_equal(c2, ocv) and np.array_equal(i2, oi)):
