@@ -90,6 +90,12 @@ const char *ldpc_build_target(void);
 /* Message of the last failed call on this thread ("" if none). */
 const char *ldpc_last_error(void);
 
+/* The message arrays of large codes (>= 1 GiB) are groups of 1 GiB chunks that the library keeps, still mapped, in a
+ * per-process pool when a decoder lets go of them, so that the next decoder of that size takes them over (at most
+ * LDPC_POOL_GIB = 64 GiB are held; the pool is emptied by itself when an allocation runs out of memory).  This gives
+ * everything in the pool back to the device now; decoders in use are not affected. */
+ldpc_status ldpc_trim_memory(void);
+
 /* Number of usable gfx950 devices (0 when there is none; never fails). */
 int32_t ldpc_device_count(void);
 

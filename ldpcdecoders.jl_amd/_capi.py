@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = (
     "ldpc_build_target",
     "ldpc_last_error",
     "ldpc_device_count",
+    "ldpc_trim_memory",
     "ldpc_bp_create",
     "ldpc_bp_destroy",
     "ldpc_bp_get_info",
@@ -122,6 +123,7 @@ def lib() -> ctypes.CDLL:
     L.ldpc_build_target.restype = ctypes.c_char_p
     L.ldpc_last_error.restype = ctypes.c_char_p
     L.ldpc_device_count.restype = i32
+    L.ldpc_trim_memory.restype = i32
     L.ldpc_bp_create.restype = i32
     L.ldpc_bp_create.argtypes = [i64, i64, i64, vp, vp, f64, i64, ctypes.POINTER(BPOptions), ctypes.POINTER(vp)]
     L.ldpc_bp_destroy.restype = i32

@@ -59,18 +59,107 @@ namespace {
         }                                                                                      \
     } while (0)
 
+// A chunk group: physical chunks (hipMemCreate) mapped side by side -- each by ONE hipMemMap -- at an aligned base inside
+// a virtual reservation of its own.  This is how every message array of >= 1 GiB is backed (DESIGN.md "Workspace
+// placement").  Groups are POOLED per process: a buffer that is released hands its group, still mapped, to the pool, and
+// the next buffer of that size takes it over.  Two reasons, both measured in round 2:
+//   * ROCm 7.2's virtual-memory path does not survive churn.  A kernel touching a freshly mapped group faulted
+//     ("Memory access fault ... Reason: Unknown") three times -- always in a process that had unmapped and RELEASED other
+//     groups before (decoders of large codes coming and going: the GPU test suite, tools/team_fault_hunt2.sh), never in a
+//     process that only created and mapped (60+ bench runs) or only mapped and unmapped (tools/vmm_probe3/7.hip).
+//     With the pool a process that keeps using the same few sizes creates each group once.
+//   * a group that has been probed carries its grade, so a later workspace of that size skips the placement search.
+// The pool holds at most LDPC_POOL_GIB (64) GiB; beyond that the oldest group is really unmapped and released (with the
+// device idle), and ldpc_trim_memory() drops everything.  Reservations are never given back (hipMemAddressFree): a
+// reservation handed out again is a re-mapped range, which faults too (tools/vmm_probe2.hip); address space is not memory.
+struct ChunkGroup {
+    void *resv = nullptr;
+    size_t resv_size = 0;
+    char *base = nullptr;
+    size_t chunk = 0, mapped = 0;            // chunk size; chunks mapped so far
+    std::vector<hipMemGenericAllocationHandle_t> h;
+    int device = 0;
+    float probe_tbs = 0.f;                   // what the placement probe measured on it as a whole workspace (0 = never probed)
+    size_t probe_bytes = 0;                  // ... of this many bytes
+    size_t bytes() const { return chunk * mapped; }
+    bool empty() const { return resv == nullptr; }
+    void destroy()                           // really give the memory back (device idle: see above)
+    {
+        if (!resv) return;
+        (void)hipDeviceSynchronize();
+        if (std::getenv("LDPC_VMM_LOG")) std::fprintf(stderr, "[ldpc-vmm] unmap %p .. %p\n", (void *)base, (void *)(base + bytes()));
+        for (size_t k = 0; k < mapped; ++k) (void)hipMemUnmap(base + k * chunk, chunk);   // one unmap per map
+        for (auto q : h) (void)hipMemRelease(q);
+        (void)hipDeviceSynchronize();
+        (void)hipGetLastError();
+        h.clear();
+        resv = nullptr; base = nullptr;
+        resv_size = chunk = mapped = 0;
+    }
+};
+
+namespace {
+std::mutex g_pool_mu;
+std::vector<ChunkGroup> g_pool;   // oldest first
+
+size_t pool_cap_bytes()
+{
+    static const size_t v = [] { const char *e = std::getenv("LDPC_POOL_GIB"); return (size_t)(e ? std::max(0, std::atoi(e)) : 64) << 30; }();
+    return v;
+}
+void pool_put(ChunkGroup &&g)
+{
+    if (g.empty()) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool.push_back(std::move(g));
+    size_t total = 0;
+    for (const ChunkGroup &q : g_pool) total += q.bytes();
+    while (total > pool_cap_bytes() && !g_pool.empty()) {
+        total -= g_pool.front().bytes();
+        (void)hipSetDevice(g_pool.front().device);
+        g_pool.front().destroy();
+        g_pool.erase(g_pool.begin());
+    }
+}
+// the pooled group of this chunk size on this device that fits `bytes` most tightly (ties: the better probed one)
+bool pool_take(size_t bytes, size_t chunk, int device, ChunkGroup *out)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    int best = -1;
+    for (int k = 0; k < (int)g_pool.size(); ++k) {
+        const ChunkGroup &q = g_pool[(size_t)k];
+        if (q.device != device || q.chunk != chunk || q.bytes() < bytes) continue;
+        if (best < 0 || q.bytes() < g_pool[(size_t)best].bytes() ||
+            (q.bytes() == g_pool[(size_t)best].bytes() && q.probe_tbs > g_pool[(size_t)best].probe_tbs))
+            best = k;
+    }
+    if (best < 0) return false;
+    *out = std::move(g_pool[(size_t)best]);
+    g_pool.erase(g_pool.begin() + best);
+    return true;
+}
+void pool_drop_all()
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (ChunkGroup &q : g_pool) { (void)hipSetDevice(q.device); q.destroy(); }
+    g_pool.clear();
+}
+}  // namespace
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
-    // virtual-memory backing (ensure_chunked): physical chunks mapped side by side into one reservation
-    std::vector<hipMemGenericAllocationHandle_t> vh;
-    void *vresv = nullptr;
-    size_t vresv_size = 0, vchunk = 0, vmapped = 0;
+    ChunkGroup grp;   // set when the buffer is a chunk group (ensure_chunked), empty for hipMalloc
     ldpc_status ensure(size_t bytes)
     {
         if (bytes <= cap) return LDPC_OK;
         release();
         hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipErrorOutOfMemory) {   // the pool may be what is in the way
+            (void)hipGetLastError();
+            pool_drop_all();
+            e = hipMalloc(&p, bytes);
+        }
         if (e != hipSuccess) {
             (void)hipGetLastError();
             p = nullptr;
@@ -79,14 +168,32 @@ struct DevBuf {
         cap = bytes;
         return LDPC_OK;
     }
-    // The same through the virtual-memory API: physical chunks of `chunk` bytes (hipMemCreate), mapped -- each by
-    // ONE hipMemMap, once, for the life of the buffer -- at a base aligned to `align` inside a reservation of its
-    // own; `shuffle` maps them in a scrambled order.  (How the workspace is backed changes what the sweeps can
-    // stream: DESIGN.md "Workspace placement".)
-    ldpc_status ensure_chunked(size_t bytes, size_t chunk, size_t align, bool shuffle, int device)
+    // A chunk group of at least `bytes`: out of the pool (unless `fresh`: the placement search wants OTHER physical
+    // memory than what it has seen) or newly created -- chunks of `chunk` bytes, base aligned to `align`; `shuffle` maps
+    // them in a scrambled order (experiments).
+    ldpc_status ensure_chunked(size_t bytes, size_t chunk, size_t align, bool shuffle, int device, bool fresh = false)
     {
         if (bytes <= cap) return LDPC_OK;
         release();
+        if (!fresh && !shuffle && pool_take(bytes, chunk, device, &grp)) {
+            p = grp.base;
+            cap = grp.bytes();
+            return LDPC_OK;
+        }
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const hipError_t e = create(bytes, chunk, align, shuffle, device);
+            if (e == hipSuccess) return LDPC_OK;
+            (void)hipGetLastError();
+            grp.destroy();
+            p = nullptr; cap = 0;
+            if (e != hipErrorOutOfMemory || attempt == 1)
+                return fail(e == hipErrorOutOfMemory ? LDPC_ERR_OUT_OF_MEMORY : LDPC_ERR_HIP, std::string("chunk group: ") + hipGetErrorString(e));
+            pool_drop_all();   // out of memory: what the pool holds may be what is missing
+        }
+        return LDPC_ERR_OUT_OF_MEMORY;
+    }
+    hipError_t create(size_t bytes, size_t chunk, size_t align, bool shuffle, int device)
+    {
         hipMemAllocationProp prop = {};
         prop.type = hipMemAllocationTypePinned;
         prop.location.type = hipMemLocationTypeDevice;
@@ -95,20 +202,17 @@ struct DevBuf {
         acc.location = prop.location;
         acc.flags = hipMemAccessFlagsProtReadWrite;
         const size_t n = (bytes + chunk - 1) / chunk;
-        auto bail = [&](const char *what, hipError_t e) {
-            (void)hipGetLastError();
-            release();
-            return fail(e == hipErrorOutOfMemory ? LDPC_ERR_OUT_OF_MEMORY : LDPC_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
-        };
-        hipError_t e = hipMemAddressReserve(&vresv, n * chunk + align, 0, nullptr, 0);
-        if (e != hipSuccess) { vresv = nullptr; return bail("hipMemAddressReserve", e); }
-        vresv_size = n * chunk + align;
-        vchunk = chunk;
-        char *base = (char *)(((uintptr_t)vresv + align - 1) / align * align);
+        grp = ChunkGroup();
+        grp.device = device;
+        hipError_t e = hipMemAddressReserve(&grp.resv, n * chunk + align, 0, nullptr, 0);
+        if (e != hipSuccess) { grp.resv = nullptr; return e; }
+        grp.resv_size = n * chunk + align;
+        grp.chunk = chunk;
+        grp.base = (char *)(((uintptr_t)grp.resv + align - 1) / align * align);
         for (size_t k = 0; k < n; ++k) {
-            hipMemGenericAllocationHandle_t h;
-            if ((e = hipMemCreate(&h, chunk, &prop, 0)) != hipSuccess) return bail("hipMemCreate", e);
-            vh.push_back(h);
+            hipMemGenericAllocationHandle_t q;
+            if ((e = hipMemCreate(&q, chunk, &prop, 0)) != hipSuccess) return e;
+            grp.h.push_back(q);
         }
         std::vector<size_t> order(n);
         for (size_t k = 0; k < n; ++k) order[k] = k;
@@ -116,37 +220,27 @@ struct DevBuf {
             unsigned long long sd = 88172645463325252ull;
             for (size_t i = n - 1; i > 0; --i) { sd ^= sd << 13; sd ^= sd >> 7; sd ^= sd << 17; std::swap(order[i], order[sd % (i + 1)]); }
         }
-        p = base;
         for (size_t k = 0; k < n; ++k) {
-            if ((e = hipMemMap(base + k * chunk, chunk, 0, vh[order[k]], 0)) != hipSuccess) return bail("hipMemMap", e);
-            vmapped = k + 1;
+            if ((e = hipMemMap(grp.base + k * chunk, chunk, 0, grp.h[order[k]], 0)) != hipSuccess) return e;
+            grp.mapped = k + 1;
         }
-        if ((e = hipMemSetAccess(base, n * chunk, &acc, 1)) != hipSuccess) return bail("hipMemSetAccess", e);
+        if ((e = hipMemSetAccess(grp.base, n * chunk, &acc, 1)) != hipSuccess) return e;
+        p = grp.base;
         cap = n * chunk;
-        return LDPC_OK;
+        if (std::getenv("LDPC_VMM_LOG")) std::fprintf(stderr, "[ldpc-vmm] map   %p .. %p (%zu chunks)\n", (void *)grp.base, (void *)(grp.base + cap), n);
+        return hipSuccess;
     }
     void swap(DevBuf &o)
     {
-        std::swap(p, o.p); std::swap(cap, o.cap); vh.swap(o.vh); std::swap(vresv, o.vresv);
-        std::swap(vresv_size, o.vresv_size); std::swap(vchunk, o.vchunk); std::swap(vmapped, o.vmapped);
+        std::swap(p, o.p);
+        std::swap(cap, o.cap);
+        std::swap(grp, o.grp);
     }
     void release()
     {
-        if (vresv) {
-            for (size_t k = 0; k < vmapped; ++k) (void)hipMemUnmap((char *)p + k * vchunk, vchunk);   // one unmap per map
-            for (auto h : vh) (void)hipMemRelease(h);
-            // The reservation is deliberately NOT given back (hipMemAddressFree): a later reservation would be handed
-            // the same addresses, and a kernel touching a range that has been mapped, unmapped and mapped again
-            // faults now and then on ROCm 7.2 ("Memory access fault ... Reason: Unknown": tools/vmm_probe2.hip, and
-            // the GPU test suite when decoders of large codes came and went in one process).  Address space is not
-            // memory: a reservation of an unmapped range costs nothing, and 47 bits hold thousands of them.
-            (void)hipGetLastError();
-            vh.clear();
-            vresv = nullptr;
-            vresv_size = vchunk = vmapped = 0;
-        } else if (p) {
-            (void)hipFree(p);
-        }
+        if (!grp.empty()) pool_put(std::move(grp));
+        else if (p) (void)hipFree(p);
+        grp = ChunkGroup();
         p = nullptr;
         cap = 0;
     }
@@ -209,7 +303,7 @@ struct ldpc_bp_decoder {
     ldpc_status prepare_kernel(const void *fn, int threads, size_t lds, int *per_cu);
     int lds_logS[2] = {-1, -1};   // [want_llr]: syndromes per workgroup pass of the LDS kernel, -1 = does not fit
     // device graph
-    DevBuf row_ptr, edge_bit, col_ptr, csc2csr;
+    DevBuf row_ptr, edge_bit, col_ptr, csc2csr, csc_row;   // (csc_row: check of every CSC edge = rowval)
     // workspace
     DevBuf msg;               // [resident_tiles][nnz][64] double
     DevBuf ctrl;              // queue (u32) + sum_iters (u64), 64 B
@@ -253,7 +347,7 @@ struct ldpc_bp_decoder {
 
     ~ldpc_bp_decoder()
     {
-        DevBuf *all[] = {&row_ptr, &edge_bit, &col_ptr, &csc2csr, &msg, &ctrl, &synmask, &nevermask,
+        DevBuf *all[] = {&row_ptr, &edge_bit, &col_ptr, &csc2csr, &csc_row, &msg, &ctrl, &synmask, &nevermask,
                          &errmask, &finmask, &llr_t, &st_all, &node_msg, &done_ctr, &team_ws, &team_ws_lvl[0], &team_ws_lvl[1], &cold};
         for (DevBuf *b : all) b->release();
         for (int l = 0; l < 2; ++l)
@@ -333,7 +427,7 @@ static size_t slot_pad_bytes()
 // virtual and the physical address are aligned alike, and the sweeps keep ~12,000 distinct 2 MiB pages hot (768
 // slots x 16 rows in flight).  Returns LDPC_ERR_UNSUPPORTED when the request is small (or LDPC_WS_ALLOC=malloc):
 // the caller then uses hipMalloc.
-static ldpc_status big_alloc(DevBuf &b, size_t bytes, int device)
+static ldpc_status big_alloc(DevBuf &b, size_t bytes, int device, bool fresh = false)
 {
     static const std::string ws_alloc = [] { const char *e = std::getenv("LDPC_WS_ALLOC"); return std::string(e ? e : ""); }();
     if (ws_alloc == "malloc" || bytes < ((size_t)1 << 30)) return LDPC_ERR_UNSUPPORTED;
@@ -344,7 +438,7 @@ static ldpc_status big_alloc(DevBuf &b, size_t bytes, int device)
         shuffle = ws_alloc.find(":shuffle") != std::string::npos;
     }
     if (bytes <= b.cap) return LDPC_OK;
-    const ldpc_status st = b.ensure_chunked(bytes, chunk, std::max<size_t>(chunk, (size_t)1 << 30), shuffle, device);
+    const ldpc_status st = b.ensure_chunked(bytes, chunk, std::max<size_t>(chunk, (size_t)1 << 30), shuffle, device, fresh);
     if (st == LDPC_OK || st == LDPC_ERR_OUT_OF_MEMORY) return st;
     return LDPC_ERR_UNSUPPORTED;   // the virtual-memory API failed for another reason: fall back to hipMalloc
 }
@@ -397,29 +491,37 @@ static ldpc_status ensure_workspace(ldpc_bp_decoder *d, size_t bytes, int grid, 
             return -1.f;
         return ms;
     };
-    // the fast class in absolute terms (what 512+ streaming workgroups reach: >= 6.0 TB/s of probe traffic; a
-    // smaller grid -- the team kernel's medium batches -- cannot be judged that way and takes the first group)
-    auto fast = [&](float ms) { return ms > 0 && probe_bytes / ((double)ms * 1e-3) >= 6.0e12; };
+    // the fast class in absolute terms: >= 6.0 TB/s of probe traffic (what 512+ streaming workgroups reach; a smaller
+    // grid -- the team kernel's medium batches -- cannot be judged that way and takes the first group)
+    // a group out of the pool that has been probed as a workspace of this size before keeps its grade
+    auto graded = [&](const DevBuf &b) { return b.grp.probe_bytes == bytes && b.grp.probe_tbs > 0.f; };
+    auto tbs_of = [&](float t) { return t > 0 ? (float)(probe_bytes / ((double)t * 1e-3) / 1e12) : 0.f; };
     std::vector<DevBuf> held;
     held.emplace_back();
     held.back().swap(first);
-    std::vector<float> ms;
-    ms.push_back(probe(held[0].p));
-    if (verbose) std::fprintf(stderr, "[ldpc] workspace group 0 @%p: probe %.3f ms (%.2f TB/s)\n", held[0].p, ms[0], ms[0] > 0 ? probe_bytes / (ms[0] * 1e-3) / 1e12 : 0.0);
+    std::vector<float> tbs;   // TB/s of probe traffic per held group
+    if (graded(held[0])) tbs.push_back(held[0].grp.probe_tbs);
+    else {
+        tbs.push_back(tbs_of(probe(held[0].p)));
+        held[0].grp.probe_tbs = tbs[0]; held[0].grp.probe_bytes = bytes;
+    }
+    if (verbose) std::fprintf(stderr, "[ldpc] workspace group 0 @%p: %.2f TB/s\n", held[0].p, tbs[0]);
     size_t best = 0;
+    int probed = 1;
     if (grid >= 512) {
-        for (int r = 1; r < max_rounds && !fast(ms[best]); ++r) {
+        for (int r = 1; r < max_rounds && tbs[best] < 6.0f; ++r) {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); break; }
             if (bytes > free_b / 2) break;
             DevBuf cand;
-            if (big_alloc(cand, bytes, d->device) != LDPC_OK) break;
+            if (big_alloc(cand, bytes, d->device, /*fresh=*/true) != LDPC_OK) break;   // OTHER physical memory than the pool's
             held.emplace_back();
             held.back().swap(cand);
-            ms.push_back(probe(held.back().p));
-            if (verbose) std::fprintf(stderr, "[ldpc] workspace group %d @%p: probe %.3f ms (%.2f TB/s)\n", r, held.back().p, ms.back(),
-                                      ms.back() > 0 ? probe_bytes / (ms.back() * 1e-3) / 1e12 : 0.0);
-            if (ms.back() > 0 && (ms[best] <= 0 || ms.back() < ms[best])) best = held.size() - 1;
+            tbs.push_back(tbs_of(probe(held.back().p)));
+            held.back().grp.probe_tbs = tbs.back(); held.back().grp.probe_bytes = bytes;
+            ++probed;
+            if (verbose) std::fprintf(stderr, "[ldpc] workspace group %d @%p: %.2f TB/s\n", r, held.back().p, tbs.back());
+            if (tbs.back() > tbs[best]) best = held.size() - 1;
         }
     }
     (void)hipStreamSynchronize(stream);
@@ -427,16 +529,22 @@ static ldpc_status ensure_workspace(ldpc_bp_decoder *d, size_t bytes, int grid, 
     (void)hipEventDestroy(ea);
     (void)hipEventDestroy(eb);
     d->msg.swap(held[best]);
-    d->placement_ms = ms[best] > 0 ? ms[best] : 0.f;
-    d->placement_candidates = (int)held.size();
-    for (DevBuf &b : held) b.release();
-    if (verbose) std::fprintf(stderr, "[ldpc] workspace: kept group %zu (%.3f ms) out of %zu probed\n", best, d->placement_ms, ms.size());
+    d->placement_ms = tbs[best] > 0 ? (float)(probe_bytes / ((double)tbs[best] * 1e12) * 1e3) : 0.f;
+    d->placement_candidates = probed;
+    for (DevBuf &b : held) b.release();   // (into the pool, with their grades)
+    if (verbose) std::fprintf(stderr, "[ldpc] workspace: kept group %zu (%.2f TB/s) out of %zu held\n", best, tbs[best], tbs.size());
     return LDPC_OK;
 }
 
 extern "C" {
 
 int32_t ldpc_abi_version(void) { return LDPC_MI355X_ABI_VERSION; }
+
+ldpc_status ldpc_trim_memory(void)
+{
+    pool_drop_all();
+    return LDPC_OK;
+}
 const char *ldpc_build_target(void) { return "gfx950"; }
 const char *ldpc_last_error(void) { return g_err.c_str(); }
 
@@ -503,7 +611,7 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     // sparse(H') (belief_propagation.jl:64): CSR of H, bits ascending inside each check,
     // plus for every CSC edge its position in that check-major order.
     std::vector<int> row_ptr((size_t)s + 1, 0), edge_bit((size_t)std::max<int64_t>(nnz, 1)),
-        col_ptr((size_t)n + 1), csc2csr((size_t)std::max<int64_t>(nnz, 1));
+        col_ptr((size_t)n + 1), csc2csr((size_t)std::max<int64_t>(nnz, 1)), csc_row((size_t)std::max<int64_t>(nnz, 1));
     for (int64_t k = 0; k < nnz; ++k) row_ptr[(size_t)rowval[k] + 1]++;
     for (int64_t i = 0; i < s; ++i) {
         d->max_cdeg = std::max(d->max_cdeg, row_ptr[(size_t)i + 1]);
@@ -518,6 +626,7 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
                 int q = fill[(size_t)rowval[k]]++;
                 edge_bit[(size_t)q] = (int)j;
                 csc2csr[(size_t)k] = q;
+                csc_row[(size_t)k] = (int)rowval[k];
             }
         }
         col_ptr[(size_t)n] = (int)nnz;
@@ -534,7 +643,8 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
         return LDPC_OK;
     };
     if ((st = upload(d->row_ptr, row_ptr)) != LDPC_OK || (st = upload(d->edge_bit, edge_bit)) != LDPC_OK ||
-        (st = upload(d->col_ptr, col_ptr)) != LDPC_OK || (st = upload(d->csc2csr, csc2csr)) != LDPC_OK) {
+        (st = upload(d->col_ptr, col_ptr)) != LDPC_OK || (st = upload(d->csc2csr, csc2csr)) != LDPC_OK ||
+        (st = upload(d->csc_row, csc_row)) != LDPC_OK) {
         delete d;
         return st;
     }
@@ -653,7 +763,7 @@ ldpc_status ldpc_bp_get_info(const ldpc_bp_decoder *d, ldpc_bp_info *info)
     info->max_check_degree = d->max_cdeg; info->max_bit_degree = d->max_bdeg;
     info->device = d->device; info->tile_syndromes = kTile; info->waves_per_tile = d->last_threads / 64;
     info->resident_tiles = d->last_grid;
-    const DevBuf *all[] = {&d->row_ptr, &d->edge_bit, &d->col_ptr, &d->csc2csr, &d->msg, &d->ctrl, &d->synmask,
+    const DevBuf *all[] = {&d->row_ptr, &d->edge_bit, &d->col_ptr, &d->csc2csr, &d->csc_row, &d->msg, &d->ctrl, &d->synmask,
                            &d->nevermask, &d->errmask, &d->finmask, &d->llr_t, &d->st_all, &d->node_msg, &d->pipe_dev[0], &d->pipe_dev[1], &d->pipe_dev[2],
                            &d->lvl_state[0], &d->lvl_state[1], &d->lvl_list[0], &d->lvl_list[1], &d->lvl_it[0], &d->lvl_it[1],
                            &d->lvl_syn[0], &d->lvl_syn[1], &d->lvl_never[0], &d->lvl_never[1], &d->lvl_err[0], &d->lvl_err[1], &d->lvl_fin[0], &d->lvl_fin[1],
@@ -748,7 +858,6 @@ static int team_size(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
         const int64_t cap = std::min<int64_t>(64, std::max<int64_t>(gcap, d->nnz / 1024));
         team = std::min<int64_t>(cap, (int64_t)8 * per_xcd / ntiles);
     }
-    if ((size_t)ntiles * ((size_t)d->max_iters + 32) * sizeof(u64) > ((size_t)16 << 20)) team = 1;
     return team < 3 ? 1 : (int)team;   // two workgroups per tile measured no better than the tile kernel's one of 16 waves
 }
 
@@ -1074,7 +1183,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         // level's count on the wrong side of node_take / team_cap and return at once.
         L.node_take = (d->node_ok && d->variant == 0 && d->node_take_max > 0)
                           ? (unsigned)std::min<int64_t>(d->node_take_max, (int64_t)L.cap_tiles * kTile) : 0u;
-        if (L.node_take && d->max_iters <= 4096 && team_geometry(d, want_llr, &L.t_per_xcd, &L.t_gcap) && L.t_gcap >= 3) {
+        if (L.node_take && team_geometry(d, want_llr, &L.t_per_xcd, &L.t_gcap) && L.t_gcap >= 3) {
             const int tiles_max = std::min(8 * (L.t_per_xcd / 3), L.cap_tiles);   // >= 3 members per tile
             if ((unsigned)tiles_max * kTile > L.node_take) L.team_cap = (unsigned)tiles_max * kTile;
         }
@@ -1092,7 +1201,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         HIP_TRY(hipGetLastError());
     }
     const int *a_row = (const int *)d->row_ptr.p, *a_eb = (const int *)d->edge_bit.p, *a_col = (const int *)d->col_ptr.p,
-              *a_c2r = (const int *)d->csc2csr.p;
+              *a_c2r = (const int *)d->csc2csr.p, *a_crow = (const int *)d->csc_row.p;
     const unsigned ticket = (unsigned)(d->ncalls & 0x7fffffffu) ? (unsigned)(d->ncalls & 0x7fffffffu) : 0x7fffffffu;
     // per pass: the hot parameters travel by value (BPParams), the rest in a BPCold block in device memory
     BPCold cold[3] = {};
@@ -1143,14 +1252,14 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     static const int always_release = std::getenv("LDPC_TEAM_ALWAYS_RELEASE") ? 1 : 0;
     auto team_params = [&](DevBuf &wsbuf, int tiles, TeamParams &tp) -> ldpc_status {
         const size_t ctl_bytes = (size_t)tiles * kTeamCtlWords * sizeof(unsigned int);
-        const size_t mism_stride = ((size_t)d->max_iters + 31) & ~(size_t)31;
-        const size_t ws_bytes = ctl_bytes + (size_t)tiles * mism_stride * sizeof(u64);
+        const size_t par_stride = ((size_t)std::max<int64_t>(d->s, 1) + 31) & ~(size_t)31;
+        const size_t ws_bytes = ctl_bytes + (size_t)tiles * par_stride * sizeof(u64);
         ldpc_status r = wsbuf.ensure(ws_bytes);
         if (r != LDPC_OK) return r;
         HIP_TRY(hipMemsetAsync(wsbuf.p, 0, ws_bytes, stream));
         tp.ctl = (unsigned int *)wsbuf.p;
-        tp.mism = (u64 *)((char *)wsbuf.p + ctl_bytes);
-        tp.mism_stride = (int)mism_stride;
+        tp.par = (u64 *)((char *)wsbuf.p + ctl_bytes);
+        tp.par_stride = (int)par_stride;
         tp.fault = d->team_fault_dev;
         tp.always_release = always_release;
         tp.scatter = 0;
@@ -1169,7 +1278,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         tp.inject_fault = d->inject_fault ? 1 : 0;   // (tests)
         team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr);
         const u64 *a_syn = (const u64 *)d->synmask.p, *a_nev = (const u64 *)d->nevermask.p;
-        void *args[] = {&p, &tp, &a_row, &a_eb, &a_col, &a_c2r, &a_syn, &a_nev};
+        void *args[] = {&p, &tp, &a_row, &a_eb, &a_col, &a_c2r, &a_crow, &a_syn, &a_nev};
         const hipError_t te = launch_team_grid(d, tk, team_grid, args, stream);
         if (te != hipSuccess) {
             // a team grid the runtime refuses must not fail the call: the tile kernel decodes the batch (one
@@ -1232,7 +1341,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             tp.G = L.t_gcap;
             tp.count_max = L.team_cap;
             team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr);
-            void *args[] = {&q3, &tp, &a_row, &a_eb, &a_col, &a_c2r, &l_syn, &l_nev};
+            void *args[] = {&q3, &tp, &a_row, &a_eb, &a_col, &a_c2r, &a_crow, &l_syn, &l_nev};
             HIP_TRY(launch_team_grid(d, tk, 8 * L.t_per_xcd, args, stream));
         }
     }

@@ -342,4 +342,8 @@ def test_two_c3_size_handles_from_two_threads(ldpc, gpu):
         assert all(torch.equal(a, b) for a, b in zip(results[k], lone[k])), k
     del results, lone
     torch.cuda.empty_cache()
+    # the chunk groups of closed decoders wait in the library's pool (up to 64 GiB) for the next decoder of that size;
+    # ldpc_trim_memory gives them back
+    assert torch.cuda.mem_get_info()[0] < free0 - (20 << 30)
+    ldpc._capi.check(ldpc._capi.lib().ldpc_trim_memory())
     assert torch.cuda.mem_get_info()[0] >= free0 - (2 << 30)     # every group, level and candidate was given back
