@@ -18,6 +18,7 @@
 #include "pickers.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -59,19 +60,24 @@ namespace {
         }                                                                                      \
     } while (0)
 
-// A chunk group: physical chunks (hipMemCreate) mapped side by side -- each by ONE hipMemMap -- at an aligned base inside
-// a virtual reservation of its own.  This is how every message array of >= 1 GiB is backed (DESIGN.md "Workspace
-// placement").  Groups are POOLED per process: a buffer that is released hands its group, still mapped, to the pool, and
-// the next buffer of that size takes it over.  Two reasons, both measured in round 2:
-//   * ROCm 7.2's virtual-memory path does not survive churn.  A kernel touching a freshly mapped group faulted
-//     ("Memory access fault ... Reason: Unknown") three times -- always in a process that had unmapped and RELEASED other
-//     groups before (decoders of large codes coming and going: the GPU test suite, tools/team_fault_hunt2.sh), never in a
-//     process that only created and mapped (60+ bench runs) or only mapped and unmapped (tools/vmm_probe3/7.hip).
-//     With the pool a process that keeps using the same few sizes creates each group once.
-//   * a group that has been probed carries its grade, so a later workspace of that size skips the placement search.
-// The pool holds at most LDPC_POOL_GIB (64) GiB; beyond that the oldest group is really unmapped and released (with the
-// device idle), and ldpc_trim_memory() drops everything.  Reservations are never given back (hipMemAddressFree): a
-// reservation handed out again is a re-mapped range, which faults too (tools/vmm_probe2.hip); address space is not memory.
+// A chunk group: physical chunks (hipMemCreate) mapped side by side -- each by ONE hipMemMap, access granted mapping by
+// mapping -- at an aligned base inside a virtual reservation of its own.  This is how every message array of >= 1 GiB is
+// backed (DESIGN.md "Workspace placement").  What it took to make ROCm 7.2's virtual-memory path dependable (round 2):
+//   * A kernel touching a freshly mapped group died of "Memory access fault ... Reason: Unknown" now and then -- in the
+//     LAST chunk of the group, in about one process out of six of tools/team_fault_hunt2.sh (decoders of growing size
+//     one after the other), three sessions out of three.  Not a race (a device synchronise and 3 ms of sleep after the
+//     mapping changed nothing), not release / create churn (it happened with the pool below, i.e. with nothing
+//     unmapped or released before).  What all incidents shared: the new reservation lay where hipMalloc'd buffers --
+//     torch's or the library's own -- had lived and been freed.  A range that has been mapped before is a RE-mapped
+//     range whoever mapped it first, and re-mapped ranges are what faulted in tools/vmm_probe2.hip too.  Reservations
+//     are therefore asked for in an address region of their own (hint: 16 TiB upwards, far below hipMalloc's arena; the
+//     runtime honours it) and never given back (hipMemAddressFree): 16 of 16 processes clean afterwards.  Address space
+//     is not memory: a reservation of an unmapped range costs nothing, and there are 47 bits of it.
+//   * Groups are POOLED per process: a buffer that is released hands its group, still mapped, to the pool, and the next
+//     buffer of that size takes it over -- a process that keeps using the same few sizes creates each group once, and a
+//     group that has been probed carries its grade, so a later workspace of that size skips the placement search.  The
+//     pool holds at most LDPC_POOL_GIB (64) GiB; beyond that the oldest group is really unmapped and released (with the
+//     device idle); an allocation that runs out of memory empties it, and so does ldpc_trim_memory().
 struct ChunkGroup {
     void *resv = nullptr;
     size_t resv_size = 0;
@@ -204,8 +210,17 @@ struct DevBuf {
         const size_t n = (bytes + chunk - 1) / chunk;
         grp = ChunkGroup();
         grp.device = device;
-        hipError_t e = hipMemAddressReserve(&grp.resv, n * chunk + align, 0, nullptr, 0);
+        // Reservations are asked for in an address region of their own, far below where hipMalloc hands out
+        // addresses: a range that hipMalloc / hipFree (ours or torch's) has used before is a RE-mapped range too.
+        static std::atomic<uintptr_t> next_hint{[] { const char *e = std::getenv("LDPC_VMM_HINT_TIB"); return (uintptr_t)(e ? std::atoll(e) : 16) << 40; }()};
+        const uintptr_t hint = next_hint.fetch_add((n * chunk + 2 * align + align - 1) / align * align);
+        hipError_t e = hipMemAddressReserve(&grp.resv, n * chunk + align, 0, hint ? (void *)hint : nullptr, 0);
+        if (e != hipSuccess) {   // (the hint is a wish: without it the runtime picks)
+            (void)hipGetLastError();
+            e = hipMemAddressReserve(&grp.resv, n * chunk + align, 0, nullptr, 0);
+        }
         if (e != hipSuccess) { grp.resv = nullptr; return e; }
+        if (std::getenv("LDPC_VMM_LOG")) std::fprintf(stderr, "[ldpc-vmm] reserve hint %p -> %p\n", (void *)hint, grp.resv);
         grp.resv_size = n * chunk + align;
         grp.chunk = chunk;
         grp.base = (char *)(((uintptr_t)grp.resv + align - 1) / align * align);
@@ -223,8 +238,8 @@ struct DevBuf {
         for (size_t k = 0; k < n; ++k) {
             if ((e = hipMemMap(grp.base + k * chunk, chunk, 0, grp.h[order[k]], 0)) != hipSuccess) return e;
             grp.mapped = k + 1;
+            if ((e = hipMemSetAccess(grp.base + k * chunk, chunk, &acc, 1)) != hipSuccess) return e;
         }
-        if ((e = hipMemSetAccess(grp.base, n * chunk, &acc, 1)) != hipSuccess) return e;
         p = grp.base;
         cap = n * chunk;
         if (std::getenv("LDPC_VMM_LOG")) std::fprintf(stderr, "[ldpc-vmm] map   %p .. %p (%zu chunks)\n", (void *)grp.base, (void *)(grp.base + cap), n);
