@@ -298,6 +298,9 @@ def test_two_c3_size_handles_from_two_threads(ldpc, gpu):
         return syn
 
     syns = [make(101), make(202)]
+    ldpc._capi.check(ldpc._capi.lib().ldpc_trim_memory())
+    torch.cuda.synchronize()
+    free_start = torch.cuda.mem_get_info()[0]
     lone = []
     for syn in syns:                                   # the reference: one decoder at a time
         dec = ldpc.BeliefPropagationDecoder(H, 0.02, 50)
@@ -310,7 +313,6 @@ def test_two_c3_size_handles_from_two_threads(ldpc, gpu):
         del e
         dec.close()
     torch.cuda.synchronize()
-    free0 = torch.cuda.mem_get_info()[0]
     errors, results = [], [None, None]
 
     def worker(k):
@@ -344,6 +346,6 @@ def test_two_c3_size_handles_from_two_threads(ldpc, gpu):
     torch.cuda.empty_cache()
     # the chunk groups of closed decoders wait in the library's pool (up to 64 GiB) for the next decoder of that size;
     # ldpc_trim_memory gives them back
-    assert torch.cuda.mem_get_info()[0] < free0 - (20 << 30)
+    assert torch.cuda.mem_get_info()[0] < free_start - (20 << 30)
     ldpc._capi.check(ldpc._capi.lib().ldpc_trim_memory())
-    assert torch.cuda.mem_get_info()[0] >= free0 - (2 << 30)     # every group, level and candidate was given back
+    assert torch.cuda.mem_get_info()[0] >= free_start - (2 << 30)     # every group, level and candidate was given back
