@@ -469,11 +469,13 @@ static ldpc_status big_alloc(DevBuf &b, size_t bytes, int device, bool fresh = f
 //     (tools/vmm_probe6.hip) -- so a search has to look at groups of chunks, not at single ones;
 //   * plain hipMalloc gets the slow class most of the time in a fresh process (5 of 6), 1 GiB chunks at a 1 GiB-
 //     aligned base the fast one most of the time (22 of 26 bench runs on three boxes; never on a fourth).
-// So: the workspace is a group of 1 GiB chunks; it is probed with both sweeps' patterns (one untimed
-// first-touch pass, one timed pass, ~35 ms); if it is not of the fast class another group is allocated WHILE the
-// candidates so far are held (freed memory would come straight back) and probed, up to LDPC_PLACEMENT_ROUNDS
-// groups (default 4; 1 = take the first) and never beyond half of the free HBM; the best is kept, the others are
-// released.  Transient HBM: 1x when the first group is fast, at most rounds x.  First-call cost 0.1 s per group.
+// So: the workspace is a group of 1 GiB chunks (out of the pool if a graded one of that size is there); it is probed
+// with both sweeps' patterns (one untimed first-touch pass, one timed pass, ~35 ms); unless it is of the fast class in
+// absolute terms another group is allocated WHILE the first is held (freed memory would come straight back) and
+// probed, and the better one kept; a third and fourth (LDPC_PLACEMENT_ROUNDS, default 4; 1 = take the first) only
+// while the best is still of the slow class, and never beyond half of the free HBM.  The others go to the pool with
+// their grades.  Transient HBM: 1x when the first group is fast, usually 2x, at most rounds x.  First-call cost
+// ~0.1 s per group.
 static ldpc_status ensure_workspace(ldpc_bp_decoder *d, size_t bytes, int grid, size_t slot_stride_bytes,
                                     hipStream_t stream)
 {
@@ -524,7 +526,12 @@ static ldpc_status ensure_workspace(ldpc_bp_decoder *d, size_t bytes, int grid, 
     size_t best = 0;
     int probed = 1;
     if (grid >= 512) {
-        for (int r = 1; r < max_rounds && tbs[best] < 6.0f; ++r) {
+        // How far to look: a group of the fast class in absolute terms (>= 6.0 TB/s) ends the search; otherwise a second
+        // group is always tried and the better of the two kept (the probe's scale moves by a few per cent from box to box
+        // -- a box whose groups all probed 5.45-5.82 ran the kernel at 1.167 s on the 5.82 one -- so the comparison
+        // inside a box is worth more than the absolute number); a third and fourth only while the best is still in the
+        // slow class (< 5.3 TB/s: launches of 1.4 s).
+        for (int r = 1; r < max_rounds && tbs[best] < 6.0f && !(r >= 2 && tbs[best] >= 5.3f); ++r) {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); break; }
             if (bytes > free_b / 2) break;
