@@ -473,8 +473,8 @@ static ldpc_status big_alloc(DevBuf &b, size_t bytes, int device, bool fresh = f
 // with both sweeps' patterns (one untimed first-touch pass, one timed pass, ~35 ms); unless it is of the fast class in
 // absolute terms another group is allocated WHILE the first is held (freed memory would come straight back) and
 // probed, and the better one kept; a third and fourth (LDPC_PLACEMENT_ROUNDS, default 4; 1 = take the first) only
-// while the best is still of the slow class, and never beyond half of the free HBM.  The others go to the pool with
-// their grades.  Transient HBM: 1x when the first group is fast, usually 2x, at most rounds x.  First-call cost
+// while the best is still of the slow class, and never beyond half of the free HBM.  The losers are unmapped and
+// released at once.  Transient HBM: 1x when the first group is fast, usually 2x, at most rounds x.  First-call cost
 // ~0.1 s per group.
 static ldpc_status ensure_workspace(ldpc_bp_decoder *d, size_t bytes, int grid, size_t slot_stride_bytes,
                                     hipStream_t stream)
@@ -553,7 +553,10 @@ static ldpc_status ensure_workspace(ldpc_bp_decoder *d, size_t bytes, int grid, 
     d->msg.swap(held[best]);
     d->placement_ms = tbs[best] > 0 ? (float)(probe_bytes / ((double)tbs[best] * 1e12) * 1e3) : 0.f;
     d->placement_candidates = probed;
-    for (DevBuf &b : held) b.release();   // (into the pool, with their grades)
+    for (DevBuf &b : held) {              // the groups that lost are given back for real: known to be no better,
+        if (!b.grp.empty()) b.grp.destroy();   // they would only sit in the pool
+        b.p = nullptr; b.cap = 0;
+    }
     if (verbose) std::fprintf(stderr, "[ldpc] workspace: kept group %zu (%.2f TB/s) out of %zu held\n", best, tbs[best], tbs.size());
     return LDPC_OK;
 }
