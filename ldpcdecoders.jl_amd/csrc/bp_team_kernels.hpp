@@ -32,11 +32,8 @@ struct TeamParams {
     int G;                      // workgroups per tile
     // per tile one control block of kTeamCtlWords words, zero at launch (see team_barrier)
     unsigned int *ctl;
-    u64 *par;                   // [ntiles][par_stride] parity of the current hard decisions over every check (lane masks), zero at
-                                // launch: kept up to date by the variable sweep (XOR of every decision word that changes into
-                                // the words of the bit's checks), so that the convergence test is s word compares that every
-                                // member makes for itself -- no third team barrier to share a verdict
-    int par_stride;             // >= s, a multiple of 32 words
+    u64 *mism;                  // [ntiles][mism_stride] mismatch words of the convergence tests, zero at launch
+    int mism_stride;            // >= max_iters, a multiple of 32 words
     unsigned int *fault;        // host-mapped: set when a team barrier timed out
     int always_release;         // experiments: 1 = release at every barrier even when the team shares one XCD
     int scatter;                // tests: 1 = deal a team's members over ALL XCDs (exercises the release path and
@@ -106,7 +103,7 @@ template <int DC, int DV, bool WANT_LLR, int THREADS>
 __global__ void
 __launch_bounds__(THREADS, (min_waves_per_simd<DC, DV, THREADS>()))
 bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const int *__restrict__ edge_bit,
-               const int *__restrict__ col_ptr, const int *__restrict__ csc2csr, const int *__restrict__ csc_row,
+               const int *__restrict__ col_ptr, const int *__restrict__ csc2csr,
                const u64 *__restrict__ synmask, const u64 *__restrict__ nevermask)
 {
     __shared__ int sh_ok;
@@ -140,7 +137,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     double *const Mt = p.msg + (size_t)tile * (size_t)p.slot_stride + lane;
     unsigned int *const ctr = tp.ctl + (size_t)tile * kTeamCtlWords;
     unsigned int *const xccs = ctr + 32;
-    u64 *const par = tp.par + (size_t)tile * (size_t)tp.par_stride;
+    u64 *const mw = tp.mism + (size_t)tile * (size_t)tp.mism_stride;
     unsigned int epoch = 0;                                    // barriers passed
     __shared__ int sh_one_xcd;
     if (threadIdx.x == 0) {
@@ -198,30 +195,38 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
             if (WANT_LLR) {
                 if ((active >> lane) & 1ull) p.llr[((size_t)tile * n + j) * kTile + lane] = log(1.0 / T);  // :163
             }
-            if (lane == 0) {
-                // every lane, the stopped ones too (theirs were captured when they stopped); what changed against the
-                // previous iteration flips the parities of the bit's checks (:180: H * err, kept incrementally)
-                const u64 delta = it == 1 ? dec : (dec ^ em[j]);   // (this wave wrote em[j] itself last time)
-                em[j] = dec;
-                if (delta)
-                    for (int k = 0; k < deg; ++k)
-                        __hip_atomic_fetch_xor(&par[csc_row[c0 + k]], delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (lane == 0) em[j] = dec;   // every lane; the stopped ones' decisions were captured when they stopped
         }
         const u64 t3 = wall_clock64();
         if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd)) return;
-        // ---- convergence test (:180-184): parity words against syndrome words, ALL s of them by every member (64 KB
-        //      out of the L2 at C3) -- the verdict is the same everywhere without a third barrier
+        // ---- convergence test (:180-184): lane = check, words = 64 syndromes; the team ORs into mw[it-1]
         u64 mism = 0;
-        for (int i = w * 64 + lane; i < s; i += W * 64)
-            mism |= __hip_atomic_load(&par[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ^ syn[i];
+        for (int i = gw * 64 + lane; i < s; i += GW * 64) {
+            u64 par = 0;
+            const int e1 = row_ptr[i + 1];
+            for (int e = row_ptr[i]; e < e1; e += 8) {
+                int jb[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) jb[q] = (e + q < e1) ? edge_bit[e + q] : -1;
+                u64 wv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) wv[q] = (jb[q] >= 0) ? em[jb[q]] : 0ull;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) par ^= wv[q];
+            }
+            mism |= par ^ syn[i];
+        }
         mism = wave_or(mism);
         if (lane == 0) sh_mism[w] = mism;
         __syncthreads();
-        u64 Uall = never;
+        if (threadIdx.x == 0) {
+            u64 part = 0;
 #pragma unroll
-        for (int q = 0; q < W; ++q) Uall |= sh_mism[q];
-        const u64 U = uniform64(Uall);
+            for (int q = 0; q < W; ++q) part |= sh_mism[q];
+            if (part) __hip_atomic_fetch_or(&mw[it - 1], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd)) return;
+        const u64 U = uniform64(never | __hip_atomic_load(&mw[it - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         const int total = it0 + it;                            // iterations of this lane's syndrome so far
         const u64 newly = active & ~U;
         if ((newly >> lane) & 1ull) { my_iters = total; my_conv = 1; }

@@ -318,7 +318,7 @@ struct ldpc_bp_decoder {
     ldpc_status prepare_kernel(const void *fn, int threads, size_t lds, int *per_cu);
     int lds_logS[2] = {-1, -1};   // [want_llr]: syndromes per workgroup pass of the LDS kernel, -1 = does not fit
     // device graph
-    DevBuf row_ptr, edge_bit, col_ptr, csc2csr, csc_row;   // (csc_row: check of every CSC edge = rowval)
+    DevBuf row_ptr, edge_bit, col_ptr, csc2csr;
     // workspace
     DevBuf msg;               // [resident_tiles][nnz][64] double
     DevBuf ctrl;              // queue (u32) + sum_iters (u64), 64 B
@@ -362,7 +362,7 @@ struct ldpc_bp_decoder {
 
     ~ldpc_bp_decoder()
     {
-        DevBuf *all[] = {&row_ptr, &edge_bit, &col_ptr, &csc2csr, &csc_row, &msg, &ctrl, &synmask, &nevermask,
+        DevBuf *all[] = {&row_ptr, &edge_bit, &col_ptr, &csc2csr, &msg, &ctrl, &synmask, &nevermask,
                          &errmask, &finmask, &llr_t, &st_all, &node_msg, &done_ctr, &team_ws, &team_ws_lvl[0], &team_ws_lvl[1], &cold};
         for (DevBuf *b : all) b->release();
         for (int l = 0; l < 2; ++l)
@@ -636,7 +636,7 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     // sparse(H') (belief_propagation.jl:64): CSR of H, bits ascending inside each check,
     // plus for every CSC edge its position in that check-major order.
     std::vector<int> row_ptr((size_t)s + 1, 0), edge_bit((size_t)std::max<int64_t>(nnz, 1)),
-        col_ptr((size_t)n + 1), csc2csr((size_t)std::max<int64_t>(nnz, 1)), csc_row((size_t)std::max<int64_t>(nnz, 1));
+        col_ptr((size_t)n + 1), csc2csr((size_t)std::max<int64_t>(nnz, 1));
     for (int64_t k = 0; k < nnz; ++k) row_ptr[(size_t)rowval[k] + 1]++;
     for (int64_t i = 0; i < s; ++i) {
         d->max_cdeg = std::max(d->max_cdeg, row_ptr[(size_t)i + 1]);
@@ -651,7 +651,6 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
                 int q = fill[(size_t)rowval[k]]++;
                 edge_bit[(size_t)q] = (int)j;
                 csc2csr[(size_t)k] = q;
-                csc_row[(size_t)k] = (int)rowval[k];
             }
         }
         col_ptr[(size_t)n] = (int)nnz;
@@ -668,8 +667,7 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
         return LDPC_OK;
     };
     if ((st = upload(d->row_ptr, row_ptr)) != LDPC_OK || (st = upload(d->edge_bit, edge_bit)) != LDPC_OK ||
-        (st = upload(d->col_ptr, col_ptr)) != LDPC_OK || (st = upload(d->csc2csr, csc2csr)) != LDPC_OK ||
-        (st = upload(d->csc_row, csc_row)) != LDPC_OK) {
+        (st = upload(d->col_ptr, col_ptr)) != LDPC_OK || (st = upload(d->csc2csr, csc2csr)) != LDPC_OK) {
         delete d;
         return st;
     }
@@ -788,7 +786,7 @@ ldpc_status ldpc_bp_get_info(const ldpc_bp_decoder *d, ldpc_bp_info *info)
     info->max_check_degree = d->max_cdeg; info->max_bit_degree = d->max_bdeg;
     info->device = d->device; info->tile_syndromes = kTile; info->waves_per_tile = d->last_threads / 64;
     info->resident_tiles = d->last_grid;
-    const DevBuf *all[] = {&d->row_ptr, &d->edge_bit, &d->col_ptr, &d->csc2csr, &d->csc_row, &d->msg, &d->ctrl, &d->synmask,
+    const DevBuf *all[] = {&d->row_ptr, &d->edge_bit, &d->col_ptr, &d->csc2csr, &d->msg, &d->ctrl, &d->synmask,
                            &d->nevermask, &d->errmask, &d->finmask, &d->llr_t, &d->st_all, &d->node_msg, &d->pipe_dev[0], &d->pipe_dev[1], &d->pipe_dev[2],
                            &d->lvl_state[0], &d->lvl_state[1], &d->lvl_list[0], &d->lvl_list[1], &d->lvl_it[0], &d->lvl_it[1],
                            &d->lvl_syn[0], &d->lvl_syn[1], &d->lvl_never[0], &d->lvl_never[1], &d->lvl_err[0], &d->lvl_err[1], &d->lvl_fin[0], &d->lvl_fin[1],
@@ -883,6 +881,7 @@ static int team_size(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
         const int64_t cap = std::min<int64_t>(64, std::max<int64_t>(gcap, d->nnz / 1024));
         team = std::min<int64_t>(cap, (int64_t)8 * per_xcd / ntiles);
     }
+    if ((size_t)ntiles * ((size_t)d->max_iters + 32) * sizeof(u64) > ((size_t)16 << 20)) team = 1;
     return team < 3 ? 1 : (int)team;   // two workgroups per tile measured no better than the tile kernel's one of 16 waves
 }
 
@@ -1208,7 +1207,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         // level's count on the wrong side of node_take / team_cap and return at once.
         L.node_take = (d->node_ok && d->variant == 0 && d->node_take_max > 0)
                           ? (unsigned)std::min<int64_t>(d->node_take_max, (int64_t)L.cap_tiles * kTile) : 0u;
-        if (L.node_take && team_geometry(d, want_llr, &L.t_per_xcd, &L.t_gcap) && L.t_gcap >= 3) {
+        if (L.node_take && d->max_iters <= 4096 && team_geometry(d, want_llr, &L.t_per_xcd, &L.t_gcap) && L.t_gcap >= 3) {
             const int tiles_max = std::min(8 * (L.t_per_xcd / 3), L.cap_tiles);   // >= 3 members per tile
             if ((unsigned)tiles_max * kTile > L.node_take) L.team_cap = (unsigned)tiles_max * kTile;
         }
@@ -1226,7 +1225,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         HIP_TRY(hipGetLastError());
     }
     const int *a_row = (const int *)d->row_ptr.p, *a_eb = (const int *)d->edge_bit.p, *a_col = (const int *)d->col_ptr.p,
-              *a_c2r = (const int *)d->csc2csr.p, *a_crow = (const int *)d->csc_row.p;
+              *a_c2r = (const int *)d->csc2csr.p;
     const unsigned ticket = (unsigned)(d->ncalls & 0x7fffffffu) ? (unsigned)(d->ncalls & 0x7fffffffu) : 0x7fffffffu;
     // per pass: the hot parameters travel by value (BPParams), the rest in a BPCold block in device memory
     BPCold cold[3] = {};
@@ -1277,14 +1276,14 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     static const int always_release = std::getenv("LDPC_TEAM_ALWAYS_RELEASE") ? 1 : 0;
     auto team_params = [&](DevBuf &wsbuf, int tiles, TeamParams &tp) -> ldpc_status {
         const size_t ctl_bytes = (size_t)tiles * kTeamCtlWords * sizeof(unsigned int);
-        const size_t par_stride = ((size_t)std::max<int64_t>(d->s, 1) + 31) & ~(size_t)31;
-        const size_t ws_bytes = ctl_bytes + (size_t)tiles * par_stride * sizeof(u64);
+        const size_t mism_stride = ((size_t)d->max_iters + 31) & ~(size_t)31;
+        const size_t ws_bytes = ctl_bytes + (size_t)tiles * mism_stride * sizeof(u64);
         ldpc_status r = wsbuf.ensure(ws_bytes);
         if (r != LDPC_OK) return r;
         HIP_TRY(hipMemsetAsync(wsbuf.p, 0, ws_bytes, stream));
         tp.ctl = (unsigned int *)wsbuf.p;
-        tp.par = (u64 *)((char *)wsbuf.p + ctl_bytes);
-        tp.par_stride = (int)par_stride;
+        tp.mism = (u64 *)((char *)wsbuf.p + ctl_bytes);
+        tp.mism_stride = (int)mism_stride;
         tp.fault = d->team_fault_dev;
         tp.always_release = always_release;
         tp.scatter = 0;
@@ -1303,7 +1302,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         tp.inject_fault = d->inject_fault ? 1 : 0;   // (tests)
         team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr);
         const u64 *a_syn = (const u64 *)d->synmask.p, *a_nev = (const u64 *)d->nevermask.p;
-        void *args[] = {&p, &tp, &a_row, &a_eb, &a_col, &a_c2r, &a_crow, &a_syn, &a_nev};
+        void *args[] = {&p, &tp, &a_row, &a_eb, &a_col, &a_c2r, &a_syn, &a_nev};
         const hipError_t te = launch_team_grid(d, tk, team_grid, args, stream);
         if (te != hipSuccess) {
             // a team grid the runtime refuses must not fail the call: the tile kernel decodes the batch (one
@@ -1366,7 +1365,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             tp.G = L.t_gcap;
             tp.count_max = L.team_cap;
             team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr);
-            void *args[] = {&q3, &tp, &a_row, &a_eb, &a_col, &a_c2r, &a_crow, &l_syn, &l_nev};
+            void *args[] = {&q3, &tp, &a_row, &a_eb, &a_col, &a_c2r, &l_syn, &l_nev};
             HIP_TRY(launch_team_grid(d, tk, 8 * L.t_per_xcd, args, stream));
         }
     }

@@ -13,8 +13,8 @@ namespace ldpc {
 typedef void (*bp_kernel_t)(BPParams, const int *, const int *, const int *, const int *, const u64 *, const u64 *);
 typedef void (*lds_kernel_t)(LdsParams, const int *, const int *, const int *, const int *);
 typedef void (*node_kernel_t)(NodeParams, const int *, const int *, const int *, const int *);
-typedef void (*team_kernel_t)(BPParams, TeamParams, const int *, const int *, const int *, const int *, const int *,
-                              const u64 *, const u64 *);
+typedef void (*team_kernel_t)(BPParams, TeamParams, const int *, const int *, const int *, const int *, const u64 *,
+                              const u64 *);
 
 bp_kernel_t pick_kernel(int dc, int dv, bool llr, int threads, bool second = false);   // pick_tile.hip
 lds_kernel_t pick_lds_kernel(int dc, int dv, bool llr, int threads);                   // pick_lds.hip
