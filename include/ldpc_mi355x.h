@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LDPC_MI355X_ABI_VERSION 1
+#define LDPC_MI355X_ABI_VERSION 2
 
 typedef enum ldpc_status {
     LDPC_OK = 0,

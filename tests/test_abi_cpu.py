@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/ldpc_mi355x.h but not exported"
     assert sorted(ldpc._capi.EXPORTED_SYMBOLS) == declared
-    assert lib.ldpc_abi_version() == 1 and lib.ldpc_build_target() == b"gfx950"
+    assert lib.ldpc_abi_version() == 2 and lib.ldpc_build_target() == b"gfx950"
 
 
 def test_code_object_is_gfx950_only():
