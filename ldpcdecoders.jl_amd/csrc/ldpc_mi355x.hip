@@ -472,8 +472,8 @@ static ldpc_status big_alloc(DevBuf &b, size_t bytes, int device, bool fresh = f
 // So: the workspace is a group of 1 GiB chunks (out of the pool if a graded one of that size is there); it is probed
 // with both sweeps' patterns (one untimed first-touch pass, one timed pass, ~35 ms); unless it is of the fast class in
 // absolute terms another group is allocated WHILE the first is held (freed memory would come straight back) and
-// probed, and the better one kept; a third and fourth (LDPC_PLACEMENT_ROUNDS, default 4; 1 = take the first) only
-// while the best is still of the slow class, and never beyond half of the free HBM.  The losers are unmapped and
+// probed, and the better one kept; up to three more (LDPC_PLACEMENT_ROUNDS, default 5; 1 = take the first) only
+// while the best is still below 5.75 TB/s, and never beyond half of the free HBM.  The losers are unmapped and
 // released at once.  Transient HBM: 1x when the first group is fast, usually 2x, at most rounds x.  First-call cost
 // ~0.1 s per group.
 static ldpc_status ensure_workspace(ldpc_bp_decoder *d, size_t bytes, int grid, size_t slot_stride_bytes,
@@ -482,7 +482,7 @@ static ldpc_status ensure_workspace(ldpc_bp_decoder *d, size_t bytes, int grid, 
     if (bytes <= d->msg.cap) return LDPC_OK;
     d->msg.release();
     const bool verbose = std::getenv("LDPC_PLACEMENT_VERBOSE") != nullptr;
-    static const int max_rounds = [] { const char *e = std::getenv("LDPC_PLACEMENT_ROUNDS"); return e ? std::max(1, std::min(8, std::atoi(e))) : 4; }();
+    static const int max_rounds = [] { const char *e = std::getenv("LDPC_PLACEMENT_ROUNDS"); return e ? std::max(1, std::min(8, std::atoi(e))) : 5; }();
     d->placement_ms = 0.f;
     d->placement_candidates = 0;
     DevBuf first;
@@ -529,9 +529,9 @@ static ldpc_status ensure_workspace(ldpc_bp_decoder *d, size_t bytes, int grid, 
         // How far to look: a group of the fast class in absolute terms (>= 6.0 TB/s) ends the search; otherwise a second
         // group is always tried and the better of the two kept (the probe's scale moves by a few per cent from box to box
         // -- a box whose groups all probed 5.45-5.82 ran the kernel at 1.167 s on the 5.82 one -- so the comparison
-        // inside a box is worth more than the absolute number); a third and fourth only while the best is still in the
-        // slow class (< 5.3 TB/s: launches of 1.4 s).
-        for (int r = 1; r < max_rounds && tbs[best] < 6.0f && !(r >= 2 && tbs[best] >= 5.3f); ++r) {
+        // inside a box is worth more than the absolute number); a third, fourth and fifth only while the best is still
+        // below 5.75 TB/s (a 5.37 group ran the kernel at 1.35 s, the 5.0 class at 1.42 s).
+        for (int r = 1; r < max_rounds && tbs[best] < 6.0f && !(r >= 2 && tbs[best] >= 5.75f); ++r) {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); break; }
             if (bytes > free_b / 2) break;
