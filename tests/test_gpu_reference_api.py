@@ -275,7 +275,7 @@ def test_two_handles_from_two_threads(ldpc, gpu):
 def test_two_c3_size_handles_from_two_threads(ldpc, gpu):
     """Two decoders of the C3 code (n = 16384), each with a full-size batch of its own -- 65,536 syndromes, so each
     allocates the 24.75 GiB message workspace, the packed hand-off levels, and may run its placement search (up to
-    four 1 GiB-chunk groups held at once, never beyond half of the free HBM) -- created and driven concurrently from
+    five 1 GiB-chunk groups held at once, never beyond half of the free HBM) -- created and driven concurrently from
     two host threads on two streams.  Neither may starve the other of memory, and both must produce what a lone
     decoder produces."""
     import threading
