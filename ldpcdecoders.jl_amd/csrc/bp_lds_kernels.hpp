@@ -56,6 +56,14 @@ struct LdsParams {
     unsigned int done_ticket;
 };
 
+// Iteration 1 of the check sweep (belief_propagation.jl:135-150 with every bit -> check message still r, :129) only
+// depends on the check's degree and on the sign of its syndrome entry: the messages it writes are tabulated once per
+// workgroup -- by lds_check_unit itself, so bit for bit what every work item would compute -- and the sweep copies them:
+// no fp64 division in the iteration that 90-99 % of the syndromes of the low-error-rate configurations (C1/C2: per 0.01,
+// C5: per 0.005) need.  Degrees up to 16 (2 x 17 x 16 doubles); wider checks compute as before.
+constexpr int kFirstTabDeg = 16;
+constexpr size_t kFirstTabBytes = 2 * (kFirstTabDeg + 1) * kFirstTabDeg * sizeof(double);
+
 // LDS carve-up (bytes), shared by host and device
 __host__ __device__ inline size_t lds_bytes_needed(int s, int n, int nnz, int S, bool want_llr)
 {
@@ -65,6 +73,7 @@ __host__ __device__ inline size_t lds_bytes_needed(int s, int n, int nnz, int S,
     b += 64 * 8;                                // per-wave reduction words + control
     b += 2 * ((size_t)s + 1 + (size_t)n + 1 + 2 * (size_t)nnz) + 16;   // the Tanner graph itself (uint16:
                                                                         // nnz*8 B must fit the LDS, so every index < 65536)
+    b += kFirstTabBytes + 8;                    // check -> bit messages of iteration 1 by (sign, degree, position)
     return b;
 }
 
@@ -175,7 +184,12 @@ bp_lds_kernel(LdsParams p, const int *__restrict__ g_row_ptr, const int *__restr
     idx_t *edge_bit = row_ptr + (s + 1);                        // [nnz]
     idx_t *col_ptr = edge_bit + nnz;                            // [n+1]
     idx_t *csc2csr = col_ptr + (n + 1);                         // [nnz]
+    double *ftab = (double *)(((uintptr_t)(csc2csr + nnz) + 7) & ~(uintptr_t)7);   // [2][kFirstTabDeg + 1][kFirstTabDeg]
     __shared__ int sh_group;
+    for (int t = threadIdx.x; t < 2 * (kFirstTabDeg + 1); t += THREADS) {   // (sign, degree) -> the messages of iteration 1
+        const int neg = t & 1, d = t >> 1;
+        if (d <= DC) lds_check_unit<DC>(ftab + (size_t)(neg * (kFirstTabDeg + 1) + d) * kFirstTabDeg, 1, d, neg ? -1.0 : 1.0, true, p.r);
+    }
     for (int i = threadIdx.x; i <= s; i += THREADS) row_ptr[i] = (idx_t)g_row_ptr[i];
     for (int i = threadIdx.x; i <= n; i += THREADS) col_ptr[i] = (idx_t)g_col_ptr[i];
     for (int i = threadIdx.x; i < nnz; i += THREADS) { edge_bit[i] = (idx_t)g_edge_bit[i]; csc2csr[i] = (idx_t)g_csc2csr[i]; }
@@ -243,8 +257,14 @@ bp_lds_kernel(LdsParams p, const int *__restrict__ g_row_ptr, const int *__restr
                 const int i = u >> logS;
                 const int e0 = row_ptr[i];
                 const int deg = row_ptr[i + 1] - e0;
-                const double sigma = ((sbits[i] >> sig) & 1ull) ? -1.0 : 1.0;     // :136
-                lds_check_unit<DC>(M + (size_t)e0 * S + sig, S, deg, sigma, first, r);
+                const bool neg = (sbits[i] >> sig) & 1ull;                       // (-1)^syndrome[i]  :136
+                if (first && deg <= kFirstTabDeg && deg <= DC) {
+                    const double *tr = ftab + (size_t)((neg ? 1 : 0) * (kFirstTabDeg + 1) + deg) * kFirstTabDeg;
+                    double *Mi = M + (size_t)e0 * S + sig;
+                    for (int k = 0; k < deg; ++k) Mi[(size_t)k * S] = tr[k];
+                } else {
+                    lds_check_unit<DC>(M + (size_t)e0 * S + sig, S, deg, neg ? -1.0 : 1.0, first, r);
+                }
             }
             __syncthreads();
             const u64 t1 = LDS_CLOCK();
