@@ -156,10 +156,27 @@ __device__ __forceinline__ u64 wave_or(u64 v)
 // belief_propagation.jl:136-149.  `M` points at the check's first row + lane.
 // D is the EXACT degree: straight-line code, all D row loads issued back to back.
 // ---------------------------------------------------------------------------
+// the arithmetic of a check once its D factors a[k] = 2/(1+m[k]) - 1 are known: ordered prefix and suffix products
+template <int D>
+__device__ __forceinline__ void check_finish_exact(double *M, const double (&a)[D], double sigma)
+{
+    double pre[D];
+    double P = sigma;                                     // :136
+#pragma unroll
+    for (int k = 0; k < D; ++k) { pre[k] = P; P = P * a[k]; }          // :139-140
+    double S = 1.0;                                       // :143
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) {
+        const double t = pre[k] * S;                      // :146
+        stm(M + (size_t)k * kTile, (1.0 - t) / (1.0 + t));  // :147
+        S = S * a[k];                                     // :148
+    }
+}
+
 template <int D, bool FIRST>
 __device__ __forceinline__ void check_update_exact(double *M, double sigma, double r)
 {
-    double a[D], pre[D];
+    double a[D];
     if (FIRST) {
         const double a0 = 2.0 / (1.0 + r) - 1.0;          // every bit->check message is still r (:129)
 #pragma unroll
@@ -171,16 +188,26 @@ __device__ __forceinline__ void check_update_exact(double *M, double sigma, doub
 #pragma unroll
         for (int k = 0; k < D; ++k) a[k] = 2.0 / (1.0 + m[k]) - 1.0;   // :140 / :148 (same value both times)
     }
-    double P = sigma;                                     // :136
+    check_finish_exact<D>(M, a, sigma);
+}
+
+// Two checks of degree D at once: all 2 D row loads are issued before anything is computed (twice the bytes in
+// flight per wave; used where there are registers to spare: bp_team_kernels.hpp).  Same arithmetic per check.
+template <int D>
+__device__ __forceinline__ void check_update_pair(double *M0, double *M1, double sigma0, double sigma1)
+{
+    double m0[D], m1[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) { pre[k] = P; P = P * a[k]; }          // :139-140
-    double S = 1.0;                                       // :143
+    for (int k = 0; k < D; ++k) m0[k] = ldm(M0 + (size_t)k * kTile);
 #pragma unroll
-    for (int k = D - 1; k >= 0; --k) {
-        const double t = pre[k] * S;                      // :146
-        stm(M + (size_t)k * kTile, (1.0 - t) / (1.0 + t));  // :147
-        S = S * a[k];                                     // :148
-    }
+    for (int k = 0; k < D; ++k) m1[k] = ldm(M1 + (size_t)k * kTile);
+    double a[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) a[k] = 2.0 / (1.0 + m0[k]) - 1.0;
+    check_finish_exact<D>(M0, a, sigma0);
+#pragma unroll
+    for (int k = 0; k < D; ++k) a[k] = 2.0 / (1.0 + m1[k]) - 1.0;
+    check_finish_exact<D>(M1, a, sigma1);
 }
 
 // Any degree, O(deg^2) recomputation of the prefix, still in place (position k is
@@ -231,15 +258,11 @@ __device__ __forceinline__ void check_update(double *M, int deg, double sigma, d
 // belief_propagation.jl:153-177.  Returns the posterior odds T.
 // `Mt` = tile message base + lane; pos = CSR positions of the bit's edges.
 // ---------------------------------------------------------------------------
+// the arithmetic of a bit once its D incoming messages c[k] (rows at[k]) are loaded
 template <int D>
-__device__ __forceinline__ double bit_update_exact(double *Mt, const int *__restrict__ pos, double r)
+__device__ __forceinline__ double bit_finish_exact(double *Mt, const size_t (&at)[D], const double (&c)[D], double r)
 {
-    double c[D], pre[D];
-    size_t at[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) at[k] = (size_t)pos[k] * kTile;
-#pragma unroll
-    for (int k = 0; k < D; ++k) c[k] = ldm(Mt + at[k]);
+    double pre[D];
     double F = r;                                         // :153
 #pragma unroll
     for (int k = 0; k < D; ++k) {
@@ -255,6 +278,35 @@ __device__ __forceinline__ double bit_update_exact(double *Mt, const int *__rest
         if (G != G) G = 1.0;                              // :174-176
     }
     return F;
+}
+
+template <int D>
+__device__ __forceinline__ double bit_update_exact(double *Mt, const int *__restrict__ pos, double r)
+{
+    double c[D];
+    size_t at[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) at[k] = (size_t)pos[k] * kTile;
+#pragma unroll
+    for (int k = 0; k < D; ++k) c[k] = ldm(Mt + at[k]);
+    return bit_finish_exact<D>(Mt, at, c, r);
+}
+
+// Two bits of degree D at once (their 2 D positions are consecutive in pos): every row load is issued before
+// anything is computed.  Same arithmetic per bit; T0 / T1 are the posterior odds.
+template <int D>
+__device__ __forceinline__ void bit_update_pair(double *Mt, const int *__restrict__ pos, double r, double &T0, double &T1)
+{
+    double c0[D], c1[D];
+    size_t at0[D], at1[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) { at0[k] = (size_t)pos[k] * kTile; at1[k] = (size_t)pos[D + k] * kTile; }
+#pragma unroll
+    for (int k = 0; k < D; ++k) c0[k] = ldm(Mt + at0[k]);
+#pragma unroll
+    for (int k = 0; k < D; ++k) c1[k] = ldm(Mt + at1[k]);
+    T0 = bit_finish_exact<D>(Mt, at0, c0, r);
+    T1 = bit_finish_exact<D>(Mt, at1, c1, r);
 }
 
 __device__ __noinline__ double bit_update_any(double *Mt, const int *__restrict__ pos, int deg, double r)

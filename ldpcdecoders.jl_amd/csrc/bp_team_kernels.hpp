@@ -15,10 +15,24 @@
 //
 // because per-XCD L2s are not coherent with each other and a CU's L1 is never refreshed by another
 // CU's stores.  All G workgroups of a team must be resident at once: the host launches
-// ntiles x G <= 2 workgroups per CU with a cooperative launch (checked against the kernel's residency,
-// never two cooperative grids at once) and every poll is bounded --
-// a team that waits longer than ~10 s raises a fault word (host-mapped, reported by the next call on
-// the handle) and all its members leave, so a lost workgroup can never hang the GPU.
+// nteams x G <= 2 workgroups per CU (checked against the kernel's residency, never two team grids at
+// once) and every poll is bounded -- a team that waits longer than ~10 s raises a fault word
+// (host-mapped, reported by the next call on the handle) and all its members leave, so a lost
+// workgroup can never hang the GPU.
+//
+// Teams are PERSISTENT: team t starts on tile t and then takes tiles from a queue until the batch is
+// done, always in ITS OWN message slot (iteration 1 reads nothing, so a slot needs no clearing between
+// tiles).  With 8 teams -- one per XCD -- the messages in flight are 8 slots: for the n = 16384 code
+// 8 x 32 MiB = 256 MiB, which the 256 MiB Infinity Cache keeps (tools/mall_probe.hip: the in-place sweeps
+// run at 8.8 TB/s on a working set of <= 256 MiB against 5.1 ... 5.6 TB/s from HBM).  The tile kernel
+// cannot do that: one workgroup per tile means 768 tiles = 24 GiB in flight.
+//
+// Within a sweep a member has a share of the node chunks (every G-th chunk), and its waves take the chunks of
+// that share one after the other from a counter in LDS (a wave's first chunk is its by right): the 8 waves of
+// a member run at different speeds from sweep to sweep -- same work, different luck with the memory system --
+// and a team barrier waits for the slowest wave of all.  (Dealing the chunks of the whole team from one
+// counter in global memory was tried first: agent-scope atomics execute at the memory side, ~20 ns apiece on
+// one address, and 4096 tickets per sweep took longer than the sweep.)
 #pragma once
 #include "bp_kernels.hpp"
 
@@ -29,26 +43,32 @@
 namespace ldpc {
 
 struct TeamParams {
-    int G;                      // workgroups per tile
-    // per tile one control block of kTeamCtlWords words, zero at launch (see team_barrier)
+    int G;                      // workgroups per team
+    int nteams;                 // teams launched; team t works in message slot t (fresh tiles) and starts on tile t
+    int pairs;                  // 1 = two nodes of the full degree are loaded together (twice the bytes in flight per wave)
+    int dynamic;                // 0 = chunks dealt statically; 1 = the waves of a member take the chunks of its share from a
+                                // counter in LDS; 2 = teams inside one XCD deal ALL their chunks from a counter in that XCD's L2
+    // per team one control block of kTeamCtlWords words, zero at launch (see team_barrier); block number nteams
+    // holds the tile queue (word 0: tiles handed out beyond the first nteams)
     unsigned int *ctl;
     u64 *mism;                  // [ntiles][mism_stride] mismatch words of the convergence tests, zero at launch
     int mism_stride;            // >= max_iters, a multiple of 32 words
     unsigned int *fault;        // host-mapped: set when a team barrier timed out
     int always_release;         // experiments: 1 = release at every barrier even when the team shares one XCD
-    int scatter;                // tests: 1 = deal a team's members over ALL XCDs (exercises the release path and
-                                // the XCC check that selects it); gridDim.x == ntiles * G
-    // As the second pass of the straggler hand-off (p.count_dev != nullptr): the number of syndromes is
-    // only known on the device, so the geometry is worked out here -- G above is then the cap, and the
-    // pass runs only for p.count_skip < *count_dev <= count_max (fewer: node kernel, more: packed tiles).
+    int scatter;                // 1 = deal a team's members over ALL XCDs (few tiles; also exercises the release path
+                                // and the XCC check that selects it); gridDim.x == nteams * G
+    // As a pass over a packed level (p.count_dev != nullptr): the number of syndromes is only known on the
+    // device; the pass runs only for p.count_skip < *count_dev <= count_max (fewer: node kernel, more: the tile
+    // kernel on the packed tiles), and its teams work IN the packed tiles (slot = tile).
     unsigned int count_max;
     int inject_fault;           // tests: raise the fault word and leave at once, as if a team barrier had timed out
     unsigned int ticket;        // what a timed-out barrier writes into the fault word: the number of this call on its
                                 // handle (never 0), so that the report can name the first call that was hit
 };
 
-// Team barrier number k (1, 2, ...).  Control block of a tile: arrival counter at word 0, XCC mask at word
-// 32, then one 128-byte line per member holding the number of the last barrier it was released from.
+// Team barrier number k (1, 2, ...).  Control block of a team: arrival counter at word 0; XCC mask, hand-off word
+// and next-tile word at words 32, 33, 34; one 128-byte line per member holding the number of the last barrier it
+// was released from.
 // The last arriver (it knows from the value its add returned) writes k into every member's line; the
 // others poll THEIR OWN line.  (All members polling the one counter cost O(G^2) memory requests per
 // barrier -- every add drops the line from every poller's L2 -- and with 8 ... 16 teams that storm took
@@ -56,10 +76,15 @@ struct TeamParams {
 // one_xcd: every member of the team runs on the same XCD, so their stores meet in ONE L2 and the
 // release (a write-back of that L2) is not needed; the acquire (this CU's L1) always is.
 // Returns false when the team is broken (somebody timed out): the caller leaves the kernel.
-constexpr int kTeamCtlWords = 32 * (2 + 64);   // per tile: counter line, XCC line, up to 64 member lines
+constexpr int kTeamMaxMembers = 96;
+constexpr int kTeamCtlMember = 64;                                  // first member line
+constexpr int kTeamCtlTicketCheck = 64 + 32 * kTeamMaxMembers;      // ticket counter of the check sweeps (team-wide dealing)
+constexpr int kTeamCtlTicketVar = kTeamCtlTicketCheck + 32;         // ... of the variable sweeps
+constexpr int kTeamCtlWords = kTeamCtlTicketVar + 32;               // per team
+constexpr int kTeamCheckChunk = 2;                                  // checks per chunk of the check sweep
 
 __device__ __forceinline__ bool team_barrier(unsigned int *ctl, int G, int rank, unsigned int k, unsigned int *fault,
-                                             unsigned int ticket, int *sh_ok, bool one_xcd)
+                                             unsigned int ticket, int *sh_ok, bool one_xcd, unsigned int *sh_deal)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its own stores
     __syncthreads();
@@ -72,9 +97,9 @@ __device__ __forceinline__ bool team_barrier(unsigned int *ctl, int G, int rank,
         const unsigned int prev = __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prev + 1u == k * (unsigned)G) {
             for (int m = 0; m < G; ++m)
-                __hip_atomic_store(ctl + 64 + 32 * m, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ctl + kTeamCtlMember + 32 * m, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            unsigned int *mine = ctl + 64 + 32 * rank;
+            unsigned int *mine = ctl + kTeamCtlMember + 32 * rank;
             const u64 t0 = wall_clock64();
             unsigned int polls = 0;
             while (__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k) {
@@ -94,59 +119,100 @@ __device__ __forceinline__ bool team_barrier(unsigned int *ctl, int G, int rank,
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // holds the barrier until the invalidate is through
         *sh_ok = ok;
+        sh_deal[0] = 0u;   // no wave of this workgroup is inside a sweep here: the dealers start afresh
+        sh_deal[1] = 0u;
     }
     __syncthreads();
     return *sh_ok != 0;
 }
 
+// Team-wide dealing (TeamParams::dynamic == 2, teams inside ONE XCD only): one ticket of the team's counter, asked for
+// by lane 0; the value stays in that lane's register until it is needed, so that the request is in flight while the
+// wave works on its current chunk.  The atomic is issued WITHOUT the agent-scope bits: it executes in the XCD's L2,
+// which all members of such a team share (an agent-scope atomic executes at the memory side, ~20 ns apiece on one
+// address: 4096 tickets per sweep took longer than the sweep).
+__device__ __forceinline__ unsigned int team_ticket_request(unsigned int *counter, int lane)
+{
+    unsigned int t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return t;
+}
+__device__ __forceinline__ unsigned int team_ticket_value(unsigned int t) { return (unsigned int)__builtin_amdgcn_readfirstlane((int)t); }
+
+// The next chunk of this member's share for the calling wave (beyond the W the waves own by right).
+__device__ __forceinline__ int team_deal(unsigned int *counter, int lane)
+{
+    unsigned int t = 0;
+    if (lane == 0) t = atomicAdd(counter, 1u);   // LDS
+    return __builtin_amdgcn_readfirstlane((int)t);
+}
+
+// Register budget: teams run one or two workgroups per CU (team_geometry() on the host), so the narrow-degree
+// instantiation may have 128 VGPRs instead of the tile kernel's 80 (three workgroups per CU) -- under 80 it spilled.
+template <int DC, int DV, int THREADS>
+constexpr int team_min_waves_per_simd()
+{
+    return min_waves_per_simd<DC, DV, THREADS>() < 4 ? min_waves_per_simd<DC, DV, THREADS>() : 4;
+}
+
 template <int DC, int DV, bool WANT_LLR, int THREADS>
 __global__ void
-__launch_bounds__(THREADS, (min_waves_per_simd<DC, DV, THREADS>()))
+__launch_bounds__(THREADS, (team_min_waves_per_simd<DC, DV, THREADS>()))
 bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const int *__restrict__ edge_bit,
                const int *__restrict__ col_ptr, const int *__restrict__ csc2csr,
                const u64 *__restrict__ synmask, const u64 *__restrict__ nevermask)
 {
     __shared__ int sh_ok;
+    __shared__ unsigned int sh_deal[2];   // chunks of this member's share dealt so far beyond the waves' first: check sweep, variable sweep
     __shared__ u64 sh_mism[THREADS / 64];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int W = THREADS / 64;
     const int s = p.s, n = p.n;
     const double r = p.r;
+    if (threadIdx.x == 0) { sh_deal[0] = 0u; sh_deal[1] = 0u; }
+    __syncthreads();
     if (tp.inject_fault) {
         if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(tp.fault, tp.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
-    int G = tp.G, ntiles = p.ntiles;
+    const int G = tp.G, nteams = tp.nteams;
+    int ntiles = p.ntiles;
     long long batch = p.batch;
-    if (p.count_dev) {                                         // second pass: sized on the device
+    if (p.count_dev) {                                         // a pass over a packed level: sized on the device
         batch = (long long)*p.count_dev;
         if (batch <= (long long)p.count_skip || batch > (long long)tp.count_max) return;
         ntiles = (int)((batch + kTile - 1) / kTile);
-        G = min(G, (int)(gridDim.x >> 3) / ((ntiles + 7) / 8));
-        if (G < 1) return;                                     // (count_max keeps this from happening)
     }
     // Workgroups are dealt round-robin over the 8 XCDs (observed, not promised): blocks b and b + 8 share
     // one.  Teams are formed among the blocks of one residue class, so that normally a team sits on ONE
     // XCD; the members check it (xccs) and fall back to full release / acquire barriers if it is not so.
-    const int bq = (int)(blockIdx.x >> 3), xslot = (int)(blockIdx.x & 7u);   // gridDim.x == 8 * G * ceil(ntiles / 8)
-    const int tile = tp.scatter ? (int)(blockIdx.x / (unsigned)G) : (bq / G) * 8 + xslot;
+    const int bq = (int)(blockIdx.x >> 3), xslot = (int)(blockIdx.x & 7u);   // gridDim.x == 8 * G * ceil(nteams / 8)
+    const int team = tp.scatter ? (int)(blockIdx.x / (unsigned)G) : (bq / G) * 8 + xslot;
     const int rank = tp.scatter ? (int)(blockIdx.x % (unsigned)G) : bq % G;
-    if (tile >= ntiles || (p.count_dev && bq >= G * ((ntiles + 7) / 8))) return;   // whole teams only: nobody waits for these
+    if (team >= nteams || team >= ntiles) return;              // whole teams only: nobody waits for these
     const int gw = rank * W + w, GW = G * W;                   // this wave among the team's waves
-    double *const Mt = p.msg + (size_t)tile * (size_t)p.slot_stride + lane;
-    unsigned int *const ctr = tp.ctl + (size_t)tile * kTeamCtlWords;
+    unsigned int *const ctr = tp.ctl + (size_t)team * kTeamCtlWords;
     unsigned int *const xccs = ctr + 32;
-    u64 *const mw = tp.mism + (size_t)tile * (size_t)tp.mism_stride;
+    unsigned int *const tile_queue = tp.ctl + (size_t)nteams * kTeamCtlWords;
     unsigned int epoch = 0;                                    // barriers passed
+    unsigned int base_check = 0, base_var = 0;                 // team-wide dealing: tickets used up by earlier sweeps
     __shared__ int sh_one_xcd;
     if (threadIdx.x == 0) {
         unsigned int xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         __hip_atomic_fetch_or(xccs, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    bool one_xcd = false;                                      // known after the first (full) barrier
+    bool one_xcd = false, placed = false;                      // known after the first (full) barrier
+    const bool resumed = p.resumed != 0;
+    const BPCold *const cd = p.cold;
+    u64 tk_check = 0, tk_var = 0, tk_rest = 0;   // this wave's own sweep time / everything else (waiting included)
+    long long tot_iters = 0;                     // (rank 0, wave 0) iterations of the syndromes this team finished
 
+    for (int tile = team; tile < ntiles;) {
+    // fresh tiles are decoded in the team's own slot, packed tiles of a level where they lie
+    double *const Mt = p.msg + (size_t)(resumed ? tile : team) * (size_t)p.slot_stride + lane;
+    u64 *const mw = tp.mism + (size_t)tile * (size_t)tp.mism_stride;
     const u64 *syn = synmask + (size_t)tile * s;
     u64 *em = p.errmask + (size_t)tile * n;
     u64 *fin = p.finmask + (size_t)tile * n;
@@ -157,48 +223,112 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     const u64 never = nevermask[tile];
     u64 active = valid;                                        // identical in every member: same inputs, same words
     // a pass over a packed level: every lane has it0 iterations behind it and its messages in the packed tile
-    const bool resumed = p.resumed != 0;
-    const BPCold *const cd = p.cold;
     const int it0 = (resumed && ((valid >> lane) & 1ull)) ? cd->it0[b0 + lane] : 0;
     int my_iters = 0, my_conv = 0, it = 0;
-    u64 tk_check = 0, tk_var = 0, tk_rest = 0;   // this wave's own sweep time / everything else (waiting included)
 
     while (active != 0) {   // (every lane retires at the latest when its total reaches max_iters)
         ++it;
         const bool first = (it == 1) && !resumed;
         const u64 t0 = wall_clock64();
-        // ---- check-node sweep  (:135-150)
-        for (int i = gw; i < s; i += GW) {
-            const int e0 = row_ptr[i];
-            const int deg = row_ptr[i + 1] - e0;
-            const double sigma = ((syn[i] >> lane) & 1ull) ? -1.0 : 1.0;
-            if (first) check_update<DC, true>(Mt + (size_t)e0 * kTile, deg, sigma, r);
-            else check_update<DC, false>(Mt + (size_t)e0 * kTile, deg, sigma, r);
+        // ---- check-node sweep  (:135-150) in chunks of kTeamCheckChunk checks
+        {
+            const int nch = (s + kTeamCheckChunk - 1) / kTeamCheckChunk;
+            auto chunk = [&](int c) {
+                const int i1 = min(s, (c + 1) * kTeamCheckChunk);
+                if (kTeamCheckChunk == 2 && !first && tp.pairs && i1 == c * 2 + 2) {
+                    // the usual case, two checks of the full degree: all 2 DC rows in flight at once
+                    const int i = c * 2;
+                    const int e0 = row_ptr[i], e1 = row_ptr[i + 1], e2 = row_ptr[i + 2];
+                    if (e1 - e0 == DC && e2 - e1 == DC) {
+                        const double sg0 = ((syn[i] >> lane) & 1ull) ? -1.0 : 1.0, sg1 = ((syn[i + 1] >> lane) & 1ull) ? -1.0 : 1.0;
+                        check_update_pair<DC>(Mt + (size_t)e0 * kTile, Mt + (size_t)e1 * kTile, sg0, sg1);
+                        return;
+                    }
+                }
+                for (int i = c * kTeamCheckChunk; i < i1; ++i) {
+                    const int e0 = row_ptr[i];
+                    const int deg = row_ptr[i + 1] - e0;
+                    const double sigma = ((syn[i] >> lane) & 1ull) ? -1.0 : 1.0;
+                    if (first) check_update<DC, true>(Mt + (size_t)e0 * kTile, deg, sigma, r);
+                    else check_update<DC, false>(Mt + (size_t)e0 * kTile, deg, sigma, r);
+                }
+            };
+            if (tp.dynamic == 2 && one_xcd && nch > GW) {
+                // the whole team's chunks from one counter: chunk gw is this wave's by right, ticket t stands for chunk
+                // GW + (t - base); every wave draws one ticket more than it gets chunks, so a sweep uses up nch tickets
+                unsigned int tv = team_ticket_request(ctr + kTeamCtlTicketCheck, lane);
+                for (int c = gw; c < nch;) {
+                    chunk(c);
+                    c = GW + (int)(team_ticket_value(tv) - base_check);
+                    if (c < nch) tv = team_ticket_request(ctr + kTeamCtlTicketCheck, lane);
+                }
+                base_check += (unsigned int)nch;
+            } else {
+                // this member's share is chunks rank, rank + G, ...; its waves take them from the counter in LDS
+                const int mine = (nch - rank + G - 1) / G;
+                for (int l = w; l < mine;) {
+                    chunk(l * G + rank);
+                    l = tp.dynamic ? W + team_deal(&sh_deal[0], lane) : l + W;
+                }
+            }
         }
         const u64 t1 = wall_clock64();
-        if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd)) return;
-        if (first) {
+        if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd, sh_deal)) return;
+        if (!placed) {
             if (threadIdx.x == 0)
                 sh_one_xcd = __popc(__hip_atomic_load(xccs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 1;
             __syncthreads();
             one_xcd = sh_one_xcd != 0 && !tp.always_release;
+            placed = true;
         }
         const u64 t2 = wall_clock64();
-        // ---- variable-node sweep  (:152-178); a wave takes 16 consecutive bits at a time, so that a
-        //      128-byte line of decision words has one writer
-        for (int jb0 = gw * 16; jb0 < n; jb0 += GW * 16)
-        for (int j = jb0; j < min(jb0 + 16, n); ++j) {
-            const int c0 = col_ptr[j];
-            const int deg = col_ptr[j + 1] - c0;
-            const double T = bit_update<DV>(Mt, csc2csr + c0, deg, r);
-            const u64 dec = __ballot(T >= 1.0);                            // :164-168
-            if (WANT_LLR) {
-                if ((active >> lane) & 1ull) p.llr[((size_t)tile * n + j) * kTile + lane] = log(1.0 / T);  // :163
+        // ---- variable-node sweep  (:152-178).  Across XCDs a chunk is 16 consecutive bits, so that a 128-byte line of
+        //      decision words has one writer; inside one XCD (one L2) 4 bits, for an even finish
+        {
+            const int vb = one_xcd ? 4 : 16;
+            const int nch = (n + vb - 1) / vb;
+            auto decide = [&](int j, double T) {
+                const u64 dec = __ballot(T >= 1.0);                                // :164-168
+                if (WANT_LLR) {
+                    if ((active >> lane) & 1ull) p.llr[((size_t)tile * n + j) * kTile + lane] = log(1.0 / T);  // :163
+                }
+                if (lane == 0) em[j] = dec;   // every lane; the stopped ones' decisions were captured when they stopped
+            };
+            auto chunk = [&](int c) {
+                const int j1 = min(n, (c + 1) * vb);
+                int j = c * vb;
+                for (; tp.pairs && j + 1 < j1; j += 2) {           // two bits of the full degree: all 2 DV rows in flight at once
+                    const int c0 = col_ptr[j], c1 = col_ptr[j + 1], c2 = col_ptr[j + 2];
+                    if (c1 - c0 != DV || c2 - c1 != DV) break;
+                    double T0, T1;
+                    bit_update_pair<DV>(Mt, csc2csr + c0, r, T0, T1);
+                    decide(j, T0);
+                    decide(j + 1, T1);
+                }
+                for (; j < j1; ++j) {
+                    const int c0 = col_ptr[j];
+                    const int deg = col_ptr[j + 1] - c0;
+                    decide(j, bit_update<DV>(Mt, csc2csr + c0, deg, r));
+                }
+            };
+            if (tp.dynamic == 2 && one_xcd && nch > GW) {
+                unsigned int tv = team_ticket_request(ctr + kTeamCtlTicketVar, lane);
+                for (int c = gw; c < nch;) {
+                    chunk(c);
+                    c = GW + (int)(team_ticket_value(tv) - base_var);
+                    if (c < nch) tv = team_ticket_request(ctr + kTeamCtlTicketVar, lane);
+                }
+                base_var += (unsigned int)nch;
+            } else {
+                const int mine = (nch - rank + G - 1) / G;
+                for (int l = w; l < mine;) {
+                    chunk(l * G + rank);
+                    l = tp.dynamic ? W + team_deal(&sh_deal[1], lane) : l + W;
+                }
             }
-            if (lane == 0) em[j] = dec;   // every lane; the stopped ones' decisions were captured when they stopped
         }
         const u64 t3 = wall_clock64();
-        if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd)) return;
+        if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd, sh_deal)) return;
         // ---- convergence test (:180-184): lane = check, words = 64 syndromes; the team ORs into mw[it-1]
         u64 mism = 0;
         for (int i = gw * 64 + lane; i < s; i += GW * 64) {
@@ -225,7 +355,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
             for (int q = 0; q < W; ++q) part |= sh_mism[q];
             if (part) __hip_atomic_fetch_or(&mw[it - 1], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd)) return;
+        if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd, sh_deal)) return;
         const u64 U = uniform64(never | __hip_atomic_load(&mw[it - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         const int total = it0 + it;                            // iterations of this lane's syndrome so far
         const u64 newly = active & ~U;
@@ -244,14 +374,14 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
         const u64 t4 = wall_clock64();
         tk_check += t1 - t0; tk_var += t3 - t2; tk_rest += (t2 - t1) + (t4 - t3);   // rest = barriers + test
         // few stragglers left: hand them, with their messages, to the next level (decided alike by every member;
-        // rank 0 reserves the room and tells the others through the tile's control block, then all copy)
+        // rank 0 reserves the room and tells the others through the team's control block, then all copy)
         if (p.defer_thresh != 0 && active != 0 && it >= p.defer_min_iter && (int)__popcll(active) <= p.defer_thresh) {
             if (rank == 0 && threadIdx.x == 0)
                 __hip_atomic_store(ctr + 33, defer_reserve(cd->defer_count, (unsigned)__popcll(active), cd->next_cap) + 1u,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // base + 1; a full level (~0u) is told as 0
-            if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd)) return;
+            if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd, sh_deal)) return;
             const unsigned told = __hip_atomic_load(ctr + 33, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd)) return;   // everyone has read it: the word may be rewritten
+            if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd, sh_deal)) return;   // everyone has read it: the word may be rewritten
             if (told != 0u) {                                  // (0 = ~0u + 1: the next level is full, carry on)
                 const unsigned base = told - 1u;
                 const bool mine = (active >> lane) & 1ull;
@@ -271,14 +401,33 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
             const long long ob = resumed ? (long long)cd->index[b0 + lane] : b0 + lane;
             cd->conv[ob] = (unsigned char)my_conv;
             if (cd->iters) cd->iters[ob] = my_iters;
-        } else {
-            my_iters = 0;
+            tot_iters += my_iters;
         }
-        int tot = my_iters;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
+    }
+    // ---- the team's next tile.  The two barriers also keep a member from starting on the next tile (whose first
+    //      check sweep overwrites the slot) while another still copies stragglers' rows out of it.
+    if (ntiles <= nteams) break;                               // one tile per team: nothing to ask for
+    if (rank == 0 && threadIdx.x == 0)
+        __hip_atomic_store(ctr + 34, (unsigned)nteams + __hip_atomic_fetch_add(tile_queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd, sh_deal)) return;
+    tile = (int)min(__hip_atomic_load(ctr + 34, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), (unsigned)ntiles);
+    tile = __builtin_amdgcn_readfirstlane(tile);
+    if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd, sh_deal)) return;   // everyone has read it
+    }
+
+    if (w == 0 && lane == 0) {   // diagnostics (LDPC_TEAM_DEBUG on the host): this member's own sweep times, where it ran
+        unsigned int hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned int *mine = ctr + kTeamCtlMember + 32 * rank;
+        mine[1] = (unsigned int)tk_check; mine[2] = (unsigned int)tk_var; mine[3] = hw;
+    }
+    if (rank == 0 && w == 0) {
+        int lo = (int)(tot_iters & 0xffffffffll), hi = (int)(tot_iters >> 32);   // (wave sum of a 64-bit count)
+        u64 tot = 0;
+        for (int l = 0; l < 64; ++l) tot += ((u64)(unsigned)__shfl(hi, l, 64) << 32) + (u64)(unsigned)__shfl(lo, l, 64);
         if (lane == 0) {
-            atomicAdd(cd->sum_iters, (u64)tot);
+            atomicAdd(cd->sum_iters, tot);
             atomicAdd(&cd->phase_ticks[0], tk_check);
             atomicAdd(&cd->phase_ticks[1], tk_var);
             atomicAdd(&cd->phase_ticks[2], tk_rest);

@@ -687,7 +687,7 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     d->variant = options ? options->kernel_variant : 0;
     if (d->variant < 0 || d->variant > 4) { delete d; return fail(LDPC_ERR_INVALID_ARGUMENT, "kernel_variant must be 0 ... 4"); }
     d->inject_fault = std::getenv("LDPC_TEAM_INJECT_FAULT") != nullptr;   // (tests)
-    if (const char *e = std::getenv("LDPC_TEAM_MAX")) { d->team_max = std::max(1, std::min(64, std::atoi(e))); d->team_max_set = true; }
+    if (const char *e = std::getenv("LDPC_TEAM_MAX")) { d->team_max = std::max(1, std::min(kTeamMaxMembers, std::atoi(e))); d->team_max_set = true; }
     {
         void *fp = nullptr, *fd = nullptr;
         if (hipHostMalloc(&fp, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
@@ -815,10 +815,19 @@ std::mutex g_team_mu;
 hipEvent_t g_team_ev[64] = {};   // per device: completion of the most recent team grid (process lifetime)
 }  // namespace
 
+// Dynamic LDS a team workgroup asks for although it uses none (LDPC_TEAM_LDS_KIB): a way to bound how many
+// members the dispatcher can put on one CU (81+ KiB: one, 54+ KiB: two), so that a grid of exactly that many
+// members per CU lands evenly.
+static size_t team_lds_bytes()
+{
+    static const size_t v = [] { const char *e = std::getenv("LDPC_TEAM_LDS_KIB"); return e ? (size_t)std::max(0, std::min(160, std::atoi(e))) * 1024 : (size_t)0; }();
+    return v;
+}
+
 static hipError_t launch_team_grid(ldpc_bp_decoder *d, team_kernel_t tk, int grid, void **args, hipStream_t stream)
 {
     static const bool coop = std::getenv("LDPC_TEAM_COOP_LAUNCH") != nullptr;
-    if (coop) return hipLaunchCooperativeKernel((const void *)tk, dim3((unsigned)grid), dim3(512), args, 0, stream);
+    if (coop) return hipLaunchCooperativeKernel((const void *)tk, dim3((unsigned)grid), dim3(512), args, (unsigned)team_lds_bytes(), stream);
     std::lock_guard<std::mutex> lk(g_team_mu);
     hipEvent_t *gev = (d->device >= 0 && d->device < 64) ? &g_team_ev[d->device] : nullptr;
     if (gev) {
@@ -829,7 +838,7 @@ static hipError_t launch_team_grid(ldpc_bp_decoder *d, team_kernel_t tk, int gri
             if (w != hipSuccess) return w;
         }
     }
-    hipError_t e = hipLaunchKernel((const void *)tk, dim3((unsigned)grid), dim3(512), args, 0, stream);
+    hipError_t e = hipLaunchKernel((const void *)tk, dim3((unsigned)grid), dim3(512), args, team_lds_bytes(), stream);
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess && gev && *gev) e = hipEventRecord(*gev, stream);
     return e;
@@ -858,8 +867,9 @@ static bool team_geometry(ldpc_bp_decoder *d, bool want_llr, int *per_xcd, int *
     // what this instantiation's registers admit (the wide-degree buckets: one 8-wave workgroup per CU), less one
     // as the margin where that leaves at least one
     int occ = 0;
-    if (d->prepare_kernel((const void *)pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr), 512, 0, &occ) != LDPC_OK) return false;
-    const int per_cu = std::min(per_cu_want, occ >= 2 ? occ - (occ > per_cu_want ? 0 : 1) : occ);
+    if (d->prepare_kernel((const void *)pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr), 512, team_lds_bytes(), &occ) != LDPC_OK) return false;
+    static const bool no_margin = std::getenv("LDPC_TEAM_NO_MARGIN") != nullptr;   // (experiments: fill the CUs exactly)
+    const int per_cu = no_margin ? std::min(per_cu_want, occ) : std::min(per_cu_want, occ >= 2 ? occ - (occ > per_cu_want ? 0 : 1) : occ);
     if (per_cu < 1) return false;
     static const int64_t min_rows = [] { const char *e = std::getenv("LDPC_TEAM_MIN_ROWS"); return e ? std::max<int64_t>(1, std::atoll(e)) : (int64_t)2048; }();
     *per_xcd = per_cu * (d->num_cus / 8);
@@ -867,23 +877,66 @@ static bool team_geometry(ldpc_bp_decoder *d, bool want_llr, int *per_xcd, int *
     return *per_xcd >= 1;
 }
 
-static int team_size(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
+// How a batch of fresh tiles is dealt to teams (bp_team_kernels.hpp).  G = 1: no teams for it.
+//   * up to 4 tiles: one team per tile, its members dealt over ALL XCDs (scatter), up to 64 of them;
+//   * otherwise teams inside one XCD, 8 x tpx of them, PERSISTENT: a team takes tile after tile in its own
+//     message slot.  tpx (teams per XCD) is as many as the tiles need but no more than keeps the slots in
+//     flight -- 8 x tpx x 512 nnz bytes -- inside the Infinity Cache (LDPC_TEAM_CACHE_MIB, default 256;
+//     0 = round 1's rule: one team per tile, at most one tile per CU, nothing persistent).  Batches of more
+//     tiles than CUs only go to teams when the slots do fit: the n = 16384 code does with tpx = 1
+//     (8 x 32 MiB), larger graphs stay with the tile kernel.
+struct TeamPlan {
+    int G = 1;            // members per team
+    int nteams = 0;       // teams (and message slots)
+    int grid = 0;         // workgroups to launch
+    bool scatter = false;
+};
+
+static size_t team_cache_bytes()
 {
+    static const size_t v = [] { const char *e = std::getenv("LDPC_TEAM_CACHE_MIB"); return (size_t)(e ? std::max(0, std::atoi(e)) : 256) << 20; }();
+    return v;
+}
+
+static TeamPlan team_plan(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
+{
+    TeamPlan pl;
     int per_xcd = 0, gcap = 0;
-    if (!team_geometry(d, want_llr, &per_xcd, &gcap)) return 1;
+    if (!team_geometry(d, want_llr, &per_xcd, &gcap)) return pl;
     const int64_t ntiles = (batch + kTile - 1) / kTile;
-    if (ntiles < 1 || ntiles > d->num_cus) return 1;
-    const int64_t teams_per_xcd = (ntiles + 7) / 8;
-    int64_t team = std::min<int64_t>(gcap, (int64_t)per_xcd / teams_per_xcd);
+    if (ntiles < 1) return pl;
+    if ((size_t)ntiles * ((size_t)d->max_iters + 32) * sizeof(u64) > ((size_t)64 << 20)) return pl;   // mismatch words per tile and iteration
+    int64_t team = 1, nteams = 0;
     if (ntiles <= 4 && !d->team_max_set) {
         // dealt over all 8 XCDs (scatter mode of the kernel): larger teams pay -- one tile of the C3 code, 50
         // iterations: 32 members 5.4 ms, 48: 4.3 ms, 64: 3.4 ms (a member still has >= 1024 message rows per sweep)
         const int64_t cap = std::min<int64_t>(64, std::max<int64_t>(gcap, d->nnz / 1024));
         team = std::min<int64_t>(cap, (int64_t)8 * per_xcd / ntiles);
+        nteams = ntiles;
+        pl.scatter = true;
+    } else {
+        const int64_t need = (ntiles + 7) / 8;
+        const size_t state = std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double);
+        const size_t cache = team_cache_bytes();
+        int64_t tpx = need;
+        if (cache == 0) {
+            if (ntiles > d->num_cus) return pl;
+        } else {
+            const int64_t fit = (int64_t)(cache / (8 * state));
+            if (ntiles > d->num_cus && fit < 1) return pl;       // slots beyond the cache: the tile kernel streams from HBM as well as teams would
+            tpx = std::min<int64_t>(need, std::max<int64_t>(1, fit));
+        }
+        team = std::min<int64_t>(gcap, (int64_t)per_xcd / tpx);
+        nteams = 8 * tpx;
     }
-    if ((size_t)ntiles * ((size_t)d->max_iters + 32) * sizeof(u64) > ((size_t)16 << 20)) team = 1;
-    return team < 3 ? 1 : (int)team;   // two workgroups per tile measured no better than the tile kernel's one of 16 waves
+    if (team < 3) return pl;   // two workgroups per tile measured no better than the tile kernel's one of 16 waves
+    pl.G = (int)std::min<int64_t>(team, kTeamMaxMembers);
+    pl.nteams = (int)nteams;
+    pl.grid = pl.scatter ? pl.nteams * pl.G : 8 * pl.G * (pl.nteams / 8);
+    return pl;
 }
+
+static int team_size(ldpc_bp_decoder *d, int64_t batch, bool want_llr) { return team_plan(d, batch, want_llr).G; }
 
 // Small batches on graphs beyond the LDS: one workgroup per syndrome (bp_node_kernels.hpp) or teams of
 // workgroups per 64-syndrome tile?  Estimated time of one iteration, from the measurements in DESIGN.md:
@@ -1131,20 +1184,23 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         threads = wpt * 64;
         grid = std::min(slots, ntiles);
     }
-    // Medium batches: fewer tiles than CUs -- G workgroups share a tile (bp_team_kernels.hpp, team_size()).
-    const int team = team_size(d, batch, want_llr);
-    // (kernel_variant 4 skips the LDS and node kernels; batches the team kernel cannot take -- more tiles than CUs,
-    // an empty graph -- go to the tile kernel)
-    if (team > 1) { threads = 512; grid = ntiles; }
+    // Teams of workgroups on the tiles (bp_team_kernels.hpp, team_plan()): medium batches, where one workgroup per
+    // tile leaves CUs idle, and large ones of graphs whose team slots fit the Infinity Cache.
+    // (kernel_variant 4 skips the LDS and node kernels; batches the team kernel cannot take -- an empty graph,
+    // slots beyond the cache -- go to the tile kernel)
+    const TeamPlan plan = team_plan(d, batch, want_llr);
+    const int team = plan.G;
+    const int tile_grid = grid, tile_threads = threads;
+    if (team > 1) { threads = 512; grid = plan.nteams; }
     d->last_threads = threads;
     // fewer than 8 tiles: a team inside one XCD would be bound by that XCD's share of the bandwidth (1.1 TB/s);
-    // dealt over all XCDs (scatter mode: tile = block / G) its sweeps run 1.4x faster and the barriers (now with
+    // dealt over all XCDs (scatter mode: team = block / G) its sweeps run 1.4x faster and the barriers (now with
     // the L2 write-back) twice as long -- 6.1 -> 5.4 ms for 64 syndromes of the C3 code, all 50 iterations.
     // (The environment switch is read per call: a test turns it on and off.)
-    const bool team_scatter = team > 1 && (std::getenv("LDPC_TEAM_SCATTER") || ntiles <= 4);
+    const bool team_scatter = team > 1 && (std::getenv("LDPC_TEAM_SCATTER") || plan.scatter);
     // scatter mode launches exactly the members (8 * team blocks for <= 4 tiles would be up to 512 workgroups,
     // more than the wide-degree instantiations can keep resident: one 8-wave workgroup per CU)
-    const int team_grid = team > 1 ? (team_scatter ? ntiles * team : 8 * team * ((ntiles + 7) / 8)) : 0;
+    const int team_grid = team > 1 ? (team_scatter ? plan.nteams * team : plan.grid) : 0;
     d->last_grid = team > 1 ? team_grid : grid;
     d->last_kernel = team > 1 ? 4 : 1;
     d->last_team = team;
@@ -1169,13 +1225,13 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         unsigned int *tile_queue = nullptr, *node_queue = nullptr;
         unsigned node_take = 0;   // up to this many syndromes: the node-parallel kernel finishes them
         unsigned team_cap = 0;    // above node_take up to this many: teams of workgroups on the packed tiles
-        int t_per_xcd = 0, t_gcap = 0;
+        int t_per_xcd = 0, t_gcap = 0, t_G = 0, t_nteams = 0;   // teams on the packed tiles: members, teams
     } lv[3];
     int nlevels = 0;
     if (T0 > 0) {
         lv[1].thresh_in = T0;
         const int worst1 = (int)(((int64_t)ntiles * T0 + kTile - 1) / kTile) + 1;
-        lv[1].cap_tiles = d->lvl_cap_force > 0 ? d->lvl_cap_force : std::min(worst1, std::max(8, grid / 3));
+        lv[1].cap_tiles = d->lvl_cap_force > 0 ? d->lvl_cap_force : std::min(worst1, std::max(8, std::max(grid, tile_grid) / 3));
         nlevels = 1;
         const int T1 = d->defer_t1;
         if (T1 > 0 && (lv[1].cap_tiles >= 8 || d->lvl_cap_force > 0)) {
@@ -1208,7 +1264,22 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         L.node_take = (d->node_ok && d->variant == 0 && d->node_take_max > 0)
                           ? (unsigned)std::min<int64_t>(d->node_take_max, (int64_t)L.cap_tiles * kTile) : 0u;
         if (L.node_take && d->max_iters <= 4096 && team_geometry(d, want_llr, &L.t_per_xcd, &L.t_gcap) && L.t_gcap >= 3) {
-            const int tiles_max = std::min(8 * (L.t_per_xcd / 3), L.cap_tiles);   // >= 3 members per tile
+            // persistent teams inside the packed tiles: as many per XCD as keep the tiles in flight inside the
+            // Infinity Cache (team_plan()); they take whatever the level holds.  Without a cache budget
+            // (LDPC_TEAM_CACHE_MIB=0): one tile per team, up to as many tiles as leave every team 3 members.
+            const size_t state = std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double);
+            const size_t cache = team_cache_bytes();
+            int tiles_max;
+            if (cache) {
+                const int tpx = (int)std::max<size_t>(1, std::min<size_t>(cache / (8 * state), (size_t)L.t_per_xcd / 3));
+                L.t_G = std::min(L.t_gcap, L.t_per_xcd / tpx);
+                L.t_nteams = 8 * tpx;
+                tiles_max = L.cap_tiles;
+            } else {
+                L.t_nteams = 8 * (L.t_per_xcd / 3);
+                L.t_G = 3;                                   // (the members of surplus teams are idle: round 1's geometry in fixed form)
+                tiles_max = std::min(L.t_nteams, L.cap_tiles);
+            }
             if ((unsigned)tiles_max * kTile > L.node_take) L.team_cap = (unsigned)tiles_max * kTile;
         }
     }
@@ -1274,8 +1345,10 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     HIP_TRY(hipGetLastError());
     bp_kernel_t kfn = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, threads);
     static const int always_release = std::getenv("LDPC_TEAM_ALWAYS_RELEASE") ? 1 : 0;
-    auto team_params = [&](DevBuf &wsbuf, int tiles, TeamParams &tp) -> ldpc_status {
-        const size_t ctl_bytes = (size_t)tiles * kTeamCtlWords * sizeof(unsigned int);
+    static const int team_pairs = [] { const char *e = std::getenv("LDPC_TEAM_PAIRS"); return e ? std::atoi(e) : 1; }();
+    static const int team_dynamic = [] { const char *e = std::getenv("LDPC_TEAM_DYNAMIC"); return e ? std::atoi(e) : 1; }();
+    auto team_params = [&](DevBuf &wsbuf, int nteams, int tiles, TeamParams &tp) -> ldpc_status {
+        const size_t ctl_bytes = ((size_t)nteams + 1) * kTeamCtlWords * sizeof(unsigned int);   // + the block of the tile queue
         const size_t mism_stride = ((size_t)d->max_iters + 31) & ~(size_t)31;
         const size_t ws_bytes = ctl_bytes + (size_t)tiles * mism_stride * sizeof(u64);
         ldpc_status r = wsbuf.ensure(ws_bytes);
@@ -1286,6 +1359,9 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         tp.mism_stride = (int)mism_stride;
         tp.fault = d->team_fault_dev;
         tp.always_release = always_release;
+        tp.nteams = nteams;
+        tp.dynamic = team_dynamic;
+        tp.pairs = team_pairs;
         tp.scatter = 0;
         tp.count_max = 0;
         tp.inject_fault = 0;
@@ -1296,7 +1372,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     HIP_TRY(hipEventRecord(ev[1], stream));
     if (team > 1) {
         TeamParams tp{};
-        if ((st = team_params(d->team_ws, ntiles, tp)) != LDPC_OK) return st;
+        if ((st = team_params(d->team_ws, plan.nteams, ntiles, tp)) != LDPC_OK) return st;
         tp.G = team;
         tp.scatter = team_scatter ? 1 : 0;
         tp.inject_fault = d->inject_fault ? 1 : 0;   // (tests)
@@ -1309,18 +1385,31 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             // workgroup per tile, same results), and teams stay off for this decoder
             (void)hipGetLastError();
             d->team_max = 1;
-            d->last_kernel = 1; d->last_team = 1; d->last_grid = grid;
+            threads = tile_threads; grid = tile_grid;
+            d->last_kernel = 1; d->last_team = 1; d->last_grid = grid; d->last_threads = threads;
+            if ((st = ensure_workspace(d, (size_t)grid * slot_stride_bytes, grid, slot_stride_bytes, stream)) != LDPC_OK) return st;
+            p.msg = (double *)d->msg.p;
+            kfn = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, threads);
             team_ran = false;
         }
         if (team_ran && std::getenv("LDPC_TEAM_DEBUG")) {   // diagnostics: which XCDs did the teams land on?
-            std::vector<unsigned> xm((size_t)ntiles);
+            const int nt = std::min(plan.nteams, ntiles);
+            std::vector<unsigned> xm((size_t)nt);
             (void)hipStreamSynchronize(stream);
-            for (int t = 0; t < ntiles; ++t)
+            for (int t = 0; t < nt; ++t)
                 (void)hipMemcpy(&xm[(size_t)t], tp.ctl + (size_t)t * kTeamCtlWords + 32, sizeof(unsigned), hipMemcpyDeviceToHost);
             int single = 0;
             for (unsigned v : xm) single += __builtin_popcount(v) == 1;
-            std::fprintf(stderr, "[ldpc] team kernel: %d tiles x %d workgroups, grid %d; %d teams on one XCD (first masks %x %x %x)\n",
-                         ntiles, team, team_grid, single, xm[0], ntiles > 1 ? xm[1] : 0u, ntiles > 2 ? xm[2] : 0u);
+            std::fprintf(stderr, "[ldpc] team kernel: %d tiles, %d teams x %d workgroups, grid %d; %d teams on one XCD (first masks %x %x %x)\n",
+                         ntiles, plan.nteams, team, team_grid, single, xm[0], nt > 1 ? xm[1] : 0u, nt > 2 ? xm[2] : 0u);
+            // per member: its own check / variable sweep time (100 MHz ticks, whole call) and HW_ID (CU in bits 8-11, SH 12, SE 13-15)
+            for (int t = 0; t < std::min(nt, 2); ++t) {
+                std::vector<unsigned> ml((size_t)team * 32);
+                (void)hipMemcpy(ml.data(), tp.ctl + (size_t)t * kTeamCtlWords + kTeamCtlMember, ml.size() * sizeof(unsigned), hipMemcpyDeviceToHost);
+                for (int m = 0; m < team; ++m)
+                    std::fprintf(stderr, "[ldpc]   team %d member %2d: check %8u var %8u  cu %2u sh %u se %u\n", t, m, ml[(size_t)m * 32 + 1], ml[(size_t)m * 32 + 2],
+                                 (ml[(size_t)m * 32 + 3] >> 8) & 15u, (ml[(size_t)m * 32 + 3] >> 12) & 1u, (ml[(size_t)m * 32 + 3] >> 13) & 7u);
+            }
         }
     }
     if (!team_ran) {
@@ -1361,12 +1450,12 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             BPParams q3 = q;
             q3.count_skip = L.node_take;
             TeamParams tp{};
-            if ((st = team_params(d->team_ws_lvl[l - 1], (int)(L.team_cap / kTile), tp)) != LDPC_OK) return st;
-            tp.G = L.t_gcap;
+            if ((st = team_params(d->team_ws_lvl[l - 1], L.t_nteams, (int)(L.team_cap / kTile), tp)) != LDPC_OK) return st;
+            tp.G = L.t_G;
             tp.count_max = L.team_cap;
             team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr);
             void *args[] = {&q3, &tp, &a_row, &a_eb, &a_col, &a_c2r, &l_syn, &l_nev};
-            HIP_TRY(launch_team_grid(d, tk, 8 * L.t_per_xcd, args, stream));
+            HIP_TRY(launch_team_grid(d, tk, L.t_G * L.t_nteams, args, stream));
         }
     }
     HIP_TRY(hipEventRecord(ev[2], stream));

@@ -273,7 +273,9 @@ def test_two_handles_from_two_threads(ldpc, gpu):
 
 
 def test_two_c3_size_handles_from_two_threads(ldpc, gpu):
-    """Two decoders of the C3 code (n = 16384), each with a full-size batch of its own -- 65,536 syndromes, so each
+    """Two decoders of the C3 code (n = 16384) on the tile kernel (kernel_variant 1: one workgroup per tile, 768 tiles
+    in flight; the default path for this code -- persistent teams -- needs 8 message slots only), each with a
+    full-size batch of its own -- 65,536 syndromes, so each
     allocates the 24.75 GiB message workspace, the packed hand-off levels, and may run its placement search (up to
     five 1 GiB-chunk groups held at once, never beyond half of the free HBM) -- created and driven concurrently from
     two host threads on two streams.  Neither may starve the other of memory, and both must produce what a lone
@@ -303,7 +305,7 @@ def test_two_c3_size_handles_from_two_threads(ldpc, gpu):
     free_start = torch.cuda.mem_get_info()[0]
     lone = []
     for syn in syns:                                   # the reference: one decoder at a time
-        dec = ldpc.BeliefPropagationDecoder(H, 0.02, 50)
+        dec = ldpc.BeliefPropagationDecoder(H, 0.02, 50, kernel_variant=1)
         e = torch.empty((B, n), dtype=torch.uint8, device=dev)
         c = torch.empty(B, dtype=torch.uint8, device=dev)
         i = torch.empty(B, dtype=torch.int32, device=dev)
@@ -319,7 +321,7 @@ def test_two_c3_size_handles_from_two_threads(ldpc, gpu):
         try:
             torch.cuda.set_device(0)
             st = torch.cuda.Stream()
-            dec = ldpc.BeliefPropagationDecoder(H, 0.02, 50)
+            dec = ldpc.BeliefPropagationDecoder(H, 0.02, 50, kernel_variant=1)
             e = torch.empty((B, n), dtype=torch.uint8, device=dev)
             c = torch.empty(B, dtype=torch.uint8, device=dev)
             i = torch.empty(B, dtype=torch.int32, device=dev)
