@@ -47,10 +47,10 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def pmc_traffic(workload):
-    """HBM bytes per launch of the sweep kernel from the committed rocprofv3 PMC passes
-    (profiles/*_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction applied).  bench.py
-    cannot collect counters itself; the number is only reported for the workload it was taken on."""
+def pmc_traffic(workload, kernel="bp_tile_kernel"):
+    """Bytes per launch of the sweep kernel between the L2s and the memory fabric, from the committed rocprofv3 PMC
+    passes (profiles/*_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction applied).  bench.py
+    cannot collect counters itself; the number is only reported for the workload AND kernel it was taken on."""
     import glob
 
     best = None
@@ -59,7 +59,7 @@ def pmc_traffic(workload):
             t = json.load(open(f))
         except Exception:
             continue
-        if t.get("workload") == workload:
+        if t.get("workload") == workload and t.get("kernel", "bp_tile_kernel") == kernel:
             best = t
     return (best["traffic_bytes_per_launch"], os.path.basename(best["source"].split(" ")[0])) if best else (None, None)
 
@@ -273,6 +273,7 @@ def main():
     # HIP-event times of the sweep kernel of the timed steps (the library keeps the events of
     # its last 16 calls, recorded on the launch stream), read after the timed region
     last_kernel = int(dec.info().last_kernel)
+    kname = {1: "bp_tile_kernel", 2: "bp_lds_kernel", 3: "bp_node_kernel", 4: "bp_team_kernel"}.get(last_kernel, "?")
     cps = max(1, device_calls[0] // max(args.steps, 1)) if device_calls[0] else 1   # calls per step
     k = max(1, min(args.steps, 16 // cps))
     per_call = [dec.last_timing(i) for i in range(k * cps)]
@@ -345,7 +346,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": {1: "bp_tile_kernel", 2: "bp_lds_kernel", 3: "bp_node_kernel", 4: "bp_team_kernel"}.get(last_kernel, "?"),
+                "kernel": kname,
                 # the LDS-resident kernels keep the messages on chip: their "achieved" is the algorithmic message
                 # traffic they would have cost in HBM, not bytes the HBM moved (it can exceed the peak)
                 "messages_on_chip": bool(last_kernel == 2 or (last_kernel == 3 and nnz * 8 <= 150 * 1024)),
@@ -355,8 +356,12 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 # NOT measured in this run: bench.py cannot collect PMC counters; this is the committed rocprofv3
                 # figure (profiles/*_traffic.json) of the same workload, named in traffic_source
-                "traffic": pmc_traffic(args.workload)[0] if (not args.batch and not args.per) else None,
-                "traffic_source": pmc_traffic(args.workload)[1],
+                "traffic": pmc_traffic(args.workload, kname)[0] if (not args.batch and not args.per) else None,
+                "traffic_source": pmc_traffic(args.workload, kname)[1],
+                # the team kernel keeps 8 message slots in flight (one persistent team per XCD): when they fit the
+                # 256 MiB Infinity Cache the sweeps are served by it, HBM only sees the syndromes and the results --
+                # the HBM peak stays the yardstick (it is what BASELINE.json's metric names), but it is not the bound
+                "message_slots_in_flight_bytes": int(dec.info().resident_tiles // max(dec.info().last_team_size, 1)) * nnz * 512 if last_kernel == 4 else None,
                 "alg_bytes_per_launch": alg_bytes,
                 "kernel_ms": sweep_ms,
                 "pack_sweep_unpack_ms": total_ms,

@@ -30,9 +30,9 @@
 // Within a sweep a member has a share of the node chunks (every G-th chunk), and its waves take the chunks of
 // that share one after the other from a counter in LDS (a wave's first chunk is its by right): the 8 waves of
 // a member run at different speeds from sweep to sweep -- same work, different luck with the memory system --
-// and a team barrier waits for the slowest wave of all.  (Dealing the chunks of the whole team from one
-// counter in global memory was tried first: agent-scope atomics execute at the memory side, ~20 ns apiece on
-// one address, and 4096 tickets per sweep took longer than the sweep.)
+// and a team barrier waits for the slowest wave of all.  (Dealing the chunks of the WHOLE team from one counter
+// in global memory -- agent-scope atomics, or atomics without the scope bits that execute in the XCD's L2 --
+// evens the finish out further but makes the sweeps themselves longer by more: profiles/r02_team_dealing_ab.txt.)
 #pragma once
 #include "bp_kernels.hpp"
 
@@ -46,8 +46,7 @@ struct TeamParams {
     int G;                      // workgroups per team
     int nteams;                 // teams launched; team t works in message slot t (fresh tiles) and starts on tile t
     int pairs;                  // 1 = two nodes of the full degree are loaded together (twice the bytes in flight per wave)
-    int dynamic;                // 0 = chunks dealt statically; 1 = the waves of a member take the chunks of its share from a
-                                // counter in LDS; 2 = teams inside one XCD deal ALL their chunks from a counter in that XCD's L2
+    int dynamic;                // 1 = the waves of a member take the chunks of its share from a counter in LDS; 0 = every W-th
     // per team one control block of kTeamCtlWords words, zero at launch (see team_barrier); block number nteams
     // holds the tile queue (word 0: tiles handed out beyond the first nteams)
     unsigned int *ctl;
@@ -78,9 +77,7 @@ struct TeamParams {
 // Returns false when the team is broken (somebody timed out): the caller leaves the kernel.
 constexpr int kTeamMaxMembers = 96;
 constexpr int kTeamCtlMember = 64;                                  // first member line
-constexpr int kTeamCtlTicketCheck = 64 + 32 * kTeamMaxMembers;      // ticket counter of the check sweeps (team-wide dealing)
-constexpr int kTeamCtlTicketVar = kTeamCtlTicketCheck + 32;         // ... of the variable sweeps
-constexpr int kTeamCtlWords = kTeamCtlTicketVar + 32;               // per team
+constexpr int kTeamCtlWords = 64 + 32 * kTeamMaxMembers;            // per team
 constexpr int kTeamCheckChunk = 2;                                  // checks per chunk of the check sweep
 
 __device__ __forceinline__ bool team_barrier(unsigned int *ctl, int G, int rank, unsigned int k, unsigned int *fault,
@@ -126,19 +123,6 @@ __device__ __forceinline__ bool team_barrier(unsigned int *ctl, int G, int rank,
     return *sh_ok != 0;
 }
 
-// Team-wide dealing (TeamParams::dynamic == 2, teams inside ONE XCD only): one ticket of the team's counter, asked for
-// by lane 0; the value stays in that lane's register until it is needed, so that the request is in flight while the
-// wave works on its current chunk.  The atomic is issued WITHOUT the agent-scope bits: it executes in the XCD's L2,
-// which all members of such a team share (an agent-scope atomic executes at the memory side, ~20 ns apiece on one
-// address: 4096 tickets per sweep took longer than the sweep).
-__device__ __forceinline__ unsigned int team_ticket_request(unsigned int *counter, int lane)
-{
-    unsigned int t = 0;
-    if (lane == 0) t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    return t;
-}
-__device__ __forceinline__ unsigned int team_ticket_value(unsigned int t) { return (unsigned int)__builtin_amdgcn_readfirstlane((int)t); }
-
 // The next chunk of this member's share for the calling wave (beyond the W the waves own by right).
 __device__ __forceinline__ int team_deal(unsigned int *counter, int lane)
 {
@@ -155,7 +139,9 @@ constexpr int team_min_waves_per_simd()
     return min_waves_per_simd<DC, DV, THREADS>() < 4 ? min_waves_per_simd<DC, DV, THREADS>() : 4;
 }
 
-template <int DC, int DV, bool WANT_LLR, int THREADS>
+// RESUMED: the pass over a packed level (the messages are in the packed tiles, every lane has iterations behind it)
+// is an instantiation of its own -- it shows under its own name in a profile, and the fresh pass loses the tests.
+template <int DC, int DV, bool WANT_LLR, int THREADS, bool RESUMED>
 __global__ void
 __launch_bounds__(THREADS, (team_min_waves_per_simd<DC, DV, THREADS>()))
 bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const int *__restrict__ edge_bit,
@@ -196,7 +182,6 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     unsigned int *const xccs = ctr + 32;
     unsigned int *const tile_queue = tp.ctl + (size_t)nteams * kTeamCtlWords;
     unsigned int epoch = 0;                                    // barriers passed
-    unsigned int base_check = 0, base_var = 0;                 // team-wide dealing: tickets used up by earlier sweeps
     __shared__ int sh_one_xcd;
     if (threadIdx.x == 0) {
         unsigned int xcc;
@@ -204,7 +189,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
         __hip_atomic_fetch_or(xccs, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     bool one_xcd = false, placed = false;                      // known after the first (full) barrier
-    const bool resumed = p.resumed != 0;
+    constexpr bool resumed = RESUMED;                          // (the host sets p.resumed alike)
     const BPCold *const cd = p.cold;
     u64 tk_check = 0, tk_var = 0, tk_rest = 0;   // this wave's own sweep time / everything else (waiting included)
     long long tot_iters = 0;                     // (rank 0, wave 0) iterations of the syndromes this team finished
@@ -253,23 +238,11 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
                     else check_update<DC, false>(Mt + (size_t)e0 * kTile, deg, sigma, r);
                 }
             };
-            if (tp.dynamic == 2 && one_xcd && nch > GW) {
-                // the whole team's chunks from one counter: chunk gw is this wave's by right, ticket t stands for chunk
-                // GW + (t - base); every wave draws one ticket more than it gets chunks, so a sweep uses up nch tickets
-                unsigned int tv = team_ticket_request(ctr + kTeamCtlTicketCheck, lane);
-                for (int c = gw; c < nch;) {
-                    chunk(c);
-                    c = GW + (int)(team_ticket_value(tv) - base_check);
-                    if (c < nch) tv = team_ticket_request(ctr + kTeamCtlTicketCheck, lane);
-                }
-                base_check += (unsigned int)nch;
-            } else {
-                // this member's share is chunks rank, rank + G, ...; its waves take them from the counter in LDS
-                const int mine = (nch - rank + G - 1) / G;
-                for (int l = w; l < mine;) {
-                    chunk(l * G + rank);
-                    l = tp.dynamic ? W + team_deal(&sh_deal[0], lane) : l + W;
-                }
+            // this member's share is chunks rank, rank + G, ...; its waves take them from the counter in LDS
+            const int mine = (nch - rank + G - 1) / G;
+            for (int l = w; l < mine;) {
+                chunk(l * G + rank);
+                l = tp.dynamic ? W + team_deal(&sh_deal[0], lane) : l + W;
             }
         }
         const u64 t1 = wall_clock64();
@@ -311,20 +284,10 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
                     decide(j, bit_update<DV>(Mt, csc2csr + c0, deg, r));
                 }
             };
-            if (tp.dynamic == 2 && one_xcd && nch > GW) {
-                unsigned int tv = team_ticket_request(ctr + kTeamCtlTicketVar, lane);
-                for (int c = gw; c < nch;) {
-                    chunk(c);
-                    c = GW + (int)(team_ticket_value(tv) - base_var);
-                    if (c < nch) tv = team_ticket_request(ctr + kTeamCtlTicketVar, lane);
-                }
-                base_var += (unsigned int)nch;
-            } else {
-                const int mine = (nch - rank + G - 1) / G;
-                for (int l = w; l < mine;) {
-                    chunk(l * G + rank);
-                    l = tp.dynamic ? W + team_deal(&sh_deal[1], lane) : l + W;
-                }
+            const int mine = (nch - rank + G - 1) / G;
+            for (int l = w; l < mine;) {
+                chunk(l * G + rank);
+                l = tp.dynamic ? W + team_deal(&sh_deal[1], lane) : l + W;
             }
         }
         const u64 t3 = wall_clock64();

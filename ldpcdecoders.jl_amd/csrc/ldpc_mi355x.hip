@@ -306,6 +306,10 @@ struct ldpc_bp_decoder {
     unsigned int *team_fault = nullptr, *team_fault_dev = nullptr;
     int team_max = 32;        // workgroups per tile at most (LDPC_TEAM_MAX; 1 = team kernel off)
     bool team_max_set = false;   // ... given by the environment: no automatic 64 for batches of <= 4 tiles
+    // (read at create, so that a test or the fuzzer can vary them from decoder to decoder)
+    size_t team_cache = (size_t)256 << 20;   // LDPC_TEAM_CACHE_MIB: message slots in flight that persistent teams may hold (team_plan())
+    int team_dynamic = 1;     // LDPC_TEAM_DYNAMIC: a member's waves take its chunks from a counter in LDS (0: every W-th)
+    int team_pairs = 1;       // LDPC_TEAM_PAIRS: two nodes of the full degree are loaded together
     // latency mode of the host-pointer entry (tiny batches, a plain decode!): the kernel reads and writes a
     // host-mapped staging image and raises a flag in it; no copies, no events, no stream synchronisation
     DevBuf done_ctr;          // one device word, zero between launches
@@ -687,6 +691,10 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     d->variant = options ? options->kernel_variant : 0;
     if (d->variant < 0 || d->variant > 4) { delete d; return fail(LDPC_ERR_INVALID_ARGUMENT, "kernel_variant must be 0 ... 4"); }
     d->inject_fault = std::getenv("LDPC_TEAM_INJECT_FAULT") != nullptr;   // (tests)
+    if (const char *e = std::getenv("LDPC_TEAM_CACHE_MIB")) d->team_cache = (size_t)std::max(0, std::atoi(e)) << 20;
+    if (const char *e = std::getenv("LDPC_TEAM_CACHE_KIB")) d->team_cache = (size_t)std::max(0, std::atoi(e)) << 10;   // (tests: persistent teams on small graphs)
+    if (const char *e = std::getenv("LDPC_TEAM_DYNAMIC")) d->team_dynamic = std::atoi(e) != 0;
+    if (const char *e = std::getenv("LDPC_TEAM_PAIRS")) d->team_pairs = std::atoi(e) != 0;
     if (const char *e = std::getenv("LDPC_TEAM_MAX")) { d->team_max = std::max(1, std::min(kTeamMaxMembers, std::atoi(e))); d->team_max_set = true; }
     {
         void *fp = nullptr, *fd = nullptr;
@@ -892,12 +900,6 @@ struct TeamPlan {
     bool scatter = false;
 };
 
-static size_t team_cache_bytes()
-{
-    static const size_t v = [] { const char *e = std::getenv("LDPC_TEAM_CACHE_MIB"); return (size_t)(e ? std::max(0, std::atoi(e)) : 256) << 20; }();
-    return v;
-}
-
 static TeamPlan team_plan(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
 {
     TeamPlan pl;
@@ -917,7 +919,7 @@ static TeamPlan team_plan(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
     } else {
         const int64_t need = (ntiles + 7) / 8;
         const size_t state = std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double);
-        const size_t cache = team_cache_bytes();
+        const size_t cache = d->team_cache;
         int64_t tpx = need;
         if (cache == 0) {
             if (ntiles > d->num_cus) return pl;
@@ -1268,7 +1270,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             // Infinity Cache (team_plan()); they take whatever the level holds.  Without a cache budget
             // (LDPC_TEAM_CACHE_MIB=0): one tile per team, up to as many tiles as leave every team 3 members.
             const size_t state = std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double);
-            const size_t cache = team_cache_bytes();
+            const size_t cache = d->team_cache;
             int tiles_max;
             if (cache) {
                 const int tpx = (int)std::max<size_t>(1, std::min<size_t>(cache / (8 * state), (size_t)L.t_per_xcd / 3));
@@ -1345,8 +1347,6 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     HIP_TRY(hipGetLastError());
     bp_kernel_t kfn = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, threads);
     static const int always_release = std::getenv("LDPC_TEAM_ALWAYS_RELEASE") ? 1 : 0;
-    static const int team_pairs = [] { const char *e = std::getenv("LDPC_TEAM_PAIRS"); return e ? std::atoi(e) : 1; }();
-    static const int team_dynamic = [] { const char *e = std::getenv("LDPC_TEAM_DYNAMIC"); return e ? std::atoi(e) : 1; }();
     auto team_params = [&](DevBuf &wsbuf, int nteams, int tiles, TeamParams &tp) -> ldpc_status {
         const size_t ctl_bytes = ((size_t)nteams + 1) * kTeamCtlWords * sizeof(unsigned int);   // + the block of the tile queue
         const size_t mism_stride = ((size_t)d->max_iters + 31) & ~(size_t)31;
@@ -1360,8 +1360,8 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         tp.fault = d->team_fault_dev;
         tp.always_release = always_release;
         tp.nteams = nteams;
-        tp.dynamic = team_dynamic;
-        tp.pairs = team_pairs;
+        tp.dynamic = d->team_dynamic;
+        tp.pairs = d->team_pairs;
         tp.scatter = 0;
         tp.count_max = 0;
         tp.inject_fault = 0;
@@ -1453,7 +1453,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             if ((st = team_params(d->team_ws_lvl[l - 1], L.t_nteams, (int)(L.team_cap / kTile), tp)) != LDPC_OK) return st;
             tp.G = L.t_G;
             tp.count_max = L.team_cap;
-            team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr);
+            team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr, true);
             void *args[] = {&q3, &tp, &a_row, &a_eb, &a_col, &a_c2r, &l_syn, &l_nev};
             HIP_TRY(launch_team_grid(d, tk, L.t_G * L.t_nteams, args, stream));
         }

@@ -4,25 +4,39 @@
 namespace ldpc {
 
 namespace {
-template <int DC, bool LLR>
+template <int DC, bool LLR, bool RESUMED>
 team_kernel_t team_pick_dv(int dv)
 {
-    if (dv <= 4) return bp_team_kernel<DC, 4, LLR, 512>;
-    return bp_team_kernel<DC, 16, LLR, 512>;
+    if (dv <= 4) return bp_team_kernel<DC, 4, LLR, 512, RESUMED>;
+    return bp_team_kernel<DC, 16, LLR, 512, RESUMED>;
 }
-template <bool LLR>
+template <bool LLR, bool RESUMED>
 team_kernel_t team_pick_dc(int dc, int dv)
 {
-    if (dc <= 8) return team_pick_dv<8, LLR>(dv);
-    if (dc <= 16) return team_pick_dv<16, LLR>(dv);
-    return team_pick_dv<32, LLR>(dv);
+    if (dc <= 8) return team_pick_dv<8, LLR, RESUMED>(dv);
+    if (dc <= 16) return team_pick_dv<16, LLR, RESUMED>(dv);
+    return team_pick_dv<32, LLR, RESUMED>(dv);
 }
 
 }  // namespace
 
-team_kernel_t pick_team_kernel(int dc, int dv, bool llr)
+// This file is compiled twice (Makefile): LDPC_TEAM_RESUMED = 0 -> the instantiations for fresh tiles and
+// pick_team_kernel itself, 1 -> the instantiations of the passes over the packed levels (<..., RESUMED = true>).
+#ifndef LDPC_TEAM_RESUMED
+#define LDPC_TEAM_RESUMED 0
+#endif
+#if LDPC_TEAM_RESUMED
+team_kernel_t pick_team_kernel_resumed(int dc, int dv, bool llr)
 {
-    return llr ? team_pick_dc<true>(dc, dv) : team_pick_dc<false>(dc, dv);
+    return llr ? team_pick_dc<true, true>(dc, dv) : team_pick_dc<false, true>(dc, dv);
 }
+#else
+team_kernel_t pick_team_kernel_resumed(int dc, int dv, bool llr);
+team_kernel_t pick_team_kernel(int dc, int dv, bool llr, bool resumed)
+{
+    if (resumed) return pick_team_kernel_resumed(dc, dv, llr);
+    return llr ? team_pick_dc<true, false>(dc, dv) : team_pick_dc<false, false>(dc, dv);
+}
+#endif
 
 }  // namespace ldpc

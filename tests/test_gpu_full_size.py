@@ -86,6 +86,11 @@ def test_c3_full_batch(ldpc, gpu, per, subset):
     e3, c3, i3 = _decode(ldpc, H, per, syn, kernel_variant=1, defer_threshold=-1)
     assert torch.equal(e3, err) and torch.equal(c3, conv) and torch.equal(i3, its)
     del e3, c3, i3
+    # (3c) ... and against the tile kernel WITH its hand-off levels (the default path of this code is the team kernel:
+    #      8 persistent teams whose message slots stay in the Infinity Cache)
+    e4, c4, i4 = _decode(ldpc, H, per, syn, kernel_variant=1)
+    assert torch.equal(e4, err) and torch.equal(c4, conv) and torch.equal(i4, its)
+    del e4, c4, i4
     # (4) the oracle on a random subset
     idx = np.sort(np.random.default_rng(7).choice(B, subset, replace=False))
     tidx = torch.from_numpy(idx).to(syn.device)

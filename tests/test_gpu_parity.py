@@ -184,20 +184,25 @@ def test_straggler_handoff_levels_and_pass_kinds(ldpc, gpu, take, team_max, t0, 
     assert_parity(ldpc, H, 0.065, 40, syn[:700], kernel_variant=1)
 
 
-@pytest.mark.parametrize("B,per,scatter", [(640, 0.02, False), (4160, 0.065, False), (3000, 0.10, False),
-                                           (640, 0.10, True), (2900, 0.065, True)])
-def test_team_kernel_is_bit_identical_to_the_tile_kernel(ldpc, gpu, B, per, scatter, monkeypatch):
+@pytest.mark.parametrize("B,per,scatter,cache_mib", [(640, 0.02, False, None), (4160, 0.065, False, None), (3000, 0.10, False, None),
+                                                     (640, 0.10, True, None), (2900, 0.065, True, None),
+                                                     (4160, 0.065, False, 64), (3000, 0.10, False, 64), (2900, 0.02, True, 64)])
+def test_team_kernel_is_bit_identical_to_the_tile_kernel(ldpc, gpu, B, per, scatter, cache_mib, monkeypatch):
     """Several workgroups per tile (agent-scope release / acquire between the sweeps) against one
     workgroup per tile: same node updates, so EVERYTHING must come out bit for bit the same, LLRs
     included -- one stale message row anywhere would show.  n = 4096 beyond the LDS, 10 ... 65 tiles
     of very different iteration counts (uneven load), teams of 8 or 7 workgroups (n = 16384 teams of 32 run
     in test_c3_code_n16384_small_batch).  scatter: the members of a team are dealt over ALL XCDs
     (LDPC_TEAM_SCATTER), so the teams find themselves on several XCDs and every barrier writes the L2
-    back -- the path taken if the round-robin placement of workgroups ever changes."""
+    back -- the path taken if the round-robin placement of workgroups ever changes.  cache_mib: the budget for
+    message slots in flight (LDPC_TEAM_CACHE_MIB; 64 MiB = 8 slots of this code): 8 persistent teams that take 6 ... 9
+    tiles each from the queue, one after the other in the same slot, instead of the default 32 teams."""
     import torch
 
     if scatter:
         monkeypatch.setenv("LDPC_TEAM_SCATTER", "1")
+    if cache_mib is not None:
+        monkeypatch.setenv("LDPC_TEAM_CACHE_MIB", str(cache_mib))
     n = 4096
     H = ldpc.codes.parity_check_csc(n, 8, 4)
     syn = torch.from_numpy(ldpc.codes.syndromes_of(H, ldpc.codes.random_errors(n, B, per, seed=B))).cuda()
@@ -221,6 +226,8 @@ def test_team_kernel_is_bit_identical_to_the_tile_kernel(ldpc, gpu, B, per, scat
             # the grid is whole teams; with more tiles than teams the teams are persistent (a team takes tile after tile)
             assert info.resident_tiles % info.last_team_size == 0
             assert info.resident_tiles >= info.last_team_size * min((B + 63) // 64, 8)
+            if cache_mib is not None:
+                assert info.resident_tiles == 8 * info.last_team_size     # 8 teams for 45 ... 65 tiles
         else:
             assert dec.info().last_kernel == 1
         dec.close()

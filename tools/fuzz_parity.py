@@ -41,7 +41,7 @@ while time.time() - t0 < budget:
     s, n = H.shape
     per = float(rng.choice([1e-6, 0.005, 0.02, 0.05, 0.1, 0.3, 0.5, 0.9]))
     iters = int(rng.choice([1, 2, 3, 7, 20, 50]))
-    B = int(rng.choice([1, 2, 63, 64, 65, 130, 400, 1500]))
+    B = int(rng.choice([1, 2, 63, 64, 65, 130, 400, 1500, 5000]))
     if rng.random() < 0.5:
         E = (rng.random((B, n)) < min(per * rng.uniform(0.5, 3), 0.5)).astype(np.uint8)
         syn = ldpc.codes.syndromes_of(H, E)
@@ -65,8 +65,17 @@ while time.time() - t0 < budget:
             os.environ["LDPC_NODE_HYBRID"] = "0"
         # hand-off levels (read at create): thresholds of fresh / level-1 tiles, tiny level capacities (levels fill
         # up and tiles must carry on), how many stragglers the node kernel finishes
-        for k in ("LDPC_DEFER_T0", "LDPC_DEFER_T1", "LDPC_DEFER_CAP_TILES", "LDPC_NODE_TAKE_MAX"):
+        for k in ("LDPC_DEFER_T0", "LDPC_DEFER_T1", "LDPC_DEFER_CAP_TILES", "LDPC_NODE_TAKE_MAX", "LDPC_TEAM_CACHE_KIB",
+                  "LDPC_TEAM_DYNAMIC", "LDPC_TEAM_PAIRS"):
             os.environ.pop(k, None)
+        # teams (read at create): a small cache budget makes them persistent on these small graphs (a team takes tile
+        # after tile in its own slot); how a member's waves share its chunks; nodes loaded in pairs or singly
+        if rng.random() < 0.6:
+            os.environ["LDPC_TEAM_CACHE_KIB"] = str(int(rng.choice([1, 8 * max(1, H.nnz) // 2, 16 * max(1, H.nnz)])))
+        if rng.random() < 0.5:
+            os.environ["LDPC_TEAM_DYNAMIC"] = str(int(rng.integers(0, 2)))
+        if rng.random() < 0.5:
+            os.environ["LDPC_TEAM_PAIRS"] = str(int(rng.integers(0, 2)))
         if rng.random() < 0.7:
             os.environ["LDPC_DEFER_T0"] = str(int(rng.choice([4, 16, 32, 48])))
             os.environ["LDPC_DEFER_T1"] = str(int(rng.choice([0, 8, 16, 40])))
