@@ -36,6 +36,9 @@
 #pragma once
 #include "bp_kernels.hpp"
 
+#ifndef LDPC_TEAM_THREADS   // threads per member (experiments: 1024 = one 16-wave member per CU)
+#define LDPC_TEAM_THREADS 512
+#endif
 #ifndef LDPC_TEAM_SLEEP   // s_sleep argument between two polls of the arrival counter (x64 cycles)
 #define LDPC_TEAM_SLEEP 16
 #endif
@@ -44,6 +47,8 @@ namespace ldpc {
 
 struct TeamParams {
     int G;                      // workgroups per team
+    int xcds;                   // XCDs that host teams (8; fewer = the blocks of the others leave at once: the slots in flight
+                                // are then 7/8 ... of the cache budget's) -- not in scatter mode
     int nteams;                 // teams launched; team t works in message slot t (fresh tiles) and starts on tile t
     int pairs;                  // 1 = two nodes of the full degree are loaded together (twice the bytes in flight per wave)
     int dynamic;                // 1 = the waves of a member take the chunks of its share from a counter in LDS; 0 = every W-th
@@ -174,7 +179,8 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     // one.  Teams are formed among the blocks of one residue class, so that normally a team sits on ONE
     // XCD; the members check it (xccs) and fall back to full release / acquire barriers if it is not so.
     const int bq = (int)(blockIdx.x >> 3), xslot = (int)(blockIdx.x & 7u);   // gridDim.x == 8 * G * ceil(nteams / 8)
-    const int team = tp.scatter ? (int)(blockIdx.x / (unsigned)G) : (bq / G) * 8 + xslot;
+    if (!tp.scatter && xslot >= tp.xcds) return;
+    const int team = tp.scatter ? (int)(blockIdx.x / (unsigned)G) : (bq / G) * tp.xcds + xslot;
     const int rank = tp.scatter ? (int)(blockIdx.x % (unsigned)G) : bq % G;
     if (team >= nteams || team >= ntiles) return;              // whole teams only: nobody waits for these
     const int gw = rank * W + w, GW = G * W;                   // this wave among the team's waves

@@ -307,7 +307,8 @@ struct ldpc_bp_decoder {
     int team_max = 32;        // workgroups per tile at most (LDPC_TEAM_MAX; 1 = team kernel off)
     bool team_max_set = false;   // ... given by the environment: no automatic 64 for batches of <= 4 tiles
     // (read at create, so that a test or the fuzzer can vary them from decoder to decoder)
-    size_t team_cache = (size_t)256 << 20;   // LDPC_TEAM_CACHE_MIB: message slots in flight that persistent teams may hold (team_plan())
+    size_t team_cache = (size_t)240 << 20;   // LDPC_TEAM_CACHE_MIB: message slots in flight that persistent teams may hold (team_fit())
+    int team_xcds = 0;        // LDPC_TEAM_XCDS: XCDs that host persistent teams, fixed (experiments; 0 = team_fit() chooses)
     int team_dynamic = 1;     // LDPC_TEAM_DYNAMIC: a member's waves take its chunks from a counter in LDS (0: every W-th)
     int team_pairs = 1;       // LDPC_TEAM_PAIRS: two nodes of the full degree are loaded together
     // latency mode of the host-pointer entry (tiny batches, a plain decode!): the kernel reads and writes a
@@ -694,6 +695,7 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     if (const char *e = std::getenv("LDPC_TEAM_CACHE_MIB")) d->team_cache = (size_t)std::max(0, std::atoi(e)) << 20;
     if (const char *e = std::getenv("LDPC_TEAM_CACHE_KIB")) d->team_cache = (size_t)std::max(0, std::atoi(e)) << 10;   // (tests: persistent teams on small graphs)
     if (const char *e = std::getenv("LDPC_TEAM_DYNAMIC")) d->team_dynamic = std::atoi(e) != 0;
+    if (const char *e = std::getenv("LDPC_TEAM_XCDS")) d->team_xcds = std::max(1, std::min(8, std::atoi(e)));
     if (const char *e = std::getenv("LDPC_TEAM_PAIRS")) d->team_pairs = std::atoi(e) != 0;
     if (const char *e = std::getenv("LDPC_TEAM_MAX")) { d->team_max = std::max(1, std::min(kTeamMaxMembers, std::atoi(e))); d->team_max_set = true; }
     {
@@ -835,7 +837,7 @@ static size_t team_lds_bytes()
 static hipError_t launch_team_grid(ldpc_bp_decoder *d, team_kernel_t tk, int grid, void **args, hipStream_t stream)
 {
     static const bool coop = std::getenv("LDPC_TEAM_COOP_LAUNCH") != nullptr;
-    if (coop) return hipLaunchCooperativeKernel((const void *)tk, dim3((unsigned)grid), dim3(512), args, (unsigned)team_lds_bytes(), stream);
+    if (coop) return hipLaunchCooperativeKernel((const void *)tk, dim3((unsigned)grid), dim3(LDPC_TEAM_THREADS), args, (unsigned)team_lds_bytes(), stream);
     std::lock_guard<std::mutex> lk(g_team_mu);
     hipEvent_t *gev = (d->device >= 0 && d->device < 64) ? &g_team_ev[d->device] : nullptr;
     if (gev) {
@@ -846,7 +848,7 @@ static hipError_t launch_team_grid(ldpc_bp_decoder *d, team_kernel_t tk, int gri
             if (w != hipSuccess) return w;
         }
     }
-    hipError_t e = hipLaunchKernel((const void *)tk, dim3((unsigned)grid), dim3(512), args, team_lds_bytes(), stream);
+    hipError_t e = hipLaunchKernel((const void *)tk, dim3((unsigned)grid), dim3(LDPC_TEAM_THREADS), args, team_lds_bytes(), stream);
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess && gev && *gev) e = hipEventRecord(*gev, stream);
     return e;
@@ -875,7 +877,7 @@ static bool team_geometry(ldpc_bp_decoder *d, bool want_llr, int *per_xcd, int *
     // what this instantiation's registers admit (the wide-degree buckets: one 8-wave workgroup per CU), less one
     // as the margin where that leaves at least one
     int occ = 0;
-    if (d->prepare_kernel((const void *)pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr), 512, team_lds_bytes(), &occ) != LDPC_OK) return false;
+    if (d->prepare_kernel((const void *)pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr), LDPC_TEAM_THREADS, team_lds_bytes(), &occ) != LDPC_OK) return false;
     static const bool no_margin = std::getenv("LDPC_TEAM_NO_MARGIN") != nullptr;   // (experiments: fill the CUs exactly)
     const int per_cu = no_margin ? std::min(per_cu_want, occ) : std::min(per_cu_want, occ >= 2 ? occ - (occ > per_cu_want ? 0 : 1) : occ);
     if (per_cu < 1) return false;
@@ -885,18 +887,43 @@ static bool team_geometry(ldpc_bp_decoder *d, bool want_llr, int *per_xcd, int *
     return *per_xcd >= 1;
 }
 
+// Persistent teams whose message slots in flight stay inside the cache budget (LDPC_TEAM_CACHE_MIB, default 240 of
+// the Infinity Cache's 256 MiB): how many XCDs host teams (8, 7 or 6), how many teams each, how many members a
+// team -- the combination that gives most workgroups a tile.  For the n = 16384 code (32 MiB a slot) that is SEVEN
+// teams of 32: with an eighth the slots fill the cache to the brim and every team is a fifth slower (full batch,
+// 50 iterations: 1111 ms on 8 XCDs, 1011 ms on 7, 1158 ms on 6).  false: nothing fits.
+static bool team_fit(const ldpc_bp_decoder *d, int per_xcd, int gcap, int64_t ntiles, int *xcds, int *tpx, int *G)
+{
+    const size_t state = std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double);
+    const size_t cache = d->team_cache;
+    if (!cache) return false;
+    int64_t best = 0;
+    const int x_hi = d->team_xcds ? d->team_xcds : 8, x_lo = d->team_xcds ? d->team_xcds : 6;
+    for (int x = x_hi; x >= x_lo; --x)
+        for (int t = 1; t <= per_xcd / 3; ++t) {
+            if ((size_t)x * (size_t)t * state > cache) break;
+            if (t > 1 && (int64_t)x * (t - 1) >= ntiles) break;            // no more teams than tiles
+            const int g = std::min(gcap, per_xcd / t);
+            if (g < 3) break;
+            const int64_t w = std::min<int64_t>((int64_t)x * t, ntiles) * g;   // workgroups with a tile
+            if (w > best) { best = w; *xcds = x; *tpx = t; *G = g; }
+        }
+    return best > 0;
+}
+
 // How a batch of fresh tiles is dealt to teams (bp_team_kernels.hpp).  G = 1: no teams for it.
 //   * up to 4 tiles: one team per tile, its members dealt over ALL XCDs (scatter), up to 64 of them;
-//   * otherwise teams inside one XCD, 8 x tpx of them, PERSISTENT: a team takes tile after tile in its own
-//     message slot.  tpx (teams per XCD) is as many as the tiles need but no more than keeps the slots in
-//     flight -- 8 x tpx x 512 nnz bytes -- inside the Infinity Cache (LDPC_TEAM_CACHE_MIB, default 256;
-//     0 = round 1's rule: one team per tile, at most one tile per CU, nothing persistent).  Batches of more
-//     tiles than CUs only go to teams when the slots do fit: the n = 16384 code does with tpx = 1
-//     (8 x 32 MiB), larger graphs stay with the tile kernel.
+//   * as many tiles as fit one round of teams with the slots at most a quarter over the cache budget: one team per
+//     tile (8 tiles of the n = 16384 code: 8 teams once rather than 7 teams twice);
+//   * otherwise PERSISTENT teams inside the budget (team_fit()): a team takes tile after tile in its own slot;
+//   * nothing fits (larger graphs; LDPC_TEAM_CACHE_MIB=0): round 1's rule -- one team per tile, at most one tile
+//     per CU -- and batches of more tiles than CUs stay with the tile kernel, which streams from HBM as well as
+//     teams would.
 struct TeamPlan {
     int G = 1;            // members per team
     int nteams = 0;       // teams (and message slots)
     int grid = 0;         // workgroups to launch
+    int xcds = 8, tpx = 0;   // XCDs that host teams, teams per XCD (not in scatter mode)
     bool scatter = false;
 };
 
@@ -919,22 +946,21 @@ static TeamPlan team_plan(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
     } else {
         const int64_t need = (ntiles + 7) / 8;
         const size_t state = std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double);
-        const size_t cache = d->team_cache;
-        int64_t tpx = need;
-        if (cache == 0) {
-            if (ntiles > d->num_cus) return pl;
-        } else {
-            const int64_t fit = (int64_t)(cache / (8 * state));
-            if (ntiles > d->num_cus && fit < 1) return pl;       // slots beyond the cache: the tile kernel streams from HBM as well as teams would
-            tpx = std::min<int64_t>(need, std::max<int64_t>(1, fit));
+        int x = 8, t = (int)need, g = 0;
+        const bool one_round = d->team_cache && !d->team_xcds && (size_t)8 * (size_t)need * state <= d->team_cache + d->team_cache / 4;
+        if (one_round || !team_fit(d, per_xcd, gcap, ntiles, &x, &t, &g)) {
+            if (!one_round && ntiles > d->num_cus) return pl;
+            x = 8; t = (int)need;
+            g = (int)std::min<int64_t>(gcap, (int64_t)per_xcd / t);
         }
-        team = std::min<int64_t>(gcap, (int64_t)per_xcd / tpx);
-        nteams = 8 * tpx;
+        team = g;
+        nteams = (int64_t)x * t;
+        pl.xcds = x; pl.tpx = t;
     }
     if (team < 3) return pl;   // two workgroups per tile measured no better than the tile kernel's one of 16 waves
     pl.G = (int)std::min<int64_t>(team, kTeamMaxMembers);
     pl.nteams = (int)nteams;
-    pl.grid = pl.scatter ? pl.nteams * pl.G : 8 * pl.G * (pl.nteams / 8);
+    pl.grid = pl.scatter ? pl.nteams * pl.G : 8 * pl.G * pl.tpx;
     return pl;
 }
 
@@ -1227,7 +1253,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         unsigned int *tile_queue = nullptr, *node_queue = nullptr;
         unsigned node_take = 0;   // up to this many syndromes: the node-parallel kernel finishes them
         unsigned team_cap = 0;    // above node_take up to this many: teams of workgroups on the packed tiles
-        int t_per_xcd = 0, t_gcap = 0, t_G = 0, t_nteams = 0;   // teams on the packed tiles: members, teams
+        int t_per_xcd = 0, t_gcap = 0, t_G = 0, t_nteams = 0, t_grid = 0, t_xcds = 8;   // teams on the packed tiles: members, teams
     } lv[3];
     int nlevels = 0;
     if (T0 > 0) {
@@ -1266,22 +1292,17 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         L.node_take = (d->node_ok && d->variant == 0 && d->node_take_max > 0)
                           ? (unsigned)std::min<int64_t>(d->node_take_max, (int64_t)L.cap_tiles * kTile) : 0u;
         if (L.node_take && d->max_iters <= 4096 && team_geometry(d, want_llr, &L.t_per_xcd, &L.t_gcap) && L.t_gcap >= 3) {
-            // persistent teams inside the packed tiles: as many per XCD as keep the tiles in flight inside the
-            // Infinity Cache (team_plan()); they take whatever the level holds.  Without a cache budget
-            // (LDPC_TEAM_CACHE_MIB=0): one tile per team, up to as many tiles as leave every team 3 members.
-            const size_t state = std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double);
-            const size_t cache = d->team_cache;
-            int tiles_max;
-            if (cache) {
-                const int tpx = (int)std::max<size_t>(1, std::min<size_t>(cache / (8 * state), (size_t)L.t_per_xcd / 3));
-                L.t_G = std::min(L.t_gcap, L.t_per_xcd / tpx);
-                L.t_nteams = 8 * tpx;
+            // persistent teams inside the packed tiles, as many as keep the tiles in flight inside the cache budget
+            // (team_fit()); they take whatever the level holds.  Nothing fits (LDPC_TEAM_CACHE_MIB=0, large graphs):
+            // one tile per team, up to as many tiles as leave every team 3 members.
+            int tiles_max, x = 8, t = 1, g = 3;
+            if (team_fit(d, L.t_per_xcd, L.t_gcap, L.cap_tiles, &x, &t, &g)) {
                 tiles_max = L.cap_tiles;
             } else {
-                L.t_nteams = 8 * (L.t_per_xcd / 3);
-                L.t_G = 3;                                   // (the members of surplus teams are idle: round 1's geometry in fixed form)
-                tiles_max = std::min(L.t_nteams, L.cap_tiles);
+                x = 8; t = L.t_per_xcd / 3; g = 3;           // (the members of surplus teams are idle: round 1's geometry in fixed form)
+                tiles_max = std::min(x * t, L.cap_tiles);
             }
+            L.t_G = g; L.t_xcds = x; L.t_nteams = x * t; L.t_grid = 8 * g * t;
             if ((unsigned)tiles_max * kTile > L.node_take) L.team_cap = (unsigned)tiles_max * kTile;
         }
     }
@@ -1360,6 +1381,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         tp.fault = d->team_fault_dev;
         tp.always_release = always_release;
         tp.nteams = nteams;
+        tp.xcds = 8;
         tp.dynamic = d->team_dynamic;
         tp.pairs = d->team_pairs;
         tp.scatter = 0;
@@ -1374,6 +1396,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         TeamParams tp{};
         if ((st = team_params(d->team_ws, plan.nteams, ntiles, tp)) != LDPC_OK) return st;
         tp.G = team;
+        tp.xcds = plan.xcds;
         tp.scatter = team_scatter ? 1 : 0;
         tp.inject_fault = d->inject_fault ? 1 : 0;   // (tests)
         team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr);
@@ -1452,10 +1475,11 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             TeamParams tp{};
             if ((st = team_params(d->team_ws_lvl[l - 1], L.t_nteams, (int)(L.team_cap / kTile), tp)) != LDPC_OK) return st;
             tp.G = L.t_G;
+            tp.xcds = L.t_xcds;
             tp.count_max = L.team_cap;
             team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr, true);
             void *args[] = {&q3, &tp, &a_row, &a_eb, &a_col, &a_c2r, &l_syn, &l_nev};
-            HIP_TRY(launch_team_grid(d, tk, L.t_G * L.t_nteams, args, stream));
+            HIP_TRY(launch_team_grid(d, tk, L.t_grid, args, stream));
         }
     }
     HIP_TRY(hipEventRecord(ev[2], stream));

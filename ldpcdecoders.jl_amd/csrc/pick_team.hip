@@ -7,8 +7,8 @@ namespace {
 template <int DC, bool LLR, bool RESUMED>
 team_kernel_t team_pick_dv(int dv)
 {
-    if (dv <= 4) return bp_team_kernel<DC, 4, LLR, 512, RESUMED>;
-    return bp_team_kernel<DC, 16, LLR, 512, RESUMED>;
+    if (dv <= 4) return bp_team_kernel<DC, 4, LLR, LDPC_TEAM_THREADS, RESUMED>;
+    return bp_team_kernel<DC, 16, LLR, LDPC_TEAM_THREADS, RESUMED>;
 }
 template <bool LLR, bool RESUMED>
 team_kernel_t team_pick_dc(int dc, int dv)
