@@ -55,7 +55,8 @@ typedef struct ldpc_bp_info {
     int32_t device;           /* HIP device ordinal */
     int32_t tile_syndromes;   /* syndromes decoded together by one workgroup (lane = syndrome) */
     int32_t waves_per_tile;   /* wavefronts cooperating on one tile */
-    int32_t resident_tiles;   /* workspace slots = workgroups in the persistent grid */
+    int32_t resident_tiles;   /* workgroups in the persistent grid of the most recent batch call (tile kernel: one
+                                 message slot each; team kernel: last_team_size per message slot) */
     int64_t workspace_bytes;  /* device bytes held by the handle */
     int32_t last_kernel;      /* kernel the most recent batch call ran: 0 none yet, 1 HBM-streaming tile kernel,
                                  2 LDS-resident, 3 node-parallel, 4 team (numbered like kernel_variant) */
@@ -71,11 +72,14 @@ typedef struct ldpc_bp_options {
                                  the graph fit a CU's LDS; node-parallel kernel (one workgroup per syndrome) when
                                  only ONE syndrome's messages fit it, at every batch size; beyond that a cost
                                  model picks between the node-parallel kernel and the team kernel (several
-                                 workgroups per 64-syndrome tile) while there are fewer tiles than CUs, and the
+                                 workgroups per 64-syndrome tile) for small batches; the team kernel takes the larger
+                                 ones with PERSISTENT teams (a team decodes tile after tile in its own message slot)
+                                 when a chip-wide set of slots fits the 256 MiB Infinity Cache (n <= ~16384 for
+                                 (4,8)-regular codes), else with one team per tile up to one tile per CU; the
                                  HBM-streaming tile kernel (one persistent workgroup per tile) takes the rest.
                                  1 = force streaming; 2 = force LDS-resident (error if it does not fit);
-                                 3 = force node-parallel; 4 = team kernel wherever the batch has at most one tile
-                                 per CU, streaming otherwise (never LDS-resident / node-parallel).
+                                 3 = force node-parallel; 4 = team kernel wherever it applies, streaming otherwise
+                                 (never LDS-resident / node-parallel).
                                  ldpc_bp_info.last_kernel reports what ran */
     int32_t defer_threshold;  /* HBM-streaming kernel: a 64-syndrome tile hands its unconverged syndromes to a
                                  densely packed second pass once at most this many are left (same results,

@@ -1229,7 +1229,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     // scatter mode launches exactly the members (8 * team blocks for <= 4 tiles would be up to 512 workgroups,
     // more than the wide-degree instantiations can keep resident: one 8-wave workgroup per CU)
     const int team_grid = team > 1 ? (team_scatter ? plan.nteams * team : plan.grid) : 0;
-    d->last_grid = team > 1 ? team_grid : grid;
+    d->last_grid = team > 1 ? plan.nteams * team : grid;   // (teams: the workgroups that take part; on an XCD that hosts no team the blocks leave at once)
     d->last_kernel = team > 1 ? 4 : 1;
     d->last_team = team;
     const size_t slot_stride_bytes = std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double) + slot_pad_bytes();
