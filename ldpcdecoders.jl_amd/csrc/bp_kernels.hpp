@@ -173,6 +173,24 @@ __device__ __forceinline__ void check_finish_exact(double *M, const double (&a)[
     }
 }
 
+// ... the same with the D new messages handed back instead of stored (rows that do not lie k * 64 doubles apart:
+// bp_team_kernels.hpp keeps some in LDS)
+template <int D>
+__device__ __forceinline__ void check_compute_exact(const double (&a)[D], double sigma, double (&out)[D])
+{
+    double pre[D];
+    double P = sigma;                                     // :136
+#pragma unroll
+    for (int k = 0; k < D; ++k) { pre[k] = P; P = P * a[k]; }          // :139-140
+    double S = 1.0;                                       // :143
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) {
+        const double t = pre[k] * S;                      // :146
+        out[k] = (1.0 - t) / (1.0 + t);                   // :147
+        S = S * a[k];                                     // :148
+    }
+}
+
 template <int D, bool FIRST>
 __device__ __forceinline__ void check_update_exact(double *M, double sigma, double r)
 {
@@ -280,6 +298,28 @@ __device__ __forceinline__ double bit_finish_exact(double *Mt, const size_t (&at
     return F;
 }
 
+// ... the same with the D new messages handed back instead of stored
+template <int D>
+__device__ __forceinline__ double bit_compute_exact(const double (&c)[D], double r, double (&out)[D])
+{
+    double pre[D];
+    double F = r;                                         // :153
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        pre[k] = F;                                       // :156
+        F = F * c[k];                                     // :157
+        if (F != F) F = 1.0;                              // :158-160
+    }
+    double G = 1.0;                                       // :170
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) {
+        out[k] = pre[k] * G;                              // :172 (unguarded, may be NaN)
+        G = G * c[k];                                     // :173
+        if (G != G) G = 1.0;                              // :174-176
+    }
+    return F;
+}
+
 template <int D>
 __device__ __forceinline__ double bit_update_exact(double *Mt, const int *__restrict__ pos, double r)
 {
@@ -292,15 +332,15 @@ __device__ __forceinline__ double bit_update_exact(double *Mt, const int *__rest
     return bit_finish_exact<D>(Mt, at, c, r);
 }
 
-// Two bits of degree D at once (their 2 D positions are consecutive in pos): every row load is issued before
-// anything is computed.  Same arithmetic per bit; T0 / T1 are the posterior odds.
+// Two bits of degree D at once: every row load is issued before anything is computed.  Same arithmetic per bit;
+// T0 / T1 are the posterior odds.
 template <int D>
-__device__ __forceinline__ void bit_update_pair(double *Mt, const int *__restrict__ pos, double r, double &T0, double &T1)
+__device__ __forceinline__ void bit_update_pair(double *Mt, const int *__restrict__ pos0, const int *__restrict__ pos1, double r, double &T0, double &T1)
 {
     double c0[D], c1[D];
     size_t at0[D], at1[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) { at0[k] = (size_t)pos[k] * kTile; at1[k] = (size_t)pos[D + k] * kTile; }
+    for (int k = 0; k < D; ++k) { at0[k] = (size_t)pos0[k] * kTile; at1[k] = (size_t)pos1[k] * kTile; }
 #pragma unroll
     for (int k = 0; k < D; ++k) c0[k] = ldm(Mt + at0[k]);
 #pragma unroll

@@ -39,13 +39,37 @@
 #ifndef LDPC_TEAM_THREADS   // threads per member (experiments: 1024 = one 16-wave member per CU)
 #define LDPC_TEAM_THREADS 512
 #endif
+#ifndef LDPC_TEAM_ROWS_WIDE   // 1 = the rows-in-LDS instantiation may use 256 VGPRs (it runs one workgroup per CU)
+#define LDPC_TEAM_ROWS_WIDE 1
+#endif
 #ifndef LDPC_TEAM_SLEEP   // s_sleep argument between two polls of the arrival counter (x64 cycles)
 #define LDPC_TEAM_SLEEP 16
 #endif
 
 namespace ldpc {
 
+// Rows in LDS (instantiations with LROWS; regular graphs of the (8,4) bucket).  A member decodes the same share of
+// the checks AND of the bits in every iteration, so an edge whose check and whose bit are both its own is never touched
+// by anybody else: its message row can live in the member's LDS instead of the team's slot.  The host deals the bits
+// to the members by the graph (team_rows_build(): a bit goes to a member that owns one of its checks -- a quarter of
+// the edges become such) and gives the kernel the bit order, per check which of its edges are in LDS and from which
+// LDS row on, per edge of a bit its LDS row or -1.  150 KB of LDS hold R = 288 rows of 512 B per member: 14 % of a
+// tile of the n = 16384 code -- that much less traffic through the XCD's port, and EIGHT slots of the remaining
+// 27.5 MiB fit the Infinity Cache where eight of 32 MiB did not.
+// The two tables the sweeps read travel in the kernel's col_ptr / csc2csr arguments (const __restrict__: scalar loads;
+// read through a pointer in a struct they became vector loads, one wait each, and the variable sweep took twice as long):
+//   col_ptr  -> ctab [s][2]   per check: which of its edges are in LDS (bit k = edge k), the LDS row of the first of
+//                             them (they follow each other)
+//   csc2csr  -> vtab [n][16]  per position p of the dealt bit order: CSR rows of its 4 edges, their LDS rows or -1, the
+//                             bit (| 1 << 31 when one of its edges is in LDS), 7 words of padding
+constexpr int kTeamVtab = 16;
+struct TeamRows {
+    const int *lds_edge;        // [G][R]  CSR rows held by each member, -1 beyond its count (write-back before a hand-off)
+    int R;                      // LDS rows per member
+};
+
 struct TeamParams {
+    TeamRows rows;              // (LROWS instantiations only)
     int G;                      // workgroups per team
     int xcds;                   // XCDs that host teams (8; fewer = the blocks of the others leave at once: the slots in flight
                                 // are then 7/8 ... of the cache budget's) -- not in scatter mode
@@ -136,23 +160,74 @@ __device__ __forceinline__ int team_deal(unsigned int *counter, int lane)
     return __builtin_amdgcn_readfirstlane((int)t);
 }
 
+// Check / bit updates with some rows in LDS: generic pointers, the hardware routes each access.  Same arithmetic.
+template <int D, bool FIRST>
+__device__ __forceinline__ void check_update_mixed(double *M, double *L, unsigned int mask, double sigma, double r)
+{
+    double *ptr[D];
+    int nl = 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const bool in_lds = (mask >> k) & 1u;
+        ptr[k] = in_lds ? L + (size_t)nl * kTile : M + (size_t)k * kTile;
+        nl += in_lds ? 1 : 0;
+    }
+    double a[D], out[D];
+    if (FIRST) {
+        const double a0 = 2.0 / (1.0 + r) - 1.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) a[k] = a0;
+    } else {
+        double m[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) m[k] = *ptr[k];
+#pragma unroll
+        for (int k = 0; k < D; ++k) a[k] = 2.0 / (1.0 + m[k]) - 1.0;
+    }
+    check_compute_exact<D>(a, sigma, out);
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) *ptr[k] = out[k];
+}
+
+template <int D>
+__device__ __forceinline__ double bit_update_mixed(double *Mt, double *L, const int (&pos)[D], const int (&lrow)[D], double r)
+{
+    double *ptr[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const bool in_lds = lrow[k] >= 0;
+        ptr[k] = (in_lds ? L : Mt) + (size_t)(in_lds ? lrow[k] : pos[k]) * kTile;
+    }
+    double c[D], out[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) c[k] = *ptr[k];
+    const double F = bit_compute_exact<D>(c, r, out);
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) *ptr[k] = out[k];
+    return F;
+}
+
 // Register budget: teams run one or two workgroups per CU (team_geometry() on the host), so the narrow-degree
 // instantiation may have 128 VGPRs instead of the tile kernel's 80 (three workgroups per CU) -- under 80 it spilled.
-template <int DC, int DV, int THREADS>
+template <int DC, int DV, int THREADS, bool LROWS = false>
 constexpr int team_min_waves_per_simd()
 {
+    if (LROWS && LDPC_TEAM_ROWS_WIDE) return THREADS / 256;   // 156 KB of LDS: one workgroup per CU anyway
     return min_waves_per_simd<DC, DV, THREADS>() < 4 ? min_waves_per_simd<DC, DV, THREADS>() : 4;
 }
 
 // RESUMED: the pass over a packed level (the messages are in the packed tiles, every lane has iterations behind it)
 // is an instantiation of its own -- it shows under its own name in a profile, and the fresh pass loses the tests.
-template <int DC, int DV, bool WANT_LLR, int THREADS, bool RESUMED>
+template <int DC, int DV, bool WANT_LLR, int THREADS, bool RESUMED, bool LROWS = false>
 __global__ void
-__launch_bounds__(THREADS, (team_min_waves_per_simd<DC, DV, THREADS>()))
+__launch_bounds__(THREADS, (team_min_waves_per_simd<DC, DV, THREADS, LROWS>()))
 bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const int *__restrict__ edge_bit,
                const int *__restrict__ col_ptr, const int *__restrict__ csc2csr,
                const u64 *__restrict__ synmask, const u64 *__restrict__ nevermask)
 {
+    static_assert(!(LROWS && RESUMED), "packed tiles are decoded where they lie, all rows in global memory");
+    extern __shared__ double lds_rows[];   // LROWS: [tp.rows.R][64]
+    double *const Lr = lds_rows + (threadIdx.x & 63);
     __shared__ int sh_ok;
     __shared__ unsigned int sh_deal[2];   // chunks of this member's share dealt so far beyond the waves' first: check sweep, variable sweep
     __shared__ u64 sh_mism[THREADS / 64];
@@ -226,6 +301,30 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
             const int nch = (s + kTeamCheckChunk - 1) / kTeamCheckChunk;
             auto chunk = [&](int c) {
                 const int i1 = min(s, (c + 1) * kTeamCheckChunk);
+                if constexpr (LROWS) {
+                    // every check has the full degree (the host instantiates this only for such graphs); col_ptr is ctab.
+                    // (Pairs of checks / bits with rows in LDS loaded together measured slower, not faster.)
+                    for (int i = c * kTeamCheckChunk; i < i1; ++i) {
+                        const unsigned int mask = (unsigned int)col_ptr[2 * i];
+                        if (mask == 0u && kTeamCheckChunk == 2 && !first && tp.pairs && i + 1 < i1 && col_ptr[2 * i + 2] == 0) {
+                            const double sg0 = ((syn[i] >> lane) & 1ull) ? -1.0 : 1.0, sg1 = ((syn[i + 1] >> lane) & 1ull) ? -1.0 : 1.0;
+                            check_update_pair<DC>(Mt + (size_t)i * DC * kTile, Mt + (size_t)(i + 1) * DC * kTile, sg0, sg1);
+                            ++i;
+                            continue;
+                        }
+                        const double sigma = ((syn[i] >> lane) & 1ull) ? -1.0 : 1.0;
+                        double *const M = Mt + (size_t)i * DC * kTile;
+                        if (mask == 0u) {
+                            if (first) check_update_exact<DC, true>(M, sigma, r);
+                            else check_update_exact<DC, false>(M, sigma, r);
+                        } else {
+                            double *const L = Lr + (size_t)col_ptr[2 * i + 1] * kTile;
+                            if (first) check_update_mixed<DC, true>(M, L, mask, sigma, r);
+                            else check_update_mixed<DC, false>(M, L, mask, sigma, r);
+                        }
+                    }
+                    return;
+                }
                 if (kTeamCheckChunk == 2 && !first && tp.pairs && i1 == c * 2 + 2) {
                     // the usual case, two checks of the full degree: all 2 DC rows in flight at once
                     const int i = c * 2;
@@ -264,7 +363,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
         // ---- variable-node sweep  (:152-178).  Across XCDs a chunk is 16 consecutive bits, so that a 128-byte line of
         //      decision words has one writer; inside one XCD (one L2) 4 bits, for an even finish
         {
-            const int vb = one_xcd ? 4 : 16;
+            const int vb = (one_xcd || LROWS) ? 4 : 16;     // (LROWS: the host dealt the bits in chunks of 4)
             const int nch = (n + vb - 1) / vb;
             auto decide = [&](int j, double T) {
                 const u64 dec = __ballot(T >= 1.0);                                // :164-168
@@ -276,11 +375,39 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
             auto chunk = [&](int c) {
                 const int j1 = min(n, (c + 1) * vb);
                 int j = c * vb;
+                if constexpr (LROWS) {
+                    // positions of the dealt bit order; every bit has the full degree; csc2csr is vtab
+                    static_assert(DV == 4, "the table has four edges per position");
+                    for (int q = j; q < j1; ++q) {
+                        const int *const vt = csc2csr + (size_t)q * kTeamVtab;
+                        const int b = vt[8];
+                        if (b >= 0 && tp.pairs && q + 1 < j1) {
+                            const int b1 = vt[kTeamVtab + 8];
+                            if (b1 >= 0) {                      // neither has a row in LDS
+                                double T0, T1;
+                                bit_update_pair<DV>(Mt, vt, vt + kTeamVtab, r, T0, T1);
+                                decide(b, T0);
+                                decide(b1, T1);
+                                ++q;
+                                continue;
+                            }
+                        }
+                        if (b >= 0) {
+                            decide(b, bit_update_exact<DV>(Mt, vt, r));
+                        } else {
+                            typedef int v4i __attribute__((ext_vector_type(4)));
+                            const v4i P = *(const v4i *)vt, V = *(const v4i *)(vt + 4);   // (all eight words before any is looked at)
+                            const int pos[4] = {P.x, P.y, P.z, P.w}, lrow[4] = {V.x, V.y, V.z, V.w};
+                            decide(b & 0x7fffffff, bit_update_mixed<DV>(Mt, Lr, pos, lrow, r));
+                        }
+                    }
+                    return;
+                }
                 for (; tp.pairs && j + 1 < j1; j += 2) {           // two bits of the full degree: all 2 DV rows in flight at once
                     const int c0 = col_ptr[j], c1 = col_ptr[j + 1], c2 = col_ptr[j + 2];
                     if (c1 - c0 != DV || c2 - c1 != DV) break;
                     double T0, T1;
-                    bit_update_pair<DV>(Mt, csc2csr + c0, r, T0, T1);
+                    bit_update_pair<DV>(Mt, csc2csr + c0, csc2csr + c1, r, T0, T1);
                     decide(j, T0);
                     decide(j + 1, T1);
                 }
@@ -345,6 +472,13 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
         // few stragglers left: hand them, with their messages, to the next level (decided alike by every member;
         // rank 0 reserves the room and tells the others through the team's control block, then all copy)
         if (p.defer_thresh != 0 && active != 0 && it >= p.defer_min_iter && (int)__popcll(active) <= p.defer_thresh) {
+            if (LROWS) {   // the rows this member keeps in LDS go back to their places in the slot: the copy below reads the slot
+                const int *const le = tp.rows.lds_edge + (size_t)rank * tp.rows.R;
+                for (int q = w; q < tp.rows.R; q += W) {
+                    const int e = le[q];
+                    if (e >= 0) Mt[(size_t)e * kTile] = Lr[(size_t)q * kTile];
+                }
+            }
             if (rank == 0 && threadIdx.x == 0)
                 __hip_atomic_store(ctr + 33, defer_reserve(cd->defer_count, (unsigned)__popcll(active), cd->next_cap) + 1u,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // base + 1; a full level (~0u) is told as 0

@@ -303,6 +303,12 @@ struct ldpc_bp_decoder {
     DevBuf node_msg;          // [workgroups][nnz] double, the node-parallel kernel's message slots
     // team kernel (bp_team_kernels.hpp): arrival counters + mismatch words, and the host-mapped fault word
     DevBuf team_ws, team_ws_lvl[2];   // control blocks of the team kernel: level 0 / the passes over the packed levels
+    // rows in LDS (bp_team_kernels.hpp, TeamRows): regular graphs of the (8,4) bucket keep the host copy of csc2csr;
+    // the tables are built for the member count of the first persistent launch (team_rows_build())
+    std::vector<int> h_csc2csr;
+    bool team_rows_on = true;         // LDPC_TEAM_ROWS at create (0 = every row in the slot)
+    int rows_G = 0, rows_R = 0;       // what the tables below were built for: members per team, LDS rows per member
+    DevBuf rows_ctab, rows_vtab, rows_lds_edge;
     unsigned int *team_fault = nullptr, *team_fault_dev = nullptr;
     int team_max = 32;        // workgroups per tile at most (LDPC_TEAM_MAX; 1 = team kernel off)
     bool team_max_set = false;   // ... given by the environment: no automatic 64 for batches of <= 4 tiles
@@ -368,7 +374,8 @@ struct ldpc_bp_decoder {
     ~ldpc_bp_decoder()
     {
         DevBuf *all[] = {&row_ptr, &edge_bit, &col_ptr, &csc2csr, &msg, &ctrl, &synmask, &nevermask,
-                         &errmask, &finmask, &llr_t, &st_all, &node_msg, &done_ctr, &team_ws, &team_ws_lvl[0], &team_ws_lvl[1], &cold};
+                         &errmask, &finmask, &llr_t, &st_all, &node_msg, &done_ctr, &team_ws, &team_ws_lvl[0], &team_ws_lvl[1], &cold,
+                         &rows_ctab, &rows_vtab, &rows_lds_edge};
         for (DevBuf *b : all) b->release();
         for (int l = 0; l < 2; ++l)
             for (DevBuf *b : {&lvl_state[l], &lvl_list[l], &lvl_it[l], &lvl_syn[l], &lvl_never[l], &lvl_err[l], &lvl_fin[l], &lvl_llr[l]}) b->release();
@@ -677,6 +684,9 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
         return st;
     }
 
+    if (d->max_cdeg == 8 && d->max_bdeg == 4 && nnz == 8 * s && nnz == 4 * n && nnz > 0) d->h_csc2csr = csc2csr;   // every check 8, every bit 4
+    if (const char *e = std::getenv("LDPC_TEAM_ROWS")) d->team_rows_on = std::atoi(e) != 0;
+
     // geometry: waves per tile (fixed by the caller or chosen per batch) and the workspace budget
     int wpt = options ? options->waves_per_tile : 0;
     if (wpt != 0 && wpt != 4 && wpt != 8 && wpt != 16) {
@@ -834,10 +844,10 @@ static size_t team_lds_bytes()
     return v;
 }
 
-static hipError_t launch_team_grid(ldpc_bp_decoder *d, team_kernel_t tk, int grid, void **args, hipStream_t stream)
+static hipError_t launch_team_grid(ldpc_bp_decoder *d, team_kernel_t tk, int grid, void **args, hipStream_t stream, size_t lds)
 {
     static const bool coop = std::getenv("LDPC_TEAM_COOP_LAUNCH") != nullptr;
-    if (coop) return hipLaunchCooperativeKernel((const void *)tk, dim3((unsigned)grid), dim3(LDPC_TEAM_THREADS), args, (unsigned)team_lds_bytes(), stream);
+    if (coop) return hipLaunchCooperativeKernel((const void *)tk, dim3((unsigned)grid), dim3(LDPC_TEAM_THREADS), args, (unsigned)lds, stream);
     std::lock_guard<std::mutex> lk(g_team_mu);
     hipEvent_t *gev = (d->device >= 0 && d->device < 64) ? &g_team_ev[d->device] : nullptr;
     if (gev) {
@@ -848,7 +858,7 @@ static hipError_t launch_team_grid(ldpc_bp_decoder *d, team_kernel_t tk, int gri
             if (w != hipSuccess) return w;
         }
     }
-    hipError_t e = hipLaunchKernel((const void *)tk, dim3((unsigned)grid), dim3(LDPC_TEAM_THREADS), args, team_lds_bytes(), stream);
+    hipError_t e = hipLaunchKernel((const void *)tk, dim3((unsigned)grid), dim3(LDPC_TEAM_THREADS), args, lds, stream);
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess && gev && *gev) e = hipEventRecord(*gev, stream);
     return e;
@@ -887,12 +897,107 @@ static bool team_geometry(ldpc_bp_decoder *d, bool want_llr, int *per_xcd, int *
     return *per_xcd >= 1;
 }
 
+// LDS rows a member of a persistent team can hold: 312 x 512 B = 156 KiB of the 160 KiB (the kernel's own few words beside)
+constexpr int kTeamRowsMax = 312;
+
+static bool team_rows_possible(const ldpc_bp_decoder *d) { return d->team_rows_on && !d->h_csc2csr.empty() && !d->wpt_fixed; }
+
+// What a member is expected to hold (a bit dealt to a member that owns one of its 4 checks: a quarter of the edges).
+static int team_rows_expected(const ldpc_bp_decoder *d, int G)
+{
+    return team_rows_possible(d) ? (int)std::min<int64_t>(kTeamRowsMax, d->nnz / 4 / std::max(G, 1)) : 0;
+}
+
+// The tables of TeamRows for teams of G members (kept until another G is asked for).  Checks are dealt as the kernel
+// deals them -- chunk c of 2 checks to member c % G -- and so are the POSITIONS of the bit order, in chunks of 4; the bits
+// are put into positions by the graph: a bit goes to the member, among the owners of its four checks, that has most
+// room left (any member once those are full).  Every edge whose check and bit then share the owner is a candidate; up
+// to kTeamRowsMax per member get a row in its LDS, numbered in check order.
+static ldpc_status team_rows_build(ldpc_bp_decoder *d, int G)
+{
+    if (d->rows_G == G) return LDPC_OK;
+    const int n = (int)d->n, s = (int)d->s, nnz = (int)d->nnz;
+    const std::vector<int> &c2r = d->h_csc2csr;
+    auto check_owner = [&](int i) { return (i / kTeamCheckChunk) % G; };
+    std::vector<int> cap((size_t)G, 0), member_of_bit((size_t)n, -1);
+    for (int p = 0; p < n; ++p) cap[(size_t)((p / 4) % G)]++;
+    std::vector<int> room = cap;
+    for (int j = 0; j < n; ++j) {
+        int best = -1;
+        for (int k = 0; k < 4; ++k) {
+            const int m = check_owner(c2r[(size_t)4 * j + k] / 8);
+            if (room[(size_t)m] > 0 && (best < 0 || room[(size_t)m] > room[(size_t)best])) best = m;
+        }
+        if (best >= 0) { member_of_bit[(size_t)j] = best; room[(size_t)best]--; }
+    }
+    for (int j = 0, m = 0; j < n; ++j) {
+        if (member_of_bit[(size_t)j] >= 0) continue;
+        while (room[(size_t)m] == 0) ++m;
+        member_of_bit[(size_t)j] = m; room[(size_t)m]--;
+    }
+    // positions: member m's bits, in ascending order, fill its positions in ascending order
+    std::vector<std::vector<int>> bits_of((size_t)G);
+    for (int j = 0; j < n; ++j) bits_of[(size_t)member_of_bit[(size_t)j]].push_back(j);
+    std::vector<int> bit((size_t)n), taken((size_t)G, 0);
+    for (int p = 0; p < n; ++p) { const int m = (p / 4) % G; bit[(size_t)p] = bits_of[(size_t)m][(size_t)taken[(size_t)m]++]; }
+    // candidates per member, in check order; the first R of each get LDS rows
+    std::vector<std::vector<int>> cand((size_t)G);
+    for (int j = 0; j < n; ++j)
+        for (int k = 0; k < 4; ++k) {
+            const int q = c2r[(size_t)4 * j + k];
+            if (check_owner(q / 8) == member_of_bit[(size_t)j]) cand[(size_t)member_of_bit[(size_t)j]].push_back(q);
+        }
+    int R = 0;
+    for (auto &v : cand) { std::sort(v.begin(), v.end()); if ((int)v.size() > kTeamRowsMax) v.resize(kTeamRowsMax); R = std::max(R, (int)v.size()); }
+    R = std::max(R, 1);
+    std::vector<int> lds_row_of((size_t)nnz, -1), lds_edge((size_t)G * R, -1), cbase((size_t)s, 0);
+    std::vector<unsigned> cmask((size_t)s, 0u);
+    for (int m = 0; m < G; ++m)
+        for (int r = 0; r < (int)cand[(size_t)m].size(); ++r) {
+            const int q = cand[(size_t)m][(size_t)r], i = q / 8;
+            lds_row_of[(size_t)q] = r;
+            lds_edge[(size_t)m * R + r] = q;
+            if (cmask[(size_t)i] == 0u) cbase[(size_t)i] = r;   // (ascending q: the check's LDS edges follow each other)
+            cmask[(size_t)i] |= 1u << (q - 8 * i);
+        }
+    std::vector<int> vtab((size_t)n * kTeamVtab, 0), ctab((size_t)s * 2);
+    for (int i = 0; i < s; ++i) { ctab[(size_t)2 * i] = (int)cmask[(size_t)i]; ctab[(size_t)2 * i + 1] = cbase[(size_t)i]; }
+    for (int p = 0; p < n; ++p) {
+        const int j = bit[(size_t)p];
+        bool any = false;
+        for (int k = 0; k < 4; ++k) {
+            const int q = c2r[(size_t)4 * j + k];
+            vtab[(size_t)p * kTeamVtab + k] = q;
+            vtab[(size_t)p * kTeamVtab + 4 + k] = lds_row_of[(size_t)q];
+            any = any || lds_row_of[(size_t)q] >= 0;
+        }
+        vtab[(size_t)p * kTeamVtab + 8] = any ? (j | (int)0x80000000u) : j;
+    }
+    auto up = [&](DevBuf &b, const void *src, size_t bytes) -> ldpc_status {
+        ldpc_status r = b.ensure(std::max<size_t>(bytes, 4));
+        if (r != LDPC_OK) return r;
+        if (hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return fail(LDPC_ERR_HIP, "hipMemcpy of the team row tables failed"); }
+        return LDPC_OK;
+    };
+    ldpc_status st;
+    (void)hipDeviceSynchronize();   // (a launch that still reads the tables of another G)
+    if ((st = up(d->rows_ctab, ctab.data(), ctab.size() * 4)) != LDPC_OK || (st = up(d->rows_vtab, vtab.data(), vtab.size() * 4)) != LDPC_OK ||
+        (st = up(d->rows_lds_edge, lds_edge.data(), lds_edge.size() * 4)) != LDPC_OK)
+        return st;
+    d->rows_G = G; d->rows_R = R;
+    if (std::getenv("LDPC_TEAM_DEBUG")) {
+        size_t tot = 0; for (auto &v : cand) tot += v.size();
+        std::fprintf(stderr, "[ldpc] team rows: %d members, %d LDS rows each at most, %zu of %d edges in LDS\n", G, R, tot, nnz);
+    }
+    return LDPC_OK;
+}
+
 // Persistent teams whose message slots in flight stay inside the cache budget (LDPC_TEAM_CACHE_MIB, default 240 of
 // the Infinity Cache's 256 MiB): how many XCDs host teams (8, 7 or 6), how many teams each, how many members a
 // team -- the combination that gives most workgroups a tile.  For the n = 16384 code (32 MiB a slot) that is SEVEN
 // teams of 32: with an eighth the slots fill the cache to the brim and every team is a fifth slower (full batch,
 // 50 iterations: 1111 ms on 8 XCDs, 1011 ms on 7, 1158 ms on 6).  false: nothing fits.
-static bool team_fit(const ldpc_bp_decoder *d, int per_xcd, int gcap, int64_t ntiles, int *xcds, int *tpx, int *G)
+static bool team_fit(const ldpc_bp_decoder *d, int per_xcd, int gcap, int64_t ntiles, bool rows, int *xcds, int *tpx, int *G)
 {
     const size_t state = std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double);
     const size_t cache = d->team_cache;
@@ -901,10 +1006,12 @@ static bool team_fit(const ldpc_bp_decoder *d, int per_xcd, int gcap, int64_t nt
     const int x_hi = d->team_xcds ? d->team_xcds : 8, x_lo = d->team_xcds ? d->team_xcds : 6;
     for (int x = x_hi; x >= x_lo; --x)
         for (int t = 1; t <= per_xcd / 3; ++t) {
-            if ((size_t)x * (size_t)t * state > cache) break;
+            if ((size_t)x * (size_t)t * (state - (rows ? state / 4 : 0)) > cache) break;   // (a quarter at most can be in LDS)
             if (t > 1 && (int64_t)x * (t - 1) >= ntiles) break;            // no more teams than tiles
             const int g = std::min(gcap, per_xcd / t);
             if (g < 3) break;
+            // rows that the members keep in LDS are not in the cache
+            if ((size_t)x * (size_t)t * (state - (rows ? (size_t)g * team_rows_expected(d, g) * kTile * sizeof(double) : 0)) > cache) continue;
             const int64_t w = std::min<int64_t>((int64_t)x * t, ntiles) * g;   // workgroups with a tile
             if (w > best) { best = w; *xcds = x; *tpx = t; *G = g; }
         }
@@ -925,6 +1032,7 @@ struct TeamPlan {
     int grid = 0;         // workgroups to launch
     int xcds = 8, tpx = 0;   // XCDs that host teams, teams per XCD (not in scatter mode)
     bool scatter = false;
+    bool rows = false;       // members keep the rows that only they touch in LDS (TeamRows)
 };
 
 static TeamPlan team_plan(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
@@ -948,7 +1056,9 @@ static TeamPlan team_plan(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
         const size_t state = std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double);
         int x = 8, t = (int)need, g = 0;
         const bool one_round = d->team_cache && !d->team_xcds && (size_t)8 * (size_t)need * state <= d->team_cache + d->team_cache / 4;
-        if (one_round || !team_fit(d, per_xcd, gcap, ntiles, &x, &t, &g)) {
+        // (the budget is applied to whole slots although members keep up to 15 % of the rows in LDS: eight teams of the
+        // C3 code -- 8 x 27 MiB with the rows in LDS -- measured 981 ms for the full batch, seven 957)
+        if (one_round || !team_fit(d, per_xcd, gcap, ntiles, false, &x, &t, &g)) {
             if (!one_round && ntiles > d->num_cus) return pl;
             x = 8; t = (int)need;
             g = (int)std::min<int64_t>(gcap, (int64_t)per_xcd / t);
@@ -959,6 +1069,7 @@ static TeamPlan team_plan(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
     }
     if (team < 3) return pl;   // two workgroups per tile measured no better than the tile kernel's one of 16 waves
     pl.G = (int)std::min<int64_t>(team, kTeamMaxMembers);
+    pl.rows = !pl.scatter && team_rows_possible(d) && team_rows_expected(d, pl.G) >= 16;
     pl.nteams = (int)nteams;
     pl.grid = pl.scatter ? pl.nteams * pl.G : 8 * pl.G * pl.tpx;
     return pl;
@@ -1296,7 +1407,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             // (team_fit()); they take whatever the level holds.  Nothing fits (LDPC_TEAM_CACHE_MIB=0, large graphs):
             // one tile per team, up to as many tiles as leave every team 3 members.
             int tiles_max, x = 8, t = 1, g = 3;
-            if (team_fit(d, L.t_per_xcd, L.t_gcap, L.cap_tiles, &x, &t, &g)) {
+            if (team_fit(d, L.t_per_xcd, L.t_gcap, L.cap_tiles, false, &x, &t, &g)) {
                 tiles_max = L.cap_tiles;
             } else {
                 x = 8; t = L.t_per_xcd / 3; g = 3;           // (the members of surplus teams are idle: round 1's geometry in fixed form)
@@ -1400,9 +1511,24 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         tp.scatter = team_scatter ? 1 : 0;
         tp.inject_fault = d->inject_fault ? 1 : 0;   // (tests)
         team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr);
+        size_t team_lds = team_lds_bytes();
+        const int *t_col = a_col, *t_c2r = a_c2r;
+        if (plan.rows && !team_scatter && team_rows_build(d, team) == LDPC_OK) {
+            // rows that only one member touches live in its LDS (TeamRows)
+            team_kernel_t tkr = pick_team_kernel_rows(want_llr);
+            const size_t need = (size_t)d->rows_R * kTile * sizeof(double);
+            int occ_rows = 0;
+            if (d->prepare_kernel((const void *)tkr, LDPC_TEAM_THREADS, need, &occ_rows) == LDPC_OK && occ_rows >= 1) {
+                tk = tkr; team_lds = need;
+                tp.rows.lds_edge = (const int *)d->rows_lds_edge.p;
+                tp.rows.R = d->rows_R;
+                t_col = (const int *)d->rows_ctab.p;     // (this instantiation reads its tables through these two arguments)
+                t_c2r = (const int *)d->rows_vtab.p;
+            }
+        }
         const u64 *a_syn = (const u64 *)d->synmask.p, *a_nev = (const u64 *)d->nevermask.p;
-        void *args[] = {&p, &tp, &a_row, &a_eb, &a_col, &a_c2r, &a_syn, &a_nev};
-        const hipError_t te = launch_team_grid(d, tk, team_grid, args, stream);
+        void *args[] = {&p, &tp, &a_row, &a_eb, &t_col, &t_c2r, &a_syn, &a_nev};
+        const hipError_t te = launch_team_grid(d, tk, team_grid, args, stream, team_lds);
         if (te != hipSuccess) {
             // a team grid the runtime refuses must not fail the call: the tile kernel decodes the batch (one
             // workgroup per tile, same results), and teams stay off for this decoder
@@ -1479,7 +1605,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             tp.count_max = L.team_cap;
             team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr, true);
             void *args[] = {&q3, &tp, &a_row, &a_eb, &a_col, &a_c2r, &l_syn, &l_nev};
-            HIP_TRY(launch_team_grid(d, tk, L.t_grid, args, stream));
+            HIP_TRY(launch_team_grid(d, tk, L.t_grid, args, stream, team_lds_bytes()));
         }
     }
     HIP_TRY(hipEventRecord(ev[2], stream));

@@ -25,7 +25,17 @@ team_kernel_t team_pick_dc(int dc, int dv)
 #ifndef LDPC_TEAM_RESUMED
 #define LDPC_TEAM_RESUMED 0
 #endif
-#if LDPC_TEAM_RESUMED
+#ifndef LDPC_TEAM_ROWS
+#define LDPC_TEAM_ROWS 0
+#endif
+#if LDPC_TEAM_ROWS
+// (a third compilation: -DLDPC_TEAM_ROWS=1) rows in LDS: regular graphs of the (8,4) bucket, fresh tiles
+team_kernel_t pick_team_kernel_rows(bool llr)
+{
+    if (llr) return bp_team_kernel<8, 4, true, LDPC_TEAM_THREADS, false, true>;
+    return bp_team_kernel<8, 4, false, LDPC_TEAM_THREADS, false, true>;
+}
+#elif LDPC_TEAM_RESUMED
 team_kernel_t pick_team_kernel_resumed(int dc, int dv, bool llr)
 {
     return llr ? team_pick_dc<true, true>(dc, dv) : team_pick_dc<false, true>(dc, dv);

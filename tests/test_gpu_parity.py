@@ -236,6 +236,36 @@ def test_team_kernel_is_bit_identical_to_the_tile_kernel(ldpc, gpu, B, per, scat
         assert torch.equal(a, b), f"{nm} differ between the tile and the team kernel"
 
 
+@pytest.mark.parametrize("per", [0.03, 0.065, 0.10])
+def test_team_rows_in_lds_change_nothing(ldpc, gpu, per, monkeypatch):
+    """(4,8)-regular graphs: the members of a persistent team keep the message rows that only they touch in LDS (a bit is
+    dealt to a member that owns one of its checks; bp_team_kernels.hpp TeamRows).  With the rows in LDS (default), with
+    every row in the slot (LDPC_TEAM_ROWS=0) and through the tile kernel: the same bits, LLRs included -- at an error
+    rate where tiles finish early, one where they hand stragglers on (the rows in LDS are written back for that) and
+    one where nothing converges."""
+    import torch
+
+    n, B = 4096, 3000
+    H = ldpc.codes.parity_check_csc(n, 8, 4)
+    syn = torch.from_numpy(ldpc.codes.syndromes_of(H, ldpc.codes.random_errors(n, B, per, seed=77))).cuda()
+    res = []
+    for variant, rows in ((4, "1"), (4, "0"), (1, "1")):
+        monkeypatch.setenv("LDPC_TEAM_ROWS", rows)
+        dec = ldpc.BeliefPropagationDecoder(H, per, 30, kernel_variant=variant)
+        err = torch.empty((B, n), dtype=torch.uint8, device="cuda")
+        conv = torch.empty(B, dtype=torch.uint8, device="cuda")
+        llr = torch.full((B, n), float("nan"), dtype=torch.float64, device="cuda")
+        its = torch.empty(B, dtype=torch.int32, device="cuda")
+        dec.decode_batch_device(syn, err, conv, llr, its)
+        dec.decode_batch_device(syn, err, conv, None, its)       # ... and the instantiation without LLRs
+        torch.cuda.synchronize()
+        assert dec.info().last_kernel == variant
+        res.append((err, conv, its, llr.view(torch.int64)))
+        dec.close()
+    for other in res[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(res[0], other))
+
+
 def test_auto_dispatch_picks_the_kernel_by_code_and_batch(ldpc, gpu, monkeypatch):
     """kernel_variant 0: LDS-resident kernel for a code that fits the LDS; node-parallel kernel with the messages
     in LDS at every batch size for a code whose messages alone fit it (n = 4096); beyond that the node-parallel

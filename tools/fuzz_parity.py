@@ -66,7 +66,7 @@ while time.time() - t0 < budget:
         # hand-off levels (read at create): thresholds of fresh / level-1 tiles, tiny level capacities (levels fill
         # up and tiles must carry on), how many stragglers the node kernel finishes
         for k in ("LDPC_DEFER_T0", "LDPC_DEFER_T1", "LDPC_DEFER_CAP_TILES", "LDPC_NODE_TAKE_MAX", "LDPC_TEAM_CACHE_KIB",
-                  "LDPC_TEAM_DYNAMIC", "LDPC_TEAM_PAIRS"):
+                  "LDPC_TEAM_DYNAMIC", "LDPC_TEAM_PAIRS", "LDPC_TEAM_ROWS"):
             os.environ.pop(k, None)
         # teams (read at create): a small cache budget makes them persistent on these small graphs (a team takes tile
         # after tile in its own slot); how a member's waves share its chunks; nodes loaded in pairs or singly
@@ -76,6 +76,8 @@ while time.time() - t0 < budget:
             os.environ["LDPC_TEAM_DYNAMIC"] = str(int(rng.integers(0, 2)))
         if rng.random() < 0.5:
             os.environ["LDPC_TEAM_PAIRS"] = str(int(rng.integers(0, 2)))
+        if rng.random() < 0.3:
+            os.environ["LDPC_TEAM_ROWS"] = "0"      # (8,4)-regular graphs: no rows in LDS
         if rng.random() < 0.7:
             os.environ["LDPC_DEFER_T0"] = str(int(rng.choice([4, 16, 32, 48])))
             os.environ["LDPC_DEFER_T1"] = str(int(rng.choice([0, 8, 16, 40])))

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import ldpcdecoders_jl_amd as ldpc
 
-n, per = 16384, 0.10
+n, per = int(os.environ.get("N", "16384")), 0.10
 H = ldpc.codes.parity_check_csc(n, 8, 4)
 variant = int(os.environ.get("VARIANT", "4"))
 dec = ldpc.BeliefPropagationDecoder(H, per, 50, kernel_variant=variant)
