@@ -1513,7 +1513,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr);
         size_t team_lds = team_lds_bytes();
         const int *t_col = a_col, *t_c2r = a_c2r;
-        if (plan.rows && !team_scatter && team_rows_build(d, team) == LDPC_OK) {
+        if (plan.rows && team_rows_build(d, team) == LDPC_OK) {   // (also with LDPC_TEAM_SCATTER: members over all XCDs, a test)
             // rows that only one member touches live in its LDS (TeamRows)
             team_kernel_t tkr = pick_team_kernel_rows(want_llr);
             const size_t need = (size_t)d->rows_R * kTile * sizeof(double);
