@@ -1,4 +1,5 @@
-// bp_team_kernels.hpp -- medium batches on Tanner graphs beyond the LDS: several workgroups per tile.
+// bp_team_kernels.hpp -- Tanner graphs beyond the LDS: several workgroups per tile.  Built in round 1 for medium
+// batches; with persistent teams (below) the kernel of the full C3 / C4 batches and of the headline number.
 //
 // The tile kernel (bp_kernels.hpp) gives one 64-syndrome tile to ONE workgroup: a batch of a few
 // thousand syndromes of the n = 16384 code is 32 ... 256 tiles, each swept by one CU at one CU's
@@ -15,17 +16,18 @@
 //
 // because per-XCD L2s are not coherent with each other and a CU's L1 is never refreshed by another
 // CU's stores.  All G workgroups of a team must be resident at once: the host launches
-// nteams x G <= 2 workgroups per CU (checked against the kernel's residency, never two team grids at
+// nteams x G workgroups, at most one per CU (checked against the kernel's residency, never two team grids at
 // once) and every poll is bounded -- a team that waits longer than ~10 s raises a fault word
 // (host-mapped, reported by the next call on the handle) and all its members leave, so a lost
 // workgroup can never hang the GPU.
 //
 // Teams are PERSISTENT: team t starts on tile t and then takes tiles from a queue until the batch is
 // done, always in ITS OWN message slot (iteration 1 reads nothing, so a slot needs no clearing between
-// tiles).  With 8 teams -- one per XCD -- the messages in flight are 8 slots: for the n = 16384 code
-// 8 x 32 MiB = 256 MiB, which the 256 MiB Infinity Cache keeps (tools/mall_probe.hip: the in-place sweeps
-// run at 8.8 TB/s on a working set of <= 256 MiB against 5.1 ... 5.6 TB/s from HBM).  The tile kernel
-// cannot do that: one workgroup per tile means 768 tiles = 24 GiB in flight.
+// tiles).  With one team per XCD the messages in flight are 7 or 8 slots: for the n = 16384 code 7 x 32 MiB, which
+// the 256 MiB Infinity Cache keeps (tools/mall_probe.hip: the in-place sweeps run at 8.8 TB/s on a working set of
+// <= 256 MiB against 5.1 ... 5.6 TB/s from HBM; the host plans the teams inside a budget of 240 MiB, team_fit() --
+// eight slots of 32 MiB fill the cache to the brim and every team is a fifth slower).  The tile kernel cannot do
+// that: one workgroup per tile means 768 tiles = 24 GiB in flight.
 //
 // Within a sweep a member has a share of the node chunks (every G-th chunk), and its waves take the chunks of
 // that share one after the other from a counter in LDS (a wave's first chunk is its by right): the 8 waves of
@@ -53,9 +55,8 @@ namespace ldpc {
 // by anybody else: its message row can live in the member's LDS instead of the team's slot.  The host deals the bits
 // to the members by the graph (team_rows_build(): a bit goes to a member that owns one of its checks -- a quarter of
 // the edges become such) and gives the kernel the bit order, per check which of its edges are in LDS and from which
-// LDS row on, per edge of a bit its LDS row or -1.  150 KB of LDS hold R = 288 rows of 512 B per member: 14 % of a
-// tile of the n = 16384 code -- that much less traffic through the XCD's port, and EIGHT slots of the remaining
-// 27.5 MiB fit the Infinity Cache where eight of 32 MiB did not.
+// LDS row on, per edge of a bit its LDS row or -1.  156 KiB of LDS hold R = 312 rows of 512 B per member: 15 % of a
+// tile of the n = 16384 code -- that much less traffic through the XCD's port (full batch 1.013 -> 0.957 s).
 // The two tables the sweeps read travel in the kernel's col_ptr / csc2csr arguments (const __restrict__: scalar loads;
 // read through a pointer in a struct they became vector loads, one wait each, and the variable sweep took twice as long):
 //   col_ptr  -> ctab [s][2]   per check: which of its edges are in LDS (bit k = edge k), the LDS row of the first of
@@ -71,8 +72,8 @@ struct TeamRows {
 struct TeamParams {
     TeamRows rows;              // (LROWS instantiations only)
     int G;                      // workgroups per team
-    int xcds;                   // XCDs that host teams (8; fewer = the blocks of the others leave at once: the slots in flight
-                                // are then 7/8 ... of the cache budget's) -- not in scatter mode
+    int xcds;                   // XCDs that host teams (8; fewer = the blocks of the others leave at once, and so many fewer
+                                // slots are in flight) -- not in scatter mode
     int nteams;                 // teams launched; team t works in message slot t (fresh tiles) and starts on tile t
     int pairs;                  // 1 = two nodes of the full degree are loaded together (twice the bytes in flight per wave)
     int dynamic;                // 1 = the waves of a member take the chunks of its share from a counter in LDS; 0 = every W-th
