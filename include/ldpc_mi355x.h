@@ -74,8 +74,9 @@ typedef struct ldpc_bp_options {
                                  model picks between the node-parallel kernel and the team kernel (several
                                  workgroups per 64-syndrome tile) for small batches; the team kernel takes the larger
                                  ones with PERSISTENT teams (a team decodes tile after tile in its own message slot)
-                                 when a chip-wide set of slots fits the 256 MiB Infinity Cache (n <= ~16384 for
-                                 (4,8)-regular codes), else with one team per tile up to one tile per CU; the
+                                 when a chip-wide set of slots fits the 256 MiB Infinity Cache or is at most about
+                                 twice its size (n <= ~32768 for (4,8)-regular codes), else with one team per tile
+                                 up to one tile per CU; the
                                  HBM-streaming tile kernel (one persistent workgroup per tile) takes the rest.
                                  1 = force streaming; 2 = force LDS-resident (error if it does not fit);
                                  3 = force node-parallel; 4 = team kernel wherever it applies, streaming otherwise

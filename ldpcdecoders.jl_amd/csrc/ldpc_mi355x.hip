@@ -996,7 +996,7 @@ static ldpc_status team_rows_build(ldpc_bp_decoder *d, int G)
 // the Infinity Cache's 256 MiB): how many XCDs host teams (8, 7 or 6), how many teams each, how many members a
 // team -- the combination that gives most workgroups a tile.  For the n = 16384 code (32 MiB a slot) that is SEVEN
 // teams of 32: with an eighth the slots fill the cache to the brim and every team is a fifth slower (full batch,
-// 50 iterations: 1111 ms on 8 XCDs, 1011 ms on 7, 1158 ms on 6).  false: nothing fits.
+// 50 iterations: 1111 ms on 8 XCDs, 1011 ms on 7, 1158 ms on 6).  false: nothing fits, not even the second tier below.
 static bool team_fit(const ldpc_bp_decoder *d, int per_xcd, int gcap, int64_t ntiles, bool rows, int *xcds, int *tpx, int *G)
 {
     const size_t state = std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double);
@@ -1015,7 +1015,16 @@ static bool team_fit(const ldpc_bp_decoder *d, int per_xcd, int gcap, int64_t nt
             const int64_t w = std::min<int64_t>((int64_t)x * t, ntiles) * g;   // workgroups with a tile
             if (w > best) { best = w; *xcds = x; *tpx = t; *G = g; }
         }
-    return best > 0;
+    if (best > 0) return true;
+    // Slots up to 2.2 x the budget: one team per XCD still pays -- the slots are partly cached, and a team streams what is
+    // not as well as three tile-kernel workgroups per CU do (n = 32768, 64 MiB a slot, 50 iterations: 16,384 syndromes
+    // 575 ms against 651 ms, 49,152 syndromes 1.76 s against 1.80 s -- with 8 slots instead of 768).  Beyond that
+    // (n = 65536) the two are equal and the tile kernel stays.
+    if (!d->team_xcds && (size_t)8 * state <= cache / 5 * 11 && std::min(gcap, per_xcd) >= 3) {
+        *xcds = 8; *tpx = 1; *G = std::min(gcap, per_xcd);
+        return true;
+    }
+    return false;
 }
 
 // How a batch of fresh tiles is dealt to teams (bp_team_kernels.hpp).  G = 1: no teams for it.

@@ -270,7 +270,7 @@ def test_auto_dispatch_picks_the_kernel_by_code_and_batch(ldpc, gpu, monkeypatch
     """kernel_variant 0: LDS-resident kernel for a code that fits the LDS; node-parallel kernel with the messages
     in LDS at every batch size for a code whose messages alone fit it (n = 4096); beyond that the node-parallel
     kernel below one tile, the team kernel from there on -- persistent teams whose message slots stay in the
-    Infinity Cache -- and the tile kernel for graphs whose slots would not fit it (n = 32768 at 8 teams)
+    Infinity Cache (or are at most 2.2 x its budget: n = 32768) -- and the tile kernel beyond that (n = 65536)
     (ldpc_bp_info.last_kernel, numbered like kernel_variant).  Results against the oracle on a sample."""
     small = ldpc.codes.parity_check_csc(1008, 6, 3)
     big = ldpc.codes.parity_check_csc(4096, 8, 4)
