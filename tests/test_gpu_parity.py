@@ -291,6 +291,19 @@ def test_auto_dispatch_picks_the_kernel_by_code_and_batch(ldpc, gpu, monkeypatch
         k = min(B, 200)
         oerr, oconv, _, oits = oc.batchdecode(syn[:k])
         assert np.array_equal(err[:k], oerr) and np.array_equal(conv[:k], oconv) and np.array_equal(its[:k], oits)
+    d_big.close()
+    # n = 32768: eight message slots are 512 MiB, twice the Infinity Cache -- still one persistent team per XCD
+    # (the second tier of the team plan), 19 tiles for 8 teams of 32
+    huge = ldpc.codes.parity_check_csc(32768, 8, 4)
+    d_huge = ldpc.BeliefPropagationDecoder(huge, 0.03, 30)
+    syn = ldpc.codes.syndromes_of(huge, ldpc.codes.random_errors(32768, 1200, 0.03, seed=5))
+    err, conv, _, its = d_huge.decode_batch_host(syn, want_iters=True)
+    info = d_huge.info()
+    assert info.last_kernel == 4 and info.last_team_size == 32 and info.resident_tiles == 8 * 32, (info.last_kernel, info.last_team_size, info.resident_tiles)
+    oc = BPOracle(csc=(huge.indptr, huge.indices), shape=huge.shape, per=0.03, max_iters=30)
+    oerr, oconv, _, oits = oc.batchdecode(syn[:100])
+    assert np.array_equal(err[:100], oerr) and np.array_equal(conv[:100], oconv) and np.array_equal(its[:100], oits)
+    d_huge.close()
 
 
 def test_device_resident_entry(ldpc, gpu):
