@@ -810,7 +810,8 @@ ldpc_status ldpc_bp_get_info(const ldpc_bp_decoder *d, ldpc_bp_info *info)
                            &d->nevermask, &d->errmask, &d->finmask, &d->llr_t, &d->st_all, &d->node_msg, &d->pipe_dev[0], &d->pipe_dev[1], &d->pipe_dev[2],
                            &d->lvl_state[0], &d->lvl_state[1], &d->lvl_list[0], &d->lvl_list[1], &d->lvl_it[0], &d->lvl_it[1],
                            &d->lvl_syn[0], &d->lvl_syn[1], &d->lvl_never[0], &d->lvl_never[1], &d->lvl_err[0], &d->lvl_err[1], &d->lvl_fin[0], &d->lvl_fin[1],
-                           &d->lvl_llr[0], &d->lvl_llr[1]};
+                           &d->lvl_llr[0], &d->lvl_llr[1], &d->team_ws, &d->team_ws_lvl[0], &d->team_ws_lvl[1],
+                           &d->rows_ctab, &d->rows_vtab, &d->rows_lds_edge};
     for (const DevBuf *b : all) info->workspace_bytes += (int64_t)b->cap;
     info->last_kernel = d->last_kernel;
     info->last_team_size = d->last_team;
