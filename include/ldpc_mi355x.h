@@ -101,6 +101,17 @@ const char *ldpc_last_error(void);
  * everything in the pool back to the device now; decoders in use are not affected. */
 ldpc_status ldpc_trim_memory(void);
 
+/* Diagnostics (tests; needs no device): the tables with which the team kernel keeps message rows in LDS, for a
+   (4,8)-regular graph (every check 8 edges, every bit 4; LDPC_ERR_UNSUPPORTED otherwise) and teams of `members`
+   workgroups.  Out: *lds_rows = R, rows per member (at most 312); vtab [n][16] = per position of the dealt bit order
+   the CSR rows of its 4 edges (row = 8 * check + place among the check's bits), their LDS rows or -1, the bit
+   (| 1 << 31 when one of its edges is in LDS), padding; ctab [s][2] = per check the mask of its edges in LDS and the
+   LDS row of the first of them; lds_edge [members][312 at most: pass room for members * 312] = the CSR rows each
+   member holds, [members][R] densely, -1 beyond a member's count.  No reference counterpart: the reference keeps
+   every message in one dense matrix (belief_propagation.jl:83-91). */
+ldpc_status ldpc_debug_team_rows(int64_t s, int64_t n, const int64_t *colptr, const int64_t *rowval, int32_t members,
+                                 int32_t *lds_rows, int32_t *vtab, int32_t *ctab, int32_t *lds_edge);
+
 /* Number of usable gfx950 devices (0 when there is none; never fails). */
 int32_t ldpc_device_count(void);
 

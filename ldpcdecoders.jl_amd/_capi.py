@@ -31,6 +31,7 @@ EXPORTED_SYMBOLS = (
     "ldpc_last_error",
     "ldpc_device_count",
     "ldpc_trim_memory",
+    "ldpc_debug_team_rows",
     "ldpc_bp_create",
     "ldpc_bp_destroy",
     "ldpc_bp_get_info",
@@ -124,6 +125,8 @@ def lib() -> ctypes.CDLL:
     L.ldpc_last_error.restype = ctypes.c_char_p
     L.ldpc_device_count.restype = i32
     L.ldpc_trim_memory.restype = i32
+    L.ldpc_debug_team_rows.restype = i32
+    L.ldpc_debug_team_rows.argtypes = [i64, i64, vp, vp, i32, ctypes.POINTER(i32), vp, vp, vp]
     L.ldpc_bp_create.restype = i32
     L.ldpc_bp_create.argtypes = [i64, i64, i64, vp, vp, f64, i64, ctypes.POINTER(BPOptions), ctypes.POINTER(vp)]
     L.ldpc_bp_destroy.restype = i32

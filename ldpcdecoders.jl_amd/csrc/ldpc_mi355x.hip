@@ -914,11 +914,15 @@ static int team_rows_expected(const ldpc_bp_decoder *d, int G)
 // are put into positions by the graph: a bit goes to the member, among the owners of its four checks, that has most
 // room left (any member once those are full).  Every edge whose check and bit then share the owner is a candidate; up
 // to kTeamRowsMax per member get a row in its LDS, numbered in check order.
-static ldpc_status team_rows_build(ldpc_bp_decoder *d, int G)
+// (pure host code: ldpc_debug_team_rows() hands the tables to a CPU test)
+struct TeamRowTables {
+    int R = 0;                    // LDS rows per member (the largest count; kTeamRowsMax at most)
+    size_t in_lds = 0;            // edges with a row in LDS
+    std::vector<int> vtab, ctab, lds_edge;
+};
+static TeamRowTables team_rows_tables(int n, int s, int nnz, const std::vector<int> &c2r, int G)
 {
-    if (d->rows_G == G) return LDPC_OK;
-    const int n = (int)d->n, s = (int)d->s, nnz = (int)d->nnz;
-    const std::vector<int> &c2r = d->h_csc2csr;
+    TeamRowTables out;
     auto check_owner = [&](int i) { return (i / kTeamCheckChunk) % G; };
     std::vector<int> cap((size_t)G, 0), member_of_bit((size_t)n, -1);
     for (int p = 0; p < n; ++p) cap[(size_t)((p / 4) % G)]++;
@@ -951,7 +955,9 @@ static ldpc_status team_rows_build(ldpc_bp_decoder *d, int G)
     int R = 0;
     for (auto &v : cand) { std::sort(v.begin(), v.end()); if ((int)v.size() > kTeamRowsMax) v.resize(kTeamRowsMax); R = std::max(R, (int)v.size()); }
     R = std::max(R, 1);
-    std::vector<int> lds_row_of((size_t)nnz, -1), lds_edge((size_t)G * R, -1), cbase((size_t)s, 0);
+    std::vector<int> lds_row_of((size_t)nnz, -1), cbase((size_t)s, 0);
+    std::vector<int> &lds_edge = out.lds_edge;
+    lds_edge.assign((size_t)G * R, -1);
     std::vector<unsigned> cmask((size_t)s, 0u);
     for (int m = 0; m < G; ++m)
         for (int r = 0; r < (int)cand[(size_t)m].size(); ++r) {
@@ -961,7 +967,9 @@ static ldpc_status team_rows_build(ldpc_bp_decoder *d, int G)
             if (cmask[(size_t)i] == 0u) cbase[(size_t)i] = r;   // (ascending q: the check's LDS edges follow each other)
             cmask[(size_t)i] |= 1u << (q - 8 * i);
         }
-    std::vector<int> vtab((size_t)n * kTeamVtab, 0), ctab((size_t)s * 2);
+    std::vector<int> &vtab = out.vtab, &ctab = out.ctab;
+    vtab.assign((size_t)n * kTeamVtab, 0);
+    ctab.assign((size_t)s * 2, 0);
     for (int i = 0; i < s; ++i) { ctab[(size_t)2 * i] = (int)cmask[(size_t)i]; ctab[(size_t)2 * i + 1] = cbase[(size_t)i]; }
     for (int p = 0; p < n; ++p) {
         const int j = bit[(size_t)p];
@@ -974,6 +982,42 @@ static ldpc_status team_rows_build(ldpc_bp_decoder *d, int G)
         }
         vtab[(size_t)p * kTeamVtab + 8] = any ? (j | (int)0x80000000u) : j;
     }
+    out.R = R;
+    for (auto &v : cand) out.in_lds += v.size();
+    return out;
+}
+
+// include/ldpc_mi355x.h: the tables above for a CPU test
+extern "C" ldpc_status ldpc_debug_team_rows(int64_t s, int64_t n, const int64_t *colptr, const int64_t *rowval, int32_t members,
+                                            int32_t *lds_rows, int32_t *vtab, int32_t *ctab, int32_t *lds_edge)
+{
+    if (!colptr || !rowval || !lds_rows || !vtab || !ctab || !lds_edge) return fail(LDPC_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (s <= 0 || n <= 0 || members < 1 || members > kTeamMaxMembers) return fail(LDPC_ERR_INVALID_ARGUMENT, "bad dimension");
+    const int64_t nnz = colptr[n];
+    if (nnz != 8 * s || nnz != 4 * n || nnz >= INT32_MAX) return fail(LDPC_ERR_UNSUPPORTED, "not a (4,8)-regular graph");
+    std::vector<int> fill((size_t)s, 0), c2r((size_t)nnz);
+    for (int64_t j = 0; j < n; ++j) {
+        if (colptr[j + 1] - colptr[j] != 4) return fail(LDPC_ERR_UNSUPPORTED, "not a (4,8)-regular graph");
+        for (int64_t k = colptr[j]; k < colptr[j + 1]; ++k) {
+            const int64_t i = rowval[k];
+            if (i < 0 || i >= s || fill[(size_t)i] >= 8) return fail(LDPC_ERR_UNSUPPORTED, "not a (4,8)-regular graph");
+            c2r[(size_t)k] = (int)(8 * i + fill[(size_t)i]++);   // bits ascending inside a check, as ldpc_bp_create lays the rows out
+        }
+    }
+    const TeamRowTables t = team_rows_tables((int)n, (int)s, (int)nnz, c2r, members);
+    *lds_rows = t.R;
+    std::memcpy(vtab, t.vtab.data(), t.vtab.size() * sizeof(int));
+    std::memcpy(ctab, t.ctab.data(), t.ctab.size() * sizeof(int));
+    std::memcpy(lds_edge, t.lds_edge.data(), t.lds_edge.size() * sizeof(int));
+    return LDPC_OK;
+}
+
+static ldpc_status team_rows_build(ldpc_bp_decoder *d, int G)
+{
+    if (d->rows_G == G) return LDPC_OK;
+    const TeamRowTables t = team_rows_tables((int)d->n, (int)d->s, (int)d->nnz, d->h_csc2csr, G);
+    const std::vector<int> &vtab = t.vtab, &ctab = t.ctab, &lds_edge = t.lds_edge;
+    const int R = t.R;
     auto up = [&](DevBuf &b, const void *src, size_t bytes) -> ldpc_status {
         ldpc_status r = b.ensure(std::max<size_t>(bytes, 4));
         if (r != LDPC_OK) return r;
@@ -986,10 +1030,8 @@ static ldpc_status team_rows_build(ldpc_bp_decoder *d, int G)
         (st = up(d->rows_lds_edge, lds_edge.data(), lds_edge.size() * 4)) != LDPC_OK)
         return st;
     d->rows_G = G; d->rows_R = R;
-    if (std::getenv("LDPC_TEAM_DEBUG")) {
-        size_t tot = 0; for (auto &v : cand) tot += v.size();
-        std::fprintf(stderr, "[ldpc] team rows: %d members, %d LDS rows each at most, %zu of %d edges in LDS\n", G, R, tot, nnz);
-    }
+    if (std::getenv("LDPC_TEAM_DEBUG"))
+        std::fprintf(stderr, "[ldpc] team rows: %d members, %d LDS rows each at most, %zu of %d edges in LDS\n", G, R, t.in_lds, (int)d->nnz);
     return LDPC_OK;
 }
 
