@@ -109,6 +109,14 @@ ldpc_status ldpc_trim_memory(void);
    LDS row of the first of them; lds_edge [members][312 at most: pass room for members * 312] = the CSR rows each
    member holds, [members][R] densely, -1 beyond a member's count.  No reference counterpart: the reference keeps
    every message in one dense matrix (belief_propagation.jl:83-91). */
+/* Diagnostics (tests; needs no device): how a batch of `batch` syndromes of a graph with nnz edges would be dealt to
+   teams of workgroups on an MI355X (256 CUs, one team workgroup per CU, members of >= 2048 message rows) under a budget
+   of cache_mib MiB of message slots in flight (the library's default: 240).  out = { members per team (1 = no teams:
+   node-parallel or tile kernel), teams = message slots in flight, workgroups launched, XCDs that host teams,
+   1 if the members of a team are dealt over all XCDs (<= 4 tiles), 1 if members keep rows in LDS }. */
+ldpc_status ldpc_debug_team_plan(int64_t nnz, int64_t max_iters, int64_t batch, int32_t cache_mib, int32_t regular_8_4,
+                                 int32_t out[6]);
+
 ldpc_status ldpc_debug_team_rows(int64_t s, int64_t n, const int64_t *colptr, const int64_t *rowval, int32_t members,
                                  int32_t *lds_rows, int32_t *vtab, int32_t *ctab, int32_t *lds_edge);
 

@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = (
     "ldpc_device_count",
     "ldpc_trim_memory",
     "ldpc_debug_team_rows",
+    "ldpc_debug_team_plan",
     "ldpc_bp_create",
     "ldpc_bp_destroy",
     "ldpc_bp_get_info",
@@ -125,6 +126,8 @@ def lib() -> ctypes.CDLL:
     L.ldpc_last_error.restype = ctypes.c_char_p
     L.ldpc_device_count.restype = i32
     L.ldpc_trim_memory.restype = i32
+    L.ldpc_debug_team_plan.restype = i32
+    L.ldpc_debug_team_plan.argtypes = [i64, i64, i64, i32, i32, ctypes.POINTER(i32 * 6)]
     L.ldpc_debug_team_rows.restype = i32
     L.ldpc_debug_team_rows.argtypes = [i64, i64, vp, vp, i32, ctypes.POINTER(i32), vp, vp, vp]
     L.ldpc_bp_create.restype = i32

@@ -903,10 +903,21 @@ constexpr int kTeamRowsMax = 312;
 
 static bool team_rows_possible(const ldpc_bp_decoder *d) { return d->team_rows_on && !d->h_csc2csr.empty() && !d->wpt_fixed; }
 
+// What the team plan depends on (pure data: ldpc_debug_team_plan() plans without a device for a CPU test)
+struct TeamPlanIn {
+    int64_t nnz = 0, max_iters = 0;
+    size_t cache = 0;          // budget of message slots in flight (ldpc_bp_decoder::team_cache)
+    int xcds_forced = 0;       // LDPC_TEAM_XCDS
+    bool team_max_set = false; // LDPC_TEAM_MAX given: no teams over all XCDs for <= 4 tiles
+    bool rows_possible = false;
+    int num_cus = 256;
+    int per_xcd = 0, gcap = 0; // team_geometry(): team workgroups one XCD hosts, members per team at most
+};
+
 // What a member is expected to hold (a bit dealt to a member that owns one of its 4 checks: a quarter of the edges).
-static int team_rows_expected(const ldpc_bp_decoder *d, int G)
+static int team_rows_expected(const TeamPlanIn &in, int G)
 {
-    return team_rows_possible(d) ? (int)std::min<int64_t>(kTeamRowsMax, d->nnz / 4 / std::max(G, 1)) : 0;
+    return in.rows_possible ? (int)std::min<int64_t>(kTeamRowsMax, in.nnz / 4 / std::max(G, 1)) : 0;
 }
 
 // The tables of TeamRows for teams of G members (kept until another G is asked for).  Checks are dealt as the kernel
@@ -1040,13 +1051,14 @@ static ldpc_status team_rows_build(ldpc_bp_decoder *d, int G)
 // team -- the combination that gives most workgroups a tile.  For the n = 16384 code (32 MiB a slot) that is SEVEN
 // teams of 32: with an eighth the slots fill the cache to the brim and every team is a fifth slower (full batch,
 // 50 iterations: 1111 ms on 8 XCDs, 1011 ms on 7, 1158 ms on 6).  false: nothing fits, not even the second tier below.
-static bool team_fit(const ldpc_bp_decoder *d, int per_xcd, int gcap, int64_t ntiles, bool rows, int *xcds, int *tpx, int *G)
+static bool team_fit(const TeamPlanIn &in, int64_t ntiles, bool rows, int *xcds, int *tpx, int *G)
 {
-    const size_t state = std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double);
-    const size_t cache = d->team_cache;
+    const int per_xcd = in.per_xcd, gcap = in.gcap;
+    const size_t state = std::max<size_t>((size_t)in.nnz, 1) * kTile * sizeof(double);
+    const size_t cache = in.cache;
     if (!cache) return false;
     int64_t best = 0;
-    const int x_hi = d->team_xcds ? d->team_xcds : 8, x_lo = d->team_xcds ? d->team_xcds : 6;
+    const int x_hi = in.xcds_forced ? in.xcds_forced : 8, x_lo = in.xcds_forced ? in.xcds_forced : 6;
     for (int x = x_hi; x >= x_lo; --x)
         for (int t = 1; t <= per_xcd / 3; ++t) {
             if ((size_t)x * (size_t)t * (state - (rows ? state / 4 : 0)) > cache) break;   // (a quarter at most can be in LDS)
@@ -1054,7 +1066,7 @@ static bool team_fit(const ldpc_bp_decoder *d, int per_xcd, int gcap, int64_t nt
             const int g = std::min(gcap, per_xcd / t);
             if (g < 3) break;
             // rows that the members keep in LDS are not in the cache
-            if ((size_t)x * (size_t)t * (state - (rows ? (size_t)g * team_rows_expected(d, g) * kTile * sizeof(double) : 0)) > cache) continue;
+            if ((size_t)x * (size_t)t * (state - (rows ? (size_t)g * team_rows_expected(in, g) * kTile * sizeof(double) : 0)) > cache) continue;
             const int64_t w = std::min<int64_t>((int64_t)x * t, ntiles) * g;   // workgroups with a tile
             if (w > best) { best = w; *xcds = x; *tpx = t; *G = g; }
         }
@@ -1063,7 +1075,7 @@ static bool team_fit(const ldpc_bp_decoder *d, int per_xcd, int gcap, int64_t nt
     // not as well as three tile-kernel workgroups per CU do (n = 32768, 64 MiB a slot, 50 iterations: 16,384 syndromes
     // 575 ms against 651 ms, 49,152 syndromes 1.76 s against 1.80 s -- with 8 slots instead of 768).  Beyond that
     // (n = 65536) the two are equal and the tile kernel stays.
-    if (!d->team_xcds && (size_t)8 * state <= cache / 5 * 11 && std::min(gcap, per_xcd) >= 3) {
+    if (!in.xcds_forced && (size_t)8 * state <= cache / 5 * 11 && std::min(gcap, per_xcd) >= 3) {
         *xcds = 8; *tpx = 1; *G = std::min(gcap, per_xcd);
         return true;
     }
@@ -1087,31 +1099,30 @@ struct TeamPlan {
     bool rows = false;       // members keep the rows that only they touch in LDS (TeamRows)
 };
 
-static TeamPlan team_plan(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
+static TeamPlan team_plan_pure(const TeamPlanIn &in, int64_t batch)
 {
     TeamPlan pl;
-    int per_xcd = 0, gcap = 0;
-    if (!team_geometry(d, want_llr, &per_xcd, &gcap)) return pl;
+    const int per_xcd = in.per_xcd, gcap = in.gcap;
     const int64_t ntiles = (batch + kTile - 1) / kTile;
-    if (ntiles < 1) return pl;
-    if ((size_t)ntiles * ((size_t)d->max_iters + 32) * sizeof(u64) > ((size_t)64 << 20)) return pl;   // mismatch words per tile and iteration
+    if (ntiles < 1 || per_xcd < 1) return pl;
+    if ((size_t)ntiles * ((size_t)in.max_iters + 32) * sizeof(u64) > ((size_t)64 << 20)) return pl;   // mismatch words per tile and iteration
     int64_t team = 1, nteams = 0;
-    if (ntiles <= 4 && !d->team_max_set) {
+    if (ntiles <= 4 && !in.team_max_set) {
         // dealt over all 8 XCDs (scatter mode of the kernel): larger teams pay -- one tile of the C3 code, 50
         // iterations: 32 members 5.4 ms, 48: 4.3 ms, 64: 3.4 ms (a member still has >= 1024 message rows per sweep)
-        const int64_t cap = std::min<int64_t>(64, std::max<int64_t>(gcap, d->nnz / 1024));
+        const int64_t cap = std::min<int64_t>(64, std::max<int64_t>(gcap, in.nnz / 1024));
         team = std::min<int64_t>(cap, (int64_t)8 * per_xcd / ntiles);
         nteams = ntiles;
         pl.scatter = true;
     } else {
         const int64_t need = (ntiles + 7) / 8;
-        const size_t state = std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double);
+        const size_t state = std::max<size_t>((size_t)in.nnz, 1) * kTile * sizeof(double);
         int x = 8, t = (int)need, g = 0;
-        const bool one_round = d->team_cache && !d->team_xcds && (size_t)8 * (size_t)need * state <= d->team_cache + d->team_cache / 4;
+        const bool one_round = in.cache && !in.xcds_forced && (size_t)8 * (size_t)need * state <= in.cache + in.cache / 4;
         // (the budget is applied to whole slots although members keep up to 15 % of the rows in LDS: eight teams of the
         // C3 code -- 8 x 27 MiB with the rows in LDS -- measured 981 ms for the full batch, seven 957)
-        if (one_round || !team_fit(d, per_xcd, gcap, ntiles, false, &x, &t, &g)) {
-            if (!one_round && ntiles > d->num_cus) return pl;
+        if (one_round || !team_fit(in, ntiles, false, &x, &t, &g)) {
+            if (!one_round && ntiles > in.num_cus) return pl;
             x = 8; t = (int)need;
             g = (int)std::min<int64_t>(gcap, (int64_t)per_xcd / t);
         }
@@ -1121,10 +1132,40 @@ static TeamPlan team_plan(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
     }
     if (team < 3) return pl;   // two workgroups per tile measured no better than the tile kernel's one of 16 waves
     pl.G = (int)std::min<int64_t>(team, kTeamMaxMembers);
-    pl.rows = !pl.scatter && team_rows_possible(d) && team_rows_expected(d, pl.G) >= 16;
+    pl.rows = !pl.scatter && in.rows_possible && team_rows_expected(in, pl.G) >= 16;
     pl.nteams = (int)nteams;
     pl.grid = pl.scatter ? pl.nteams * pl.G : 8 * pl.G * pl.tpx;
     return pl;
+}
+
+static TeamPlanIn team_plan_in(const ldpc_bp_decoder *d, int per_xcd, int gcap)
+{
+    TeamPlanIn in;
+    in.nnz = d->nnz; in.max_iters = d->max_iters; in.cache = d->team_cache; in.xcds_forced = d->team_xcds;
+    in.team_max_set = d->team_max_set; in.rows_possible = team_rows_possible(d); in.num_cus = d->num_cus;
+    in.per_xcd = per_xcd; in.gcap = gcap;
+    return in;
+}
+
+static TeamPlan team_plan(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
+{
+    int per_xcd = 0, gcap = 0;
+    if (!team_geometry(d, want_llr, &per_xcd, &gcap)) return TeamPlan();
+    return team_plan_pure(team_plan_in(d, per_xcd, gcap), batch);
+}
+
+// include/ldpc_mi355x.h: the plan for a CPU test (an MI355X's geometry: 256 CUs, one team workgroup per CU)
+extern "C" ldpc_status ldpc_debug_team_plan(int64_t nnz, int64_t max_iters, int64_t batch, int32_t cache_mib, int32_t regular_8_4,
+                                            int32_t out[6])
+{
+    if (!out || nnz < 0 || batch < 0 || cache_mib < 0) return fail(LDPC_ERR_INVALID_ARGUMENT, "bad argument");
+    TeamPlanIn in;
+    in.nnz = nnz; in.max_iters = max_iters; in.cache = (size_t)cache_mib << 20; in.rows_possible = regular_8_4 != 0;
+    in.num_cus = 256; in.per_xcd = 32;
+    in.gcap = (int)std::min<int64_t>(32, std::max<int64_t>(1, nnz / 2048));
+    const TeamPlan pl = team_plan_pure(in, batch);
+    out[0] = pl.G; out[1] = pl.nteams; out[2] = pl.grid; out[3] = pl.xcds; out[4] = pl.scatter ? 1 : 0; out[5] = pl.rows ? 1 : 0;
+    return LDPC_OK;
 }
 
 static int team_size(ldpc_bp_decoder *d, int64_t batch, bool want_llr) { return team_plan(d, batch, want_llr).G; }
@@ -1459,7 +1500,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             // (team_fit()); they take whatever the level holds.  Nothing fits (LDPC_TEAM_CACHE_MIB=0, large graphs):
             // one tile per team, up to as many tiles as leave every team 3 members.
             int tiles_max, x = 8, t = 1, g = 3;
-            if (team_fit(d, L.t_per_xcd, L.t_gcap, L.cap_tiles, false, &x, &t, &g)) {
+            if (team_fit(team_plan_in(d, L.t_per_xcd, L.t_gcap), L.cap_tiles, false, &x, &t, &g)) {
                 tiles_max = L.cap_tiles;
             } else {
                 x = 8; t = L.t_per_xcd / 3; g = 3;           // (the members of surplus teams are idle: round 1's geometry in fixed form)

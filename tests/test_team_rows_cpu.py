@@ -86,3 +86,43 @@ def test_only_4_8_regular_graphs():
     st = ldpc._capi.lib().ldpc_debug_team_rows(H.shape[0], 1008, colptr.ctypes.data, rowval.ctypes.data, 8, ctypes.byref(R),
                                                buf.ctypes.data, buf.ctypes.data, buf.ctypes.data)
     assert st == 5      # LDPC_ERR_UNSUPPORTED
+
+
+def plan(nnz, batch, cache_mib=240, max_iters=50, regular=1):
+    out = (ctypes.c_int32 * 6)()
+    ldpc._capi.check(ldpc._capi.lib().ldpc_debug_team_plan(nnz, max_iters, batch, cache_mib, regular, ctypes.byref(out)))
+    return dict(zip(("members", "teams", "grid", "xcds", "scatter", "rows"), list(out)))
+
+
+def test_team_plan_by_graph_and_batch():
+    """The host's choice of teams (ldpc_mi355x.hip team_plan_pure / team_fit), for an MI355X's geometry.  Message slot of
+    a graph: nnz x 512 B; budget of slots in flight: 240 MiB of the 256 MiB Infinity Cache."""
+    c3 = 65536                                                   # n = 16384, (4,8)-regular: 32 MiB a slot
+    # the headline batch: SEVEN persistent teams of 32 (224 MiB; an eighth slot overfills the cache), rows in LDS;
+    # 8 x 32 workgroups are launched, the blocks of the eighth XCD leave at once
+    assert plan(c3, 65536) == dict(members=32, teams=7, grid=256, xcds=7, scatter=0, rows=1)
+    assert plan(c3, 65536, regular=0)["rows"] == 0
+    # exactly eight tiles: one round of eight teams rather than seven teams twice
+    assert plan(c3, 512) == dict(members=32, teams=8, grid=256, xcds=8, scatter=0, rows=1)
+    assert plan(c3, 576)["teams"] == 7                           # nine tiles: persistent again
+    # up to four tiles: one team per tile, members dealt over all XCDs, up to 64 of them, no rows in LDS
+    assert plan(c3, 1) == dict(members=64, teams=1, grid=64, xcds=8, scatter=1, rows=0)
+    assert plan(c3, 256) == dict(members=64, teams=4, grid=256, xcds=8, scatter=1, rows=0)
+    # 28 MiB slots (n = 14336): eight fit the budget
+    assert plan(57344, 65536)["teams"] == 8 and plan(57344, 65536)["members"] == 28
+    # 16 MiB slots (n = 8192): members of >= 2048 rows are 16 at most, so two teams per XCD on seven XCDs (224 MiB)
+    p = plan(32768, 65536)
+    assert p["members"] == 16 and p["teams"] == 14 and p["xcds"] == 7 and p["grid"] == 256
+    # 64 MiB slots (n = 32768): twice the cache -- the second tier, one persistent team per XCD
+    assert plan(131072, 65536) == dict(members=32, teams=8, grid=256, xcds=8, scatter=0, rows=1)
+    # 128 MiB slots (n = 65536): the tile kernel for more tiles than CUs, one team per tile below
+    assert plan(262144, 65536)["members"] == 1
+    p = plan(262144, 1024)                                       # 16 tiles: two teams per XCD
+    assert p["teams"] == 16 and p["members"] == 16 and p["scatter"] == 0
+    # no budget at all (LDPC_TEAM_CACHE_MIB=0): round 1's rule
+    assert plan(c3, 65536, cache_mib=0)["members"] == 1
+    assert plan(c3, 2048, cache_mib=0) == dict(members=8, teams=32, grid=256, xcds=8, scatter=0, rows=0) or \
+        plan(c3, 2048, cache_mib=0)["teams"] == 32
+    # graphs too small for teams (fewer than 3 x 2048 rows) and batches whose mismatch words would not fit
+    assert plan(4096, 65536)["members"] == 1
+    assert plan(c3, 1 << 26, max_iters=4000)["members"] == 1
