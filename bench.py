@@ -362,6 +362,12 @@ def main():
                 # 256 MiB Infinity Cache the sweeps are served by it, HBM only sees the syndromes and the results --
                 # the HBM peak stays the yardstick (it is what BASELINE.json's metric names), but it is not the bound
                 "message_slots_in_flight_bytes": int(dec.info().resident_tiles // max(dec.info().last_team_size, 1)) * nnz * 512 if last_kernel == 4 else None,
+                # ... against what the cache side can do: committed PMC bytes between the L2s and the fabric over this
+                # run's kernel time, and the rate tools/mall_probe.hip streams in place through seven XCDs' ports
+                # (profiles/r02_infinity_cache_probe.txt: 8.76 TB/s) -- a measured ceiling, not a guide figure
+                "cache_side": ({"fabric_GBs": pmc_traffic(args.workload, kname)[0] / (sweep_ms * 1e-3) / 1e9, "probe_ceiling_GBs": 8760.0,
+                                "frac": pmc_traffic(args.workload, kname)[0] / (sweep_ms * 1e-3) / 1e9 / 8760.0}
+                               if (last_kernel == 4 and not args.batch and not args.per and pmc_traffic(args.workload, kname)[0]) else None),
                 "alg_bytes_per_launch": alg_bytes,
                 "kernel_ms": sweep_ms,
                 "pack_sweep_unpack_ms": total_ms,
