@@ -320,6 +320,34 @@ __device__ __forceinline__ double bit_compute_exact(const double (&c)[D], double
     return F;
 }
 
+// (pos as values already in registers)
+template <int D>
+__device__ __forceinline__ double bit_update_exact_v(double *Mt, const int (&pos)[D], double r)
+{
+    double c[D];
+    size_t at[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) at[k] = (size_t)pos[k] * kTile;
+#pragma unroll
+    for (int k = 0; k < D; ++k) c[k] = ldm(Mt + at[k]);
+    return bit_finish_exact<D>(Mt, at, c, r);
+}
+
+template <int D>
+__device__ __forceinline__ void bit_update_pair_v(double *Mt, const int (&pos0)[D], const int (&pos1)[D], double r, double &T0, double &T1)
+{
+    double c0[D], c1[D];
+    size_t at0[D], at1[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) { at0[k] = (size_t)pos0[k] * kTile; at1[k] = (size_t)pos1[k] * kTile; }
+#pragma unroll
+    for (int k = 0; k < D; ++k) c0[k] = ldm(Mt + at0[k]);
+#pragma unroll
+    for (int k = 0; k < D; ++k) c1[k] = ldm(Mt + at1[k]);
+    T0 = bit_finish_exact<D>(Mt, at0, c0, r);
+    T1 = bit_finish_exact<D>(Mt, at1, c1, r);
+}
+
 template <int D>
 __device__ __forceinline__ double bit_update_exact(double *Mt, const int *__restrict__ pos, double r)
 {

@@ -305,24 +305,33 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
                 if constexpr (LROWS) {
                     // every check has the full degree (the host instantiates this only for such graphs); col_ptr is ctab.
                     // (Pairs of checks / bits with rows in LDS loaded together measured slower, not faster.)
-                    for (int i = c * kTeamCheckChunk; i < i1; ++i) {
-                        const unsigned int mask = (unsigned int)col_ptr[2 * i];
-                        if (mask == 0u && kTeamCheckChunk == 2 && !first && tp.pairs && i + 1 < i1 && col_ptr[2 * i + 2] == 0) {
-                            const double sg0 = ((syn[i] >> lane) & 1ull) ? -1.0 : 1.0, sg1 = ((syn[i + 1] >> lane) & 1ull) ? -1.0 : 1.0;
-                            check_update_pair<DC>(Mt + (size_t)i * DC * kTile, Mt + (size_t)(i + 1) * DC * kTile, sg0, sg1);
-                            ++i;
-                            continue;
-                        }
-                        const double sigma = ((syn[i] >> lane) & 1ull) ? -1.0 : 1.0;
-                        double *const M = Mt + (size_t)i * DC * kTile;
-                        if (mask == 0u) {
-                            if (first) check_update_exact<DC, true>(M, sigma, r);
-                            else check_update_exact<DC, false>(M, sigma, r);
+                    typedef int v4i __attribute__((ext_vector_type(4)));
+                    const int i = c * kTeamCheckChunk;
+                    if (kTeamCheckChunk == 2 && i + 2 == i1) {
+                        const v4i ct = *(const v4i *)(col_ptr + 2 * i);   // both checks' masks and bases in one scalar load
+                        const u64 s0 = syn[i], s1 = syn[i + 1];
+                        const double sg0 = ((s0 >> lane) & 1ull) ? -1.0 : 1.0, sg1 = ((s1 >> lane) & 1ull) ? -1.0 : 1.0;
+                        double *const M0 = Mt + (size_t)i * DC * kTile, *const M1 = M0 + (size_t)DC * kTile;
+                        if ((ct.x | ct.z) == 0 && !first && tp.pairs) {
+                            check_update_pair<DC>(M0, M1, sg0, sg1);
+                        } else if (first) {
+                            check_update_mixed<DC, true>(M0, Lr + (size_t)ct.y * kTile, (unsigned int)ct.x, sg0, r);
+                            check_update_mixed<DC, true>(M1, Lr + (size_t)ct.w * kTile, (unsigned int)ct.z, sg1, r);
                         } else {
-                            double *const L = Lr + (size_t)col_ptr[2 * i + 1] * kTile;
-                            if (first) check_update_mixed<DC, true>(M, L, mask, sigma, r);
-                            else check_update_mixed<DC, false>(M, L, mask, sigma, r);
+                            if (ct.x == 0) check_update_exact<DC, false>(M0, sg0, r);
+                            else check_update_mixed<DC, false>(M0, Lr + (size_t)ct.y * kTile, (unsigned int)ct.x, sg0, r);
+                            if (ct.z == 0) check_update_exact<DC, false>(M1, sg1, r);
+                            else check_update_mixed<DC, false>(M1, Lr + (size_t)ct.w * kTile, (unsigned int)ct.z, sg1, r);
                         }
+                        return;
+                    }
+                    for (int ii = i; ii < i1; ++ii) {
+                        const unsigned int mask = (unsigned int)col_ptr[2 * ii];
+                        const double sigma = ((syn[ii] >> lane) & 1ull) ? -1.0 : 1.0;
+                        double *const M = Mt + (size_t)ii * DC * kTile;
+                        double *const L = Lr + (size_t)col_ptr[2 * ii + 1] * kTile;
+                        if (first) check_update_mixed<DC, true>(M, L, mask, sigma, r);
+                        else check_update_mixed<DC, false>(M, L, mask, sigma, r);
                     }
                     return;
                 }
@@ -377,30 +386,47 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
                 const int j1 = min(n, (c + 1) * vb);
                 int j = c * vb;
                 if constexpr (LROWS) {
-                    // positions of the dealt bit order; every bit has the full degree; csc2csr is vtab
+                    // positions of the dealt bit order; every bit has the full degree; csc2csr is vtab.  Everything the
+                    // table says about two positions is asked for at once (one scalar round trip per pair, not two)
                     static_assert(DV == 4, "the table has four edges per position");
-                    for (int q = j; q < j1; ++q) {
-                        const int *const vt = csc2csr + (size_t)q * kTeamVtab;
-                        const int b = vt[8];
-                        if (b >= 0 && tp.pairs && q + 1 < j1) {
-                            const int b1 = vt[kTeamVtab + 8];
-                            if (b1 >= 0) {                      // neither has a row in LDS
-                                double T0, T1;
-                                bit_update_pair<DV>(Mt, vt, vt + kTeamVtab, r, T0, T1);
-                                decide(b, T0);
-                                decide(b1, T1);
-                                ++q;
-                                continue;
-                            }
-                        }
-                        if (b >= 0) {
-                            decide(b, bit_update_exact<DV>(Mt, vt, r));
+                    typedef int v8i __attribute__((ext_vector_type(8)));
+                    auto single = [&](int b, const int (&pos)[4], const int (&lrow)[4]) {
+                        if (b >= 0) decide(b, bit_update_exact_v<DV>(Mt, pos, r));
+                        else decide(b & 0x7fffffff, bit_update_mixed<DV>(Mt, Lr, pos, lrow, r));
+                    };
+                    auto two = [&](const v8i &A, int b0, const v8i &B, int b1) {
+                        const int pos0[4] = {A.s0, A.s1, A.s2, A.s3}, lrow0[4] = {A.s4, A.s5, A.s6, A.s7};
+                        const int pos1[4] = {B.s0, B.s1, B.s2, B.s3}, lrow1[4] = {B.s4, B.s5, B.s6, B.s7};
+                        if ((b0 | b1) >= 0 && tp.pairs) {       // neither has a row in LDS: both loaded together
+                            double T0, T1;
+                            bit_update_pair_v<DV>(Mt, pos0, pos1, r, T0, T1);
+                            decide(b0, T0);
+                            decide(b1, T1);
                         } else {
-                            typedef int v4i __attribute__((ext_vector_type(4)));
-                            const v4i P = *(const v4i *)vt, V = *(const v4i *)(vt + 4);   // (all eight words before any is looked at)
-                            const int pos[4] = {P.x, P.y, P.z, P.w}, lrow[4] = {V.x, V.y, V.z, V.w};
-                            decide(b & 0x7fffffff, bit_update_mixed<DV>(Mt, Lr, pos, lrow, r));
+                            single(b0, pos0, lrow0);
+                            single(b1, pos1, lrow1);
                         }
+                    };
+                    int q = j;
+                    if (q + 4 == j1) {                          // the usual chunk: the table rows of all four positions at once
+                        const int *const vt = csc2csr + (size_t)q * kTeamVtab;
+                        const v8i A = *(const v8i *)vt, B = *(const v8i *)(vt + kTeamVtab), C = *(const v8i *)(vt + 2 * kTeamVtab),
+                                  D = *(const v8i *)(vt + 3 * kTeamVtab);
+                        const int b0 = vt[8], b1 = vt[kTeamVtab + 8], b2 = vt[2 * kTeamVtab + 8], b3 = vt[3 * kTeamVtab + 8];
+                        two(A, b0, B, b1);
+                        two(C, b2, D, b3);
+                        return;
+                    }
+                    for (; q + 1 < j1; q += 2) {
+                        const int *const vt = csc2csr + (size_t)q * kTeamVtab;
+                        const v8i A = *(const v8i *)vt, B = *(const v8i *)(vt + kTeamVtab);
+                        two(A, vt[8], B, vt[kTeamVtab + 8]);
+                    }
+                    for (; q < j1; ++q) {
+                        const int *const vt = csc2csr + (size_t)q * kTeamVtab;
+                        const v8i A = *(const v8i *)vt;
+                        const int pos0[4] = {A.s0, A.s1, A.s2, A.s3}, lrow0[4] = {A.s4, A.s5, A.s6, A.s7};
+                        single(vt[8], pos0, lrow0);
                     }
                     return;
                 }
