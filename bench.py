@@ -1,16 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- decoded syndromes/s of the MI355X BP decoder on BASELINE.json's metric.
 
-One "step" = one batchdecode!-equivalent pass (ldpc_bp_decode_batch_device) over one
-HBM-resident batch of synthetic syndromes.  Default workload = BASELINE configs[2]:
-Gallager (4,8)-regular LDPC, n=16384, m=8192, row weight 8, batch 65536, max_iters 50,
-per = 0.10 ("full-50": above the BP threshold, so every syndrome runs all 50 iterations;
-SURVEY.md 8d).  N>1: every rank decodes its own 65536-syndrome shard (weak scaling, no
-data-path collective -- syndromes are independent).
+One "step" = one batchdecode!-equivalent pass over one HBM-resident batch of synthetic
+syndromes.  Default workload = BASELINE configs[2]: Gallager (4,8)-regular LDPC, n=16384,
+m=8192, row weight 8, batch 65536 per GPU, max_iters 50, per = 0.10 ("full-50": above the BP
+threshold, so every syndrome runs all 50 iterations).
+
+N > 1 is BASELINE configs[3] as worded: ONE root-held (N x 65536) x s syndrome matrix
+(belief_propagation.jl:220), contiguous shards scattered from GPU 0, decoded, hard decisions /
+flags / iteration counts gathered on GPU 0 (weak scaling; no collective inside the decode --
+syndromes are independent).  Two hosts for the same exchange:
+  --mode scatter (default)  one process per GPU (torch.distributed.run), shards moved with
+                            RCCL send/recv groups by ldpcdecoders.jl_amd/sharding.py;
+  --mode cabi               ONE process drives all N GPUs through the C ABI
+                            (ldpc_bp_create_multi / ldpc_bp_decode_batch_multi_device:
+                            what a Julia host binds with ccall); other ranks, if the
+                            launcher started any, only take part in the barriers.
+N = 1 is the degenerate case of either (no exchange, decode straight into the result arrays).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with the extra objects
   roofline     : algorithmic bytes (32*nnz per syndrome*iteration) / sweep-kernel time
-  cpu_baseline : the CPU oracle in its reference-faithful dense mode, bounded sample.
+  cpu_baseline : the CPU oracle on edge lists over all host cores + its reference-faithful
+                 dense mode on one, bounded samples, every sample checked against the GPU
+  also         : (default workload, N = 1) the waterfall and the realistic error rate of the
+                 same code, 3 steps each, under the same oracle gate.
 """
 from __future__ import annotations
 
@@ -136,6 +149,105 @@ def cpu_baseline_edge_list(H, per, max_iters, syn_sample, gpu_err, gpu_conv, gpu
     return done / wall, done, all(r[1] for r in res)
 
 
+# What tools/mall_probe.hip streams in place (read-modify-write of 512-byte rows) through the XCDs' fabric ports when
+# the regions fit the Infinity Cache, by the number of XCDs that host a region (profiles/r02_infinity_cache_probe.txt;
+# measured ceilings, not guide figures)
+CACHE_SIDE_CEILING_GBS = {4: 5920.0, 5: 7250.0, 6: 7390.0, 7: 8760.0, 8: 11010.0}
+INFINITY_CACHE_BYTES = 256 << 20
+
+
+def roofline_object(dec, args, kname, last_kernel, nnz, s_checks, n, batch, achieved, alg_bytes, sweep_ms, total_ms):
+    """`achieved` / `peak` / `frac` are the metric's own yardstick: algorithmic message bytes over the sweep kernel's
+    time against the HBM peak (BASELINE.json: "achieved HBM GB/s fraction").  `bound` says what actually limits the
+    kernel that ran: the persistent teams keep their message slots inside the Infinity Cache, so their bound is the
+    cache side of the fabric, and `bound_ceiling` sets the (committed, PMC-measured) bytes between the L2s and the
+    fabric against the measured in-place streaming rate of as many XCDs' ports; `hbm_side` bounds what the HBM itself
+    has to move for such a launch from below (syndromes in, results out)."""
+    info = dec.info()
+    default_size = not args.batch and not args.per
+    traffic, traffic_src = pmc_traffic(args.workload, kname) if default_size else (None, None)
+    slots = int(info.resident_tiles // max(info.last_team_size, 1)) if last_kernel == 4 else 0
+    slot_bytes = slots * nnz * 512
+    in_cache = last_kernel == 4 and 0 < slot_bytes <= INFINITY_CACHE_BYTES
+    on_chip = bool(last_kernel == 2 or (last_kernel == 3 and nnz * 8 <= 150 * 1024))
+    ticks = dec.phase_ticks(0)
+    obj = {
+        "bound": "infinity_cache" if in_cache else "hbm",
+        "kernel": kname,
+        # the LDS-resident kernels keep the messages on chip: their "achieved" is the algorithmic message
+        # traffic they would have cost in HBM, not bytes the HBM moved (it can exceed the peak)
+        "messages_on_chip": on_chip,
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "peak_is": "HBM3E peak of the MI355X (the yardstick BASELINE.json's metric names), not this kernel's bound" if in_cache else "HBM3E peak of the MI355X",
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        # NOT measured in this run: bench.py cannot collect PMC counters; this is the committed rocprofv3
+        # figure (profiles/*_traffic.json) of the same workload AND kernel, named in traffic_source
+        "traffic": traffic,
+        "traffic_source": traffic_src,
+        "message_slots_in_flight_bytes": slot_bytes if last_kernel == 4 else None,
+        "alg_bytes_per_launch": alg_bytes,
+        "kernel_ms": sweep_ms,
+        "pack_sweep_unpack_ms": total_ms,
+        "phase_share_check_var_conv": [round(x / max(sum(ticks), 1), 4) for x in ticks],
+    }
+    if in_cache:
+        ceiling = CACHE_SIDE_CEILING_GBS.get(slots if slots <= 8 else 8, CACHE_SIDE_CEILING_GBS[8])
+        fabric = traffic / (sweep_ms * 1e-3) / 1e9 if (traffic and sweep_ms > 0) else None
+        obj["bound_ceiling"] = {
+            "what": f"in-place streaming of {min(slots, 8)} cache-resident regions, one per XCD (tools/mall_probe.hip, profiles/r02_infinity_cache_probe.txt)",
+            "peak": ceiling, "unit": "GB/s",
+            "achieved": fabric,        # committed PMC bytes between the L2s and the fabric / this run's kernel time
+            "frac": fabric / ceiling if fabric else None,
+        }
+        io_bytes = float(batch) * (s_checks + n + 1 + 4)     # what must cross the HBM at least: syndromes in, results out
+        obj["hbm_side"] = {"bytes_per_launch_lower_bound": io_bytes,
+                           "GBs_lower_bound": io_bytes / (total_ms * 1e-3) / 1e9 if total_ms > 0 else None,
+                           "note": "no counter in profiles/ separates HBM from Infinity-Cache hits (FETCH_SIZE / WRITE_SIZE count L2<->fabric requests)"}
+    return obj
+
+
+def also_workloads(ldpc, torch, H, Hcsr, n, nnz, device, local_rank, names=("c3_waterfall", "c3_realistic"), steps=3, sample=512):
+    """The same code at other error rates, after the timed region (they are not the headline; they make the
+    early-exit path -- straggler hand-off, packed levels -- observable in the driver's own run): `steps` calls each,
+    kernel time and iteration sum from the library's HIP events, and the same oracle gate on a sample."""
+    res = {}
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+    for name in names:
+        _, _, _, batch, per, max_iters = WORKLOADS[name]
+        dec = ldpc.BeliefPropagationDecoder(H, per, max_iters, device=local_rank)
+        syn = make_syndromes(torch, Hcsr, n, batch, per, seed=1234, device=device)
+        err = torch.empty((batch, n), dtype=torch.uint8, device=device)
+        conv = torch.empty(batch, dtype=torch.uint8, device=device)
+        iters = torch.empty(batch, dtype=torch.int32, device=device)
+        dec.decode_batch_device(syn, err, conv, None, iters)      # warm-up (workspace, levels)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            dec.decode_batch_device(syn, err, conv, None, iters)
+        dec.last_status()
+        torch.cuda.synchronize()
+        wall_ms = (time.perf_counter() - t0) / steps * 1e3
+        per_call = [dec.last_timing(i) for i in range(steps)]
+        kernel_ms = sum(x[0] for x in per_call) / steps
+        total_ms = sum(x[1] for x in per_call) / steps
+        sum_iters = per_call[0][2]
+        gbs = sum_iters * 32.0 * nnz / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        k = min(batch, sample)
+        h = [x[:k].cpu().numpy() for x in (syn, err, conv, iters)]
+        _, done, ok = cpu_baseline_edge_list(H, per, max_iters, h[0], h[1], h[2], h[3], cores, budget_s=10.0)
+        res[name] = {"per": per, "batch": batch, "steps": steps, "ms_per_step": wall_ms, "kernel_ms": kernel_ms, "pack_sweep_unpack_ms": total_ms,
+                     "mean_iters": sum_iters / batch, "converged_frac": float(conv.float().mean().item()),
+                     "value": batch / (wall_ms * 1e-3), "achieved": gbs, "frac": gbs / HBM_PEAK_GBS,
+                     "frac_is": "sum over syndromes of iterations executed x 32 nnz bytes / sweep-kernel time / HBM peak",
+                     "kernel": {1: "bp_tile_kernel", 2: "bp_lds_kernel", 3: "bp_node_kernel", 4: "bp_team_kernel"}.get(int(dec.info().last_kernel), "?"),
+                     "gpu_matches_oracle_on_sample": bool(ok), "oracle_sample": int(done)}
+        dec.close()
+        del syn, err, conv, iters
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,11 +256,13 @@ def main():
     ap.add_argument("--workload", default="c3_full50", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="syndromes per GPU (default: the workload's)")
     ap.add_argument("--per", type=float, default=0.0, help="physical error rate (default: the workload's)")
-    ap.add_argument("--mode", default="auto", choices=["auto", "scatter", "replicas"],
+    ap.add_argument("--mode", default="auto", choices=["auto", "scatter", "cabi", "replicas"],
                     help="scatter (default): BASELINE config 4 as worded -- rank 0 holds the whole N x batch matrix in HBM, "
                          "ldpcdecoders.jl_amd.sharding scatters the shards over RCCL, every rank decodes, the root gathers; "
-                         "N = 1 is the degenerate case of the same code.  replicas: every rank decodes a shard of its own, "
-                         "no exchange (round 1's mode)")
+                         "N = 1 is the degenerate case of the same code.  cabi: the same exchange from ONE process through the "
+                         "C ABI (ldpc_bp_create_multi: one handle and stream per GPU, RCCL send/recv from GPU 0).  replicas: every "
+                         "rank decodes a shard of its own, no exchange (round 1's mode)")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra workloads of the `also` object")
     ap.add_argument("--verify", action="store_true",
                     help="scatter mode: after the timed steps the root decodes every shard once more by itself and compares")
     ap.add_argument("--waves-per-tile", type=int, default=0)
@@ -169,17 +283,26 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    cabi = args.mode == "cabi"
+    if world != args.gpus and not (cabi and world == 1):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if args.rehearse_on_one_gpu:
-        local_rank = 0
+    if args.rehearse_on_one_gpu or cabi:
+        local_rank = 0                      # (cabi: rank 0's process drives every GPU; the batch lives on GPU 0)
+    if cabi and rank != 0:
+        # a rank the launcher started but the single-process host does not need: it joins the barriers and leaves
+        dist.init_process_group("gloo")
+        for _ in range(3):
+            dist.barrier()
+        dist.destroy_process_group()
+        return
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        if args.rehearse_on_one_gpu:
+        if args.rehearse_on_one_gpu or cabi:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)   # RCCL over xGMI
+    shards = args.gpus                      # shards of the job = GPUs (logical ones in a rehearsal)
 
     import ldpcdecoders_jl_amd as ldpc
     from ldpcdecoders_jl_amd import sharding
@@ -205,19 +328,29 @@ def main():
         H = ldpc.codes.parity_check_csc(n, wr, wc)
     nnz = int(H.nnz)
     s_checks = int(H.shape[0])
-    dec = ldpc.BeliefPropagationDecoder(H, per, max_iters, device=local_rank,
-                                        waves_per_tile=args.waves_per_tile, resident_tiles=args.resident_tiles,
-                                        kernel_variant=args.kernel_variant, defer_threshold=args.defer_threshold)
+    if cabi:
+        cabi_devices = [0] * shards if args.rehearse_on_one_gpu else list(range(shards))
+        dec = ldpc.BeliefPropagationDecoder(H, per, max_iters, devices=cabi_devices,
+                                            waves_per_tile=args.waves_per_tile, resident_tiles=args.resident_tiles,
+                                            kernel_variant=args.kernel_variant, defer_threshold=args.defer_threshold)
+    else:
+        dec = ldpc.BeliefPropagationDecoder(H, per, max_iters, device=local_rank,
+                                            waves_per_tile=args.waves_per_tile, resident_tiles=args.resident_tiles,
+                                            kernel_variant=args.kernel_variant, defer_threshold=args.defer_threshold)
     # Synthetic data: shard g of the job is Bernoulli(per) errors from seed 1234 + g.  scatter mode: the root holds
     # all N shards as ONE caller-owned matrix (belief_propagation.jl:220: one `syndromes`, columns independent).
     Hcsr = H.tocsr()
-    if mode == "scatter":
+    if mode in ("scatter", "cabi"):
         syn = None
         if rank == 0:
-            syn = torch.empty((batch * world, s_checks), dtype=torch.uint8, device=device)
-            for g in range(world):
+            syn = torch.empty((batch * shards, s_checks), dtype=torch.uint8, device=device)
+            for g in range(shards):
                 syn[g * batch:(g + 1) * batch] = make_syndromes(torch, Hcsr, n, batch, per, seed=1234 + g, device=device)
         err = conv = iters = None
+        if cabi:
+            err = torch.empty((batch * shards, n), dtype=torch.uint8, device=device)
+            conv = torch.empty(batch * shards, dtype=torch.uint8, device=device)
+            iters = torch.empty(batch * shards, dtype=torch.int32, device=device)
     else:
         syn = make_syndromes(torch, Hcsr, n, batch, per, seed=1234 + rank, device=device)
         err = torch.empty((batch, n), dtype=torch.uint8, device=device)
@@ -241,6 +374,10 @@ def main():
             conv.copy_(c)
             osd_sent[0] = k
             device_calls[0] += 2 if k else 1   # BP for all, then the unconverged ones once more with LLRs
+    elif cabi:
+        def step():
+            dec.decode_batch_device(syn, err, conv, None, iters)   # ldpc_bp_decode_batch_multi_device: scatter, decode, gather
+            result[0] = (err, conv, iters)
     elif mode == "scatter":
         decode_fn = sharding.gpu_decode_fn(dec)
         comm = torch.device("cpu") if (args.rehearse_on_one_gpu and world > 1) else None
@@ -255,6 +392,8 @@ def main():
             dec.decode_batch_device(syn, err, conv, None, iters)
 
     def fence():
+        if cabi:
+            dec.last_status()               # every device's share of the calls enqueued so far
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -282,37 +421,52 @@ def main():
     sum_iters = sum(t[2] for t in per_call[:cps])
     ph = {key: (sum(p[key] for p in phases) / len(phases) if phases else 0.0) for key in ("scatter_ms", "decode_ms", "gather_ms")}
     decode_ms_max = ph["decode_ms"]
-    if world > 1:
+    if cabi:
+        mi = dec.multi_info()
+        ph = {"scatter_ms": mi.scatter_ms, "decode_ms": mi.decode_ms_max, "gather_ms": mi.gather_ms}
+        decode_ms_max = mi.decode_ms_max
+    if world > 1 and cabi:
+        dist.barrier()
+    elif world > 1:
         cdev = "cpu" if args.rehearse_on_one_gpu else device
         t = torch.tensor([elapsed, ph["decode_ms"]], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, decode_ms_max = float(t[0].item()), float(t[1].item())
 
     verified = None
-    if mode == "scatter" and args.verify and rank == 0:
+    if mode in ("scatter", "cabi") and args.verify and rank == 0:
         # the root decodes every shard by itself and compares with what came back from the ranks
         g_err, g_conv, g_it = result[0]
         e1 = torch.empty((batch, n), dtype=torch.uint8, device=device)
         c1 = torch.empty(batch, dtype=torch.uint8, device=device)
         i1 = torch.empty(batch, dtype=torch.int32, device=device)
         verified = True
-        for g in range(world):
-            dec.decode_batch_device(syn[g * batch:(g + 1) * batch], e1, c1, None, i1)
+        vdec = ldpc.BeliefPropagationDecoder(H, per, max_iters, device=local_rank) if cabi else dec
+        for g in range(shards):
+            vdec.decode_batch_device(syn[g * batch:(g + 1) * batch], e1, c1, None, i1)
             torch.cuda.synchronize()
             sl = slice(g * batch, (g + 1) * batch)
             verified = verified and bool(torch.equal(e1, g_err[sl])) and bool(torch.equal(c1, g_conv[sl])) and bool(torch.equal(i1, g_it[sl]))
+        if cabi:
+            vdec.close()
 
     if rank == 0:
-        if mode == "scatter":
+        if mode in ("scatter", "cabi"):
             err, conv, iters = (t[:batch] for t in result[0])   # the root's own shard (seed 1234)
             syn0 = syn[:batch]
         else:
             syn0 = syn
-        total_syndromes = batch * world * args.steps
+        total_syndromes = batch * shards * args.steps
         value = total_syndromes / elapsed
         alg_bytes = float(sum_iters) * 32.0 * nnz        # 32*nnz B per syndrome*iteration
         achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
-        if mode == "scatter":
+        if cabi:
+            xk = {0: "auto", 1: "hipMemcpyPeerAsync (logical devices share a GPU: rehearsal)", 2: "RCCL ncclSend/ncclRecv groups over xGMI", 3: "none"}[int(mi.exchange)]
+            par = (f"ONE process, C ABI (ldpc_bp_create_multi): one root-held {batch * shards} x {s_checks} syndrome matrix on GPU 0 -> "
+                   f"contiguous shards to {shards} devices {list(mi.devices[:mi.ndev])}, exchange: {xk} -> one handle + stream per device "
+                   f"-> results gathered on GPU 0" if shards > 1 else
+                   "ldpc_bp_decode_batch_multi_device with one device (degenerate case: no exchange, decode straight into the result arrays)")
+        elif mode == "scatter":
             par = (f"one root-held {batch * world} x {s_checks} syndrome matrix -> contiguous shards scattered from rank 0 "
                    f"({'gloo via host staging, all ranks on one GPU (rehearsal)' if args.rehearse_on_one_gpu and world > 1 else 'RCCL send/recv groups over xGMI'}) "
                    f"-> {world} x HIP decode -> hard decisions / flags / iteration counts gathered on rank 0"
@@ -324,7 +478,7 @@ def main():
             "metric": "decoded syndromes/sec (batchdecode!, 50 iters) + achieved HBM GB/s fraction",
             "value": value,
             "unit": "syndromes/s",
-            "n_gpus": world,
+            "n_gpus": shards,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -337,49 +491,21 @@ def main():
                 "workload": f"{args.workload}: Gallager ({wc},{wr})-regular LDPC n={n} m={s_checks} nnz={nnz}, "
                             f"batch={batch}/GPU, per={per}, max_iters={max_iters}, HBM-resident uint8 syndromes in, "
                             f"uint8 hard decisions + converged + iteration counts out",
-                "global_batch": batch * world,
+                "global_batch": batch * shards,
                 "mode": mode,
                 "parallelism": par,
                 "mean_iters": sum_iters / batch,
                 "converged_frac": float(conv.float().mean().item()),
                 "osd_postprocessed_per_step": osd_sent[0],
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": kname,
-                # the LDS-resident kernels keep the messages on chip: their "achieved" is the algorithmic message
-                # traffic they would have cost in HBM, not bytes the HBM moved (it can exceed the peak)
-                "messages_on_chip": bool(last_kernel == 2 or (last_kernel == 3 and nnz * 8 <= 150 * 1024)),
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                # NOT measured in this run: bench.py cannot collect PMC counters; this is the committed rocprofv3
-                # figure (profiles/*_traffic.json) of the same workload, named in traffic_source
-                "traffic": pmc_traffic(args.workload, kname)[0] if (not args.batch and not args.per) else None,
-                "traffic_source": pmc_traffic(args.workload, kname)[1],
-                # the team kernel keeps 8 message slots in flight (one persistent team per XCD): when they fit the
-                # 256 MiB Infinity Cache the sweeps are served by it, HBM only sees the syndromes and the results --
-                # the HBM peak stays the yardstick (it is what BASELINE.json's metric names), but it is not the bound
-                "message_slots_in_flight_bytes": int(dec.info().resident_tiles // max(dec.info().last_team_size, 1)) * nnz * 512 if last_kernel == 4 else None,
-                # ... against what the cache side can do: committed PMC bytes between the L2s and the fabric over this
-                # run's kernel time, and the rate tools/mall_probe.hip streams in place through seven XCDs' ports
-                # (profiles/r02_infinity_cache_probe.txt: 8.76 TB/s) -- a measured ceiling, not a guide figure
-                "cache_side": ({"fabric_GBs": pmc_traffic(args.workload, kname)[0] / (sweep_ms * 1e-3) / 1e9, "probe_ceiling_GBs": 8760.0,
-                                "frac": pmc_traffic(args.workload, kname)[0] / (sweep_ms * 1e-3) / 1e9 / 8760.0}
-                               if (last_kernel == 4 and not args.batch and not args.per and pmc_traffic(args.workload, kname)[0]) else None),
-                "alg_bytes_per_launch": alg_bytes,
-                "kernel_ms": sweep_ms,
-                "pack_sweep_unpack_ms": total_ms,
-                "phase_share_check_var_conv": [round(t / max(sum(dec.phase_ticks(0)), 1), 4) for t in dec.phase_ticks(0)],
-            },
+            "roofline": roofline_object(dec, args, kname, last_kernel, nnz, s_checks, n, batch, achieved, alg_bytes, sweep_ms, total_ms),
         }
-        if mode == "scatter":
+        if mode in ("scatter", "cabi"):
             out["exchange"] = {"scatter_ms": ph["scatter_ms"], "decode_ms_max_rank": decode_ms_max, "gather_ms": ph["gather_ms"],
-                               "scatter_bytes_per_peer": batch * s_checks if world > 1 else 0,
-                               "gather_bytes_per_peer": batch * (n + 1 + 4) if world > 1 else 0,
+                               "scatter_bytes_per_peer": batch * s_checks if shards > 1 else 0,
+                               "gather_bytes_per_peer": batch * (n + 1 + 4) if shards > 1 else 0,
                                "sharded_matches_local": verified}
-        if not args.no_cpu_baseline and world == 1 and not bposd_workload:
+        if not args.no_cpu_baseline and shards == 1 and not bposd_workload:
             cores = max(1, min(len(os.sched_getaffinity(0)), 16))   # a one-GPU box grants 16 cores
             k_edge = min(batch, 2048)
             h_syn, h_err, h_conv, h_it = (t[:k_edge].cpu().numpy() for t in (syn0, err, conv, iters))
@@ -399,6 +525,9 @@ def main():
                               f"1 thread like the reference",
                 },
             }
+        if args.workload == "c3_full50" and shards == 1 and mode != "replicas" and not args.no_also and not args.batch and not args.per \
+                and not args.kernel_variant and not args.waves_per_tile and not args.resident_tiles:
+            out["also"] = also_workloads(ldpc, torch, H, Hcsr, n, nnz, device, local_rank)
         print(json.dumps(out), flush=True)
     # explicit teardown, in this order, before the interpreter starts dismantling modules: the decoder handles
     # (hipDeviceSynchronize + frees), then the process group

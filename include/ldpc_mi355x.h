@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LDPC_MI355X_ABI_VERSION 2
+#define LDPC_MI355X_ABI_VERSION 3
 
 typedef enum ldpc_status {
     LDPC_OK = 0,
@@ -97,28 +97,9 @@ const char *ldpc_last_error(void);
 
 /* The message arrays of large codes (>= 1 GiB) are groups of 1 GiB chunks that the library keeps, still mapped, in a
  * per-process pool when a decoder lets go of them, so that the next decoder of that size takes them over (at most
- * LDPC_POOL_GIB = 64 GiB are held; the pool is emptied by itself when an allocation runs out of memory).  This gives
+ * 64 GiB are held; the pool is emptied by itself when an allocation runs out of memory).  This gives
  * everything in the pool back to the device now; decoders in use are not affected. */
 ldpc_status ldpc_trim_memory(void);
-
-/* Diagnostics (tests; needs no device): the tables with which the team kernel keeps message rows in LDS, for a
-   (4,8)-regular graph (every check 8 edges, every bit 4; LDPC_ERR_UNSUPPORTED otherwise) and teams of `members`
-   workgroups.  Out: *lds_rows = R, rows per member (at most 312); vtab [n][16] = per position of the dealt bit order
-   the CSR rows of its 4 edges (row = 8 * check + place among the check's bits), their LDS rows or -1, the bit
-   (| 1 << 31 when one of its edges is in LDS), padding; ctab [s][2] = per check the mask of its edges in LDS and the
-   LDS row of the first of them; lds_edge [members][312 at most: pass room for members * 312] = the CSR rows each
-   member holds, [members][R] densely, -1 beyond a member's count.  No reference counterpart: the reference keeps
-   every message in one dense matrix (belief_propagation.jl:83-91). */
-/* Diagnostics (tests; needs no device): how a batch of `batch` syndromes of a graph with nnz edges would be dealt to
-   teams of workgroups on an MI355X (256 CUs, one team workgroup per CU, members of >= 2048 message rows) under a budget
-   of cache_mib MiB of message slots in flight (the library's default: 240).  out = { members per team (1 = no teams:
-   node-parallel or tile kernel), teams = message slots in flight, workgroups launched, XCDs that host teams,
-   1 if the members of a team are dealt over all XCDs (<= 4 tiles), 1 if members keep rows in LDS }. */
-ldpc_status ldpc_debug_team_plan(int64_t nnz, int64_t max_iters, int64_t batch, int32_t cache_mib, int32_t regular_8_4,
-                                 int32_t out[6]);
-
-ldpc_status ldpc_debug_team_rows(int64_t s, int64_t n, const int64_t *colptr, const int64_t *rowval, int32_t members,
-                                 int32_t *lds_rows, int32_t *vtab, int32_t *ctab, int32_t *lds_edge);
 
 /* Number of usable gfx950 devices (0 when there is none; never fails). */
 int32_t ldpc_device_count(void);
@@ -208,6 +189,77 @@ ldpc_status ldpc_bp_last_timing(ldpc_bp_decoder *dec, double *sweep_ms, double *
  * back-to-back asynchronous calls without synchronising between them. */
 ldpc_status ldpc_bp_call_timing(ldpc_bp_decoder *dec, int32_t calls_back, double *sweep_ms,
                                 double *total_ms, int64_t *sum_iters);
+
+/* ------------------------------------------------------------------------
+ * batchdecode! over several GPUs of one node from ONE process (BASELINE config 4).
+ *
+ * `batchdecode!(decoder, syndromes, errors, success)` (src/decoders/belief_propagation.jl:220-231) is one call on one
+ * caller-held s x B matrix whose columns are decoded independently (:224-228).  A multi-device decoder keeps that
+ * contract: logical device g decodes the contiguous columns [g*B/G, (g+1)*B/G) with a single-device handle of its own
+ * (its own copy of the Tanner graph, workspace and stream); there is no collective inside the decode.  This is what a
+ * Julia host binds with `ccall`; a host that runs one process per GPU (PyTorch) shards the same way
+ * above the single-device entries instead (ldpcdecoders.jl_amd/sharding.py).
+ * ------------------------------------------------------------------------ */
+#define LDPC_MULTI_MAX_DEVICES 16
+
+/* How the ROOT-DEVICE form moves shards between devices[0] and the others. */
+enum {
+    LDPC_EXCHANGE_AUTO = 0, /* create: RCCL when every logical device is a GPU of its own, else COPY; one device: NONE */
+    LDPC_EXCHANGE_COPY = 1, /* hipMemcpyPeerAsync ordered by events (logical devices that share a GPU cannot form an RCCL
+                               clique: the rehearsal of G shards on fewer GPUs) */
+    LDPC_EXCHANGE_RCCL = 2, /* one RCCL communicator per device (ncclCommInitAll, created by the first root-device call);
+                               scatter and gather are ncclGroupStart / ncclSend + ncclRecv / ncclGroupEnd over xGMI.  RCCL
+                               is loaded at run time (librccl.so.1).  With ONE device the shard travels to itself through a
+                               one-rank communicator (a rehearsal of the RCCL calls on a one-GPU box) */
+    LDPC_EXCHANGE_NONE = 3  /* (reported only) one device: the batch is decoded where it lies */
+};
+
+typedef struct ldpc_bp_multi ldpc_bp_multi; /* opaque; owns one ldpc_bp_decoder, one stream and the shard buffers per device */
+
+typedef struct ldpc_bp_multi_info {
+    int32_t ndev;
+    int32_t exchange;                         /* LDPC_EXCHANGE_NONE / _COPY / _RCCL */
+    int32_t devices[LDPC_MULTI_MAX_DEVICES];  /* HIP ordinal of logical device g; g = 0 is the root */
+    /* the most recent ldpc_bp_decode_batch_multi_device call, from HIP events on the root's stream (zeros after a
+       host-form call): */
+    double scatter_ms;      /* enqueueing + sending the syndrome shards */
+    double root_decode_ms;  /* the root's own shard */
+    double gather_ms;       /* receiving the results: includes waiting for the slowest peer's decode */
+    double decode_ms_max;   /* slowest device's pack + sweeps + unpack (its handle's ldpc_bp_last_timing) */
+    int64_t scatter_bytes_per_peer, gather_bytes_per_peer;
+} ldpc_bp_multi_info;
+
+/* The constructor of ldpc_bp_create (belief_propagation.jl:61-67), once per logical device: devices[ndev] are HIP
+ * ordinals (an ordinal may appear more than once: those logical devices share the GPU and their team grids run one
+ * after the other), devices[0] is the root of the root-device form.  options->device is ignored. */
+ldpc_status ldpc_bp_create_multi(int32_t ndev, const int32_t *devices, int32_t exchange, int64_t s, int64_t n, int64_t nnz,
+                                 const int64_t *colptr, const int64_t *rowval, double per, int64_t max_iters,
+                                 const ldpc_bp_options *options, ldpc_bp_multi **out);
+ldpc_status ldpc_bp_destroy_multi(ldpc_bp_multi *dec);
+
+/* The single-device handle of logical device g (ldpc_bp_get_info, ldpc_bp_call_timing ...); NULL if out of range.
+ * Owned by the multi-device decoder: do not destroy it, and do not decode through it while a multi call is in flight. */
+ldpc_bp_decoder *ldpc_bp_multi_handle(ldpc_bp_multi *dec, int32_t g);
+
+/* `batchdecode!` (belief_propagation.jl:220-231) on HOST buffers laid out as for ldpc_bp_decode_batch: shard g goes
+ * pinned host -> ITS OWN GPU -> pinned host through that device's 3-slot copy / decode / copy pipeline, one host thread
+ * per device; nothing hops through GPU 0.  Synchronous.  With ndev = 1 this is ldpc_bp_decode_batch. */
+ldpc_status ldpc_bp_decode_batch_multi(ldpc_bp_multi *dec, int64_t batch, const uint8_t *syndromes, uint8_t *errors,
+                                       uint8_t *converged, double *llr, int32_t *iters);
+
+/* The same with the whole batch resident in the HBM of devices[0] (pointers as for ldpc_bp_decode_batch_device):
+ * scatter the syndrome shards, decode, gather hard decisions / flags (/ iteration counts / LLRs) into the caller's
+ * arrays.  Asynchronous: the root's work is enqueued on `stream` (a hipStream_t of devices[0]; NULL = its default
+ * stream), the peers' on streams of their own; the outputs are valid once `stream` has been synchronised.  With
+ * ndev = 1 (and no RCCL rehearsal) this is ldpc_bp_decode_batch_device. */
+ldpc_status ldpc_bp_decode_batch_multi_device(ldpc_bp_multi *dec, int64_t batch, const uint8_t *d_syndromes,
+                                              uint8_t *d_errors, uint8_t *d_converged, double *d_llr, int32_t *d_iters,
+                                              void *stream);
+
+/* ldpc_bp_last_status over every device: waits for the most recent call everywhere and reports the first failure. */
+ldpc_status ldpc_bp_multi_last_status(ldpc_bp_multi *dec);
+/* Blocks until the most recent root-device call has finished. */
+ldpc_status ldpc_bp_multi_get_info(ldpc_bp_multi *dec, ldpc_bp_multi_info *info);
 
 /* ------------------------------------------------------------------------
  * BP+OSD host post-processing (BASELINE config 5).  Pure host

@@ -1,0 +1,40 @@
+/*
+ * ldpc_mi355x_debug.h -- test hooks of libldpc_mi355x.so.  NOT part of the drop-in boundary (include/ldpc_mi355x.h):
+ * nothing here replaces a reference interface; the CPU test-suite uses these entries to check, without a GPU, the
+ * host-side planning the team kernel relies on (ldpcdecoders.jl_amd/csrc/ldpc_mi355x.hip: team_plan_pure(),
+ * team_rows_tables()).  Pure host code; no device is needed or touched.
+ */
+#ifndef LDPC_MI355X_DEBUG_H
+#define LDPC_MI355X_DEBUG_H
+
+#include "ldpc_mi355x.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* How a batch of `batch` syndromes of a graph with nnz edges would be dealt to teams of workgroups on an MI355X
+   (256 CUs, one team workgroup per CU, members of >= 2048 message rows) under a budget of cache_mib MiB of message
+   slots in flight (the library's default: 240).  rows_dv: the bit degree when the graph is regular and has a
+   rows-in-LDS instantiation, else 0.  out = { members per team (1 = no teams: node-parallel or tile kernel),
+   teams = message slots in flight, workgroups launched, XCDs that host teams, 1 if the members of a team are dealt
+   over all XCDs (<= 4 tiles), 1 if members keep rows in LDS }. */
+ldpc_status ldpc_debug_team_plan(int64_t nnz, int64_t max_iters, int64_t batch, int32_t cache_mib, int32_t rows_dv,
+                                 int32_t out[6]);
+
+/* The tables with which the team kernel keeps message rows in LDS, for a REGULAR graph (every check dc edges, every
+   bit dv) whose degree pair has an instantiation -- (6,3), (8,4), (10,5); LDPC_ERR_UNSUPPORTED otherwise -- and teams
+   of `members` workgroups.  Out: degrees = {dc, dv}; *vt_words = words per position record (8 or 16); *lds_rows = R,
+   rows per member (at most 312); vtab [n][vt_words] = per position of the dealt bit order the CSR rows of its dv edges
+   (row = dc * check + place among the check's bits), their LDS rows or -1, the bit (| 1 << 31 when one of its edges is
+   in LDS), padding; ctab [s][2] = per check the mask of its edges in LDS and the LDS row of the first of them;
+   lds_edge [members][R] = the CSR rows each member holds, -1 beyond a member's count (pass room for members * 312).
+   No reference counterpart: the reference keeps every message in one dense matrix (belief_propagation.jl:83-91). */
+ldpc_status ldpc_debug_team_rows(int64_t s, int64_t n, const int64_t *colptr, const int64_t *rowval, int32_t members,
+                                 int32_t *degrees, int32_t *vt_words, int32_t *lds_rows, int32_t *vtab, int32_t *ctab,
+                                 int32_t *lds_edge);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDPC_MI355X_DEBUG_H */

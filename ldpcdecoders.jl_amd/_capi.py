@@ -13,6 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 # LDPC_MI355X_LIB selects another build of the same library (tuning experiments, installed copies)
 LIB_PATH = os.environ.get("LDPC_MI355X_LIB") or os.path.join(CSRC, "libldpc_mi355x.so")
+# The experiments build (-DLDPC_EXPERIMENTS): the same code plus the environment knobs and the fault injection that
+# tests and tools use to force a code path.  The product library above reads no environment variable.
+EXP_LIB_PATH = os.environ.get("LDPC_MI355X_EXP_LIB") or os.path.join(CSRC, "libldpc_mi355x_exp.so")
 
 LDPC_OK = 0
 STATUS_NAMES = {
@@ -31,8 +34,6 @@ EXPORTED_SYMBOLS = (
     "ldpc_last_error",
     "ldpc_device_count",
     "ldpc_trim_memory",
-    "ldpc_debug_team_rows",
-    "ldpc_debug_team_plan",
     "ldpc_bp_create",
     "ldpc_bp_destroy",
     "ldpc_bp_get_info",
@@ -42,6 +43,13 @@ EXPORTED_SYMBOLS = (
     "ldpc_bp_last_timing",
     "ldpc_bp_call_timing",
     "ldpc_bp_call_phase_ticks",
+    "ldpc_bp_create_multi",
+    "ldpc_bp_destroy_multi",
+    "ldpc_bp_multi_handle",
+    "ldpc_bp_decode_batch_multi",
+    "ldpc_bp_decode_batch_multi_device",
+    "ldpc_bp_multi_last_status",
+    "ldpc_bp_multi_get_info",
     "ldpc_osd_create",
     "ldpc_osd_destroy",
     "ldpc_osd_postprocess_batch",
@@ -51,6 +59,11 @@ EXPORTED_SYMBOLS = (
     "ldpc_bpots_decode_batch",
     "ldpc_bpots_decode_batch_device",
 )
+# ... and include/ldpc_mi355x_debug.h (test hooks, not part of the boundary)
+DEBUG_SYMBOLS = ("ldpc_debug_team_rows", "ldpc_debug_team_plan")
+
+MULTI_MAX_DEVICES = 16
+EXCHANGE_AUTO, EXCHANGE_COPY, EXCHANGE_RCCL, EXCHANGE_NONE = 0, 1, 2, 3
 
 
 class LdpcError(RuntimeError):
@@ -72,6 +85,15 @@ class BPInfo(ctypes.Structure):
     ]
 
 
+class BPMultiInfo(ctypes.Structure):
+    _fields_ = [
+        ("ndev", ctypes.c_int32), ("exchange", ctypes.c_int32), ("devices", ctypes.c_int32 * MULTI_MAX_DEVICES),
+        ("scatter_ms", ctypes.c_double), ("root_decode_ms", ctypes.c_double), ("gather_ms", ctypes.c_double),
+        ("decode_ms_max", ctypes.c_double),
+        ("scatter_bytes_per_peer", ctypes.c_int64), ("gather_bytes_per_peer", ctypes.c_int64),
+    ]
+
+
 class BPOptions(ctypes.Structure):
     _fields_ = [
         ("device", ctypes.c_int32), ("waves_per_tile", ctypes.c_int32),
@@ -82,18 +104,21 @@ class BPOptions(ctypes.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("ldpc_mi355x.hip", "pick_tile.hip", "pick_lds.hip", "pick_node.hip", "pick_team.hip", "pickers.hpp",
+    srcs = [os.path.join(CSRC, f) for f in ("ldpc_mi355x.hip", "ldpc_multi.hip", "host_env.hpp", "pick_tile.hip", "pick_lds.hip", "pick_node.hip", "pick_team.hip", "pickers.hpp",
                                              "ldpc_bpots.hip", "osd_host.cpp", "bp_kernels.hpp", "bp_lds_kernels.hpp", "bp_node_kernels.hpp", "bp_team_kernels.hpp", "latency_mode.hpp",
                                              "bpots_kernels.hpp", "portable_math.h", "Makefile")]
     srcs.append(os.path.join(_HERE, "..", "include", "ldpc_mi355x.h"))
-    stale = (not os.path.exists(LIB_PATH)) or any(
-        os.path.getmtime(f) > os.path.getmtime(LIB_PATH) for f in srcs if os.path.exists(f))
-    if force or stale:
-        subprocess.check_call(["make", "-s", "-C", CSRC, "libldpc_mi355x.so"])
+    srcs.append(os.path.join(_HERE, "..", "include", "ldpc_mi355x_debug.h"))
+    for target in (LIB_PATH, EXP_LIB_PATH):
+        stale = (not os.path.exists(target)) or any(
+            os.path.getmtime(f) > os.path.getmtime(target) for f in srcs if os.path.exists(f))
+        if force or stale:
+            subprocess.check_call(["make", "-s", "-C", CSRC, "all"])
+            break
     return LIB_PATH
 
 
-_LIB = None
+_LIBS = {}
 
 
 def _one_hip_runtime() -> None:
@@ -110,16 +135,17 @@ def _one_hip_runtime() -> None:
         pass
 
 
-def lib() -> ctypes.CDLL:
-    """Load the HIP library; raises (never falls back) if it is not built."""
-    global _LIB
-    if _LIB is not None:
-        return _LIB
-    if not os.path.exists(LIB_PATH):
-        raise LdpcError(2, f"{LIB_PATH} is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
+def lib(experiments: bool = False) -> ctypes.CDLL:
+    """Load the HIP library; raises (never falls back) if it is not built.  experiments=True: the build with the
+    environment knobs and the fault injection (tests, tools); both builds may live in one process."""
+    if experiments in _LIBS:
+        return _LIBS[experiments]
+    path = EXP_LIB_PATH if experiments else LIB_PATH
+    if not os.path.exists(path):
+        raise LdpcError(2, f"{path} is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "or `make -C ldpcdecoders.jl_amd/csrc`. There is no CPU fallback.")
     _one_hip_runtime()
-    L = ctypes.CDLL(LIB_PATH)
+    L = ctypes.CDLL(path)
     vp, i64, i32, f64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_double
     L.ldpc_abi_version.restype = i32
     L.ldpc_build_target.restype = ctypes.c_char_p
@@ -129,7 +155,21 @@ def lib() -> ctypes.CDLL:
     L.ldpc_debug_team_plan.restype = i32
     L.ldpc_debug_team_plan.argtypes = [i64, i64, i64, i32, i32, ctypes.POINTER(i32 * 6)]
     L.ldpc_debug_team_rows.restype = i32
-    L.ldpc_debug_team_rows.argtypes = [i64, i64, vp, vp, i32, ctypes.POINTER(i32), vp, vp, vp]
+    L.ldpc_debug_team_rows.argtypes = [i64, i64, vp, vp, i32, ctypes.POINTER(i32 * 2), ctypes.POINTER(i32), ctypes.POINTER(i32), vp, vp, vp]
+    L.ldpc_bp_create_multi.restype = i32
+    L.ldpc_bp_create_multi.argtypes = [i32, ctypes.POINTER(i32), i32, i64, i64, i64, vp, vp, f64, i64, ctypes.POINTER(BPOptions), ctypes.POINTER(vp)]
+    L.ldpc_bp_destroy_multi.restype = i32
+    L.ldpc_bp_destroy_multi.argtypes = [vp]
+    L.ldpc_bp_multi_handle.restype = vp
+    L.ldpc_bp_multi_handle.argtypes = [vp, i32]
+    L.ldpc_bp_decode_batch_multi.restype = i32
+    L.ldpc_bp_decode_batch_multi.argtypes = [vp, i64, vp, vp, vp, vp, vp]
+    L.ldpc_bp_decode_batch_multi_device.restype = i32
+    L.ldpc_bp_decode_batch_multi_device.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
+    L.ldpc_bp_multi_last_status.restype = i32
+    L.ldpc_bp_multi_last_status.argtypes = [vp]
+    L.ldpc_bp_multi_get_info.restype = i32
+    L.ldpc_bp_multi_get_info.argtypes = [vp, ctypes.POINTER(BPMultiInfo)]
     L.ldpc_bp_create.restype = i32
     L.ldpc_bp_create.argtypes = [i64, i64, i64, vp, vp, f64, i64, ctypes.POINTER(BPOptions), ctypes.POINTER(vp)]
     L.ldpc_bp_destroy.restype = i32
@@ -164,10 +204,21 @@ def lib() -> ctypes.CDLL:
     L.ldpc_bpots_decode_batch.argtypes = [vp, i64, vp, vp, vp, vp]
     L.ldpc_bpots_decode_batch_device.restype = i32
     L.ldpc_bpots_decode_batch_device.argtypes = [vp, i64, vp, vp, vp, vp, vp]
-    _LIB = L
+    _LIBS[experiments] = L
     return L
 
 
-def check(status: int) -> None:
+def knobs_in_env() -> bool:
+    """Is any of the library's experiment knobs (LDPC_TEAM_*, LDPC_DEFER_*, ... DESIGN.md "Environment knobs") set?"""
+    return any(k.startswith("LDPC_") and not k.startswith("LDPC_MI355X_") for k in os.environ)
+
+
+def lib_for(experiments=None) -> ctypes.CDLL:
+    """The library a new decoder binds: the product build, unless the caller asks for the experiments build or has
+    set one of its knobs in the environment (only that build reads them)."""
+    return lib(knobs_in_env() if experiments is None else bool(experiments))
+
+
+def check(status: int, L: ctypes.CDLL = None) -> None:
     if status != LDPC_OK:
-        raise LdpcError(status, lib().ldpc_last_error().decode("utf-8", "replace"))
+        raise LdpcError(status, (L or lib()).ldpc_last_error().decode("utf-8", "replace"))

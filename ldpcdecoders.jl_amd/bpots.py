@@ -14,7 +14,7 @@ from .decoder import AbstractDecoder, _pattern_of, syndrome_bytes
 class BPOTSDecoder(AbstractDecoder):
     """`BPOTSDecoder(H, per::Float64, max_iters::Int; T::Int=9, C::Float64=2.0)`."""
 
-    def __init__(self, H, per: float, max_iters: int, *, T: int = 9, C: float = 2.0, device=None):
+    def __init__(self, H, per: float, max_iters: int, *, T: int = 9, C: float = 2.0, device=None, experiments=None):
         if not isinstance(per, float):
             raise TypeError("per must be a Float64")
         M = _pattern_of(H)
@@ -24,19 +24,20 @@ class BPOTSDecoder(AbstractDecoder):
         colptr = np.ascontiguousarray(M.indptr, dtype=np.int64)
         rowval = np.ascontiguousarray(M.indices, dtype=np.int64)
         self._h = ctypes.c_void_p()
-        _capi.check(_capi.lib().ldpc_bpots_create(self.s, self.n, int(rowval.size), colptr.ctypes.data,
+        self._L = _capi.lib_for(experiments)
+        _capi.check(self._L.ldpc_bpots_create(self.s, self.n, int(rowval.size), colptr.ctypes.data,
                                                   rowval.ctypes.data, self.per, self.max_iters, self.T, self.C,
-                                                  -1 if device is None else int(device), ctypes.byref(self._h)))
+                                                  -1 if device is None else int(device), ctypes.byref(self._h)), self._L)
 
     @property
     def kernel(self) -> int:
         """2 = LDS-resident kernel, 3 = node-parallel kernel with the messages in a global slot (ldpc_bpots_kernel)."""
-        return int(_capi.lib().ldpc_bpots_kernel(self._h))
+        return int(self._L.ldpc_bpots_kernel(self._h))
 
     def close(self) -> None:
         h, self._h = getattr(self, "_h", None), None
         if h:
-            _capi.lib().ldpc_bpots_destroy(h)
+            self._L.ldpc_bpots_destroy(h)
 
     def __del__(self):
         try:
@@ -53,8 +54,8 @@ class BPOTSDecoder(AbstractDecoder):
         err = np.empty((B, self.n), dtype=np.uint8)
         conv = np.empty(B, dtype=np.uint8)
         its = np.empty(B, dtype=np.int32)
-        _capi.check(_capi.lib().ldpc_bpots_decode_batch(self._h, B, syn.ctypes.data, err.ctypes.data,
-                                                        conv.ctypes.data, its.ctypes.data))
+        _capi.check(self._L.ldpc_bpots_decode_batch(self._h, B, syn.ctypes.data, err.ctypes.data,
+                                                    conv.ctypes.data, its.ctypes.data), self._L)
         return err, conv, its
 
     def decode_(self, syndrome) -> Tuple[np.ndarray, bool]:

@@ -50,10 +50,11 @@
 
 namespace ldpc {
 
-// Rows in LDS (instantiations with LROWS; regular graphs of the (8,4) bucket).  A member decodes the same share of
+// Rows in LDS (instantiations with LROWS: REGULAR graphs, every check exactly DC edges and every bit exactly DV --
+// (3,6), (4,8), (5,10): team_rows_degrees_ok()).  A member decodes the same share of
 // the checks AND of the bits in every iteration, so an edge whose check and whose bit are both its own is never touched
 // by anybody else: its message row can live in the member's LDS instead of the team's slot.  The host deals the bits
-// to the members by the graph (team_rows_build(): a bit goes to a member that owns one of its checks -- a quarter of
+// to the members by the graph (team_rows_build(): a bit goes to a member that owns one of its checks -- 1 / DV of
 // the edges become such) and gives the kernel the bit order, per check which of its edges are in LDS and from which
 // LDS row on, per edge of a bit its LDS row or -1.  156 KiB of LDS hold R = 312 rows of 512 B per member: 15 % of a
 // tile of the n = 16384 code -- that much less traffic through the XCD's port (full batch 1.013 -> 0.957 s).
@@ -61,9 +62,49 @@ namespace ldpc {
 // read through a pointer in a struct they became vector loads, one wait each, and the variable sweep took twice as long):
 //   col_ptr  -> ctab [s][2]   per check: which of its edges are in LDS (bit k = edge k), the LDS row of the first of
 //                             them (they follow each other)
-//   csc2csr  -> vtab [n][16]  per position p of the dealt bit order: CSR rows of its 4 edges, their LDS rows or -1, the
-//                             bit (| 1 << 31 when one of its edges is in LDS), 7 words of padding
-constexpr int kTeamVtab = 16;
+//   csc2csr  -> vtab [n][VT]  per position p of the dealt bit order: CSR rows of its DV edges, their LDS rows or -1, the
+//                             bit (| 1 << 31 when one of its edges is in LDS), padding to VT = 8 or 16 words
+__host__ __device__ constexpr int team_vtab_words(int dv) { return 2 * dv + 1 <= 8 ? 8 : 16; }
+// the degree pairs that have a rows-in-LDS instantiation (pick_team.hip)
+__host__ __device__ constexpr bool team_rows_degrees_ok(int dc, int dv) { return (dc == 6 && dv == 3) || (dc == 8 && dv == 4) || (dc == 10 && dv == 5); }
+
+// One position record of vtab, read with as few scalar loads as its width allows (words 0 ... 7 in one, the rest in one more).
+template <int DV>
+struct TeamVRec {
+    int pos[DV], lrow[DV], bit;
+};
+template <int DV>
+__device__ __forceinline__ TeamVRec<DV> team_vrec_load(const int *__restrict__ vt)
+{
+    static_assert(2 * DV + 1 <= 16, "a position record is at most 16 words");
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef int v8i __attribute__((ext_vector_type(8)));
+    constexpr int N = 2 * DV + 1;
+    int w[16];
+    const v8i A = *(const v8i *)vt;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = A[k];
+    if constexpr (N == 9) {
+        w[8] = vt[8];
+    } else if constexpr (N > 8 && N <= 10) {
+        const v2i B = *(const v2i *)(vt + 8);
+        w[8] = B[0]; w[9] = B[1];
+    } else if constexpr (N > 10 && N <= 12) {
+        const v4i B = *(const v4i *)(vt + 8);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[8 + k] = B[k];
+    } else if constexpr (N > 12) {
+        const v8i B = *(const v8i *)(vt + 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[8 + k] = B[k];
+    }
+    TeamVRec<DV> rc;
+#pragma unroll
+    for (int k = 0; k < DV; ++k) { rc.pos[k] = w[k]; rc.lrow[k] = w[DV + k]; }
+    rc.bit = w[2 * DV];
+    return rc;
+}
 struct TeamRows {
     const int *lds_edge;        // [G][R]  CSR rows held by each member, -1 beyond its count (write-back before a hand-off)
     int R;                      // LDS rows per member
@@ -90,14 +131,18 @@ struct TeamParams {
     // device; the pass runs only for p.count_skip < *count_dev <= count_max (fewer: node kernel, more: the tile
     // kernel on the packed tiles), and its teams work IN the packed tiles (slot = tile).
     unsigned int count_max;
-    int inject_fault;           // tests: raise the fault word and leave at once, as if a team barrier had timed out
+    int inject_fault;           // experiments build only (tests): 1 = raise the fault word and leave at once, as if a team
+                                // barrier had timed out; 2 = the last member of team 0 stays away from the roll call
     unsigned int ticket;        // what a timed-out barrier writes into the fault word: the number of this call on its
-                                // handle (never 0), so that the report can name the first call that was hit
+                                // handle (low 31 bits, never 0), so that the report can name the first call that was hit;
+                                // bit 31 set = the ROLL CALL failed: the call wrote no output at all
+    unsigned int rollcall_ticks;   // how long (100 MHz ticks) the members of a team wait for each other at launch
 };
+constexpr unsigned int kTeamRollcallFailed = 0x80000000u;
 
 // Team barrier number k (1, 2, ...).  Control block of a team: arrival counter at word 0; XCC mask, hand-off word
-// and next-tile word at words 32, 33, 34; one 128-byte line per member holding the number of the last barrier it
-// was released from.
+// and next-tile word at words 32, 33, 34; roll-call word at 36 (team_rollcall); one 128-byte line per member holding
+// the number of the last barrier it was released from.
 // The last arriver (it knows from the value its add returned) writes k into every member's line; the
 // others poll THEIR OWN line.  (All members polling the one counter cost O(G^2) memory requests per
 // barrier -- every add drops the line from every poller's L2 -- and with 8 ... 16 teams that storm took
@@ -148,6 +193,48 @@ __device__ __forceinline__ bool team_barrier(unsigned int *ctl, int G, int rank,
         *sh_ok = ok;
         sh_deal[0] = 0u;   // no wave of this workgroup is inside a sweep here: the dealers start afresh
         sh_deal[1] = 0u;
+    }
+    __syncthreads();
+    return *sh_ok != 0;
+}
+
+// Launch-time residency handshake.  A team barrier only works when all G members are on the machine at once.  The
+// host sizes the grid so that they fit and never runs two team grids of one process together, but it cannot see what
+// OTHER processes have put on the GPU: a member may be waiting for a CU that a foreign kernel holds.  So the first
+// thing a team does is a roll call with a SHORT bound (tp.rollcall_ticks: milliseconds): every member adds itself to
+// the team's roll-call word and waits until all G are counted.  A member that runs out of patience marks the word
+// DEAD -- by compare-and-swap, which can only succeed while the count is still short, so "dead" and "complete" exclude
+// each other -- raises the fault word (ticket | kTeamRollcallFailed) and leaves; every other member sees the mark (a
+// late arriver in the value its add returns) and leaves too.  Nothing has been read or written at that point: the
+// host decodes the batch with the tile kernel, which needs no co-residency, instead of finding out from a barrier
+// that times out after 10 s.  Co-tenancy with other processes' kernels therefore costs throughput, not correctness.
+__device__ __forceinline__ bool team_rollcall(unsigned int *word, int G, unsigned int *fault, unsigned int ticket,
+                                              unsigned int ticks, int *sh_ok)
+{
+    constexpr unsigned int DEAD = 0x80000000u;
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        const unsigned int prev = __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev & DEAD) {
+            ok = 0;                                            // somebody gave up before this member got a CU
+        } else if (prev + 1u != (unsigned)G) {
+            const u64 t0 = wall_clock64();
+            for (unsigned int polls = 1;; ++polls) {
+                unsigned int c = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (c & DEAD) { ok = 0; break; }
+                if (c >= (unsigned)G) break;                   // everybody is here
+                __builtin_amdgcn_s_sleep(8);
+                if ((polls & 31u) == 0u && wall_clock64() - t0 > (u64)ticks) {
+                    bool dead = false;
+                    while (c < (unsigned)G && !dead)           // (c is refreshed by a failed exchange)
+                        dead = __hip_atomic_compare_exchange_strong(word, &c, c | DEAD, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                    __HIP_MEMORY_SCOPE_AGENT);
+                    if (dead) __hip_atomic_store(fault, ticket | kTeamRollcallFailed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (dead || (c & DEAD)) { ok = 0; break; }
+                }
+            }
+        }
+        *sh_ok = ok;
     }
     __syncthreads();
     return *sh_ok != 0;
@@ -239,10 +326,12 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     const double r = p.r;
     if (threadIdx.x == 0) { sh_deal[0] = 0u; sh_deal[1] = 0u; }
     __syncthreads();
-    if (tp.inject_fault) {
+#ifdef LDPC_EXPERIMENTS
+    if (tp.inject_fault == 1) {
         if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(tp.fault, tp.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
+#endif
     const int G = tp.G, nteams = tp.nteams;
     int ntiles = p.ntiles;
     long long batch = p.batch;
@@ -265,6 +354,10 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     unsigned int *const tile_queue = tp.ctl + (size_t)nteams * kTeamCtlWords;
     unsigned int epoch = 0;                                    // barriers passed
     __shared__ int sh_one_xcd;
+#ifdef LDPC_EXPERIMENTS
+    if (tp.inject_fault == 2 && team == 0 && rank == G - 1) return;   // (tests) a member that never gets its CU
+#endif
+    if (!team_rollcall(ctr + 36, G, tp.fault, tp.ticket, tp.rollcall_ticks, &sh_ok)) return;
     if (threadIdx.x == 0) {
         unsigned int xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -387,47 +480,38 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
                 int j = c * vb;
                 if constexpr (LROWS) {
                     // positions of the dealt bit order; every bit has the full degree; csc2csr is vtab.  Everything the
-                    // table says about two positions is asked for at once (one scalar round trip per pair, not two)
-                    static_assert(DV == 4, "the table has four edges per position");
-                    typedef int v8i __attribute__((ext_vector_type(8)));
-                    auto single = [&](int b, const int (&pos)[4], const int (&lrow)[4]) {
-                        if (b >= 0) decide(b, bit_update_exact_v<DV>(Mt, pos, r));
-                        else decide(b & 0x7fffffff, bit_update_mixed<DV>(Mt, Lr, pos, lrow, r));
+                    // table says about the four positions of a chunk is asked for at once (one scalar round trip per chunk)
+                    constexpr int VT = team_vtab_words(DV);
+                    auto single = [&](const TeamVRec<DV> &a) {
+                        if (a.bit >= 0) decide(a.bit, bit_update_exact_v<DV>(Mt, a.pos, r));
+                        else decide(a.bit & 0x7fffffff, bit_update_mixed<DV>(Mt, Lr, a.pos, a.lrow, r));
                     };
-                    auto two = [&](const v8i &A, int b0, const v8i &B, int b1) {
-                        const int pos0[4] = {A.s0, A.s1, A.s2, A.s3}, lrow0[4] = {A.s4, A.s5, A.s6, A.s7};
-                        const int pos1[4] = {B.s0, B.s1, B.s2, B.s3}, lrow1[4] = {B.s4, B.s5, B.s6, B.s7};
-                        if ((b0 | b1) >= 0 && tp.pairs) {       // neither has a row in LDS: both loaded together
+                    auto two = [&](const TeamVRec<DV> &a, const TeamVRec<DV> &b) {
+                        if ((a.bit | b.bit) >= 0 && tp.pairs) {   // neither has a row in LDS: both loaded together
                             double T0, T1;
-                            bit_update_pair_v<DV>(Mt, pos0, pos1, r, T0, T1);
-                            decide(b0, T0);
-                            decide(b1, T1);
+                            bit_update_pair_v<DV>(Mt, a.pos, b.pos, r, T0, T1);
+                            decide(a.bit, T0);
+                            decide(b.bit, T1);
                         } else {
-                            single(b0, pos0, lrow0);
-                            single(b1, pos1, lrow1);
+                            single(a);
+                            single(b);
                         }
                     };
                     int q = j;
                     if (q + 4 == j1) {                          // the usual chunk: the table rows of all four positions at once
-                        const int *const vt = csc2csr + (size_t)q * kTeamVtab;
-                        const v8i A = *(const v8i *)vt, B = *(const v8i *)(vt + kTeamVtab), C = *(const v8i *)(vt + 2 * kTeamVtab),
-                                  D = *(const v8i *)(vt + 3 * kTeamVtab);
-                        const int b0 = vt[8], b1 = vt[kTeamVtab + 8], b2 = vt[2 * kTeamVtab + 8], b3 = vt[3 * kTeamVtab + 8];
-                        two(A, b0, B, b1);
-                        two(C, b2, D, b3);
+                        const int *const vt = csc2csr + (size_t)q * VT;
+                        const TeamVRec<DV> A = team_vrec_load<DV>(vt), B = team_vrec_load<DV>(vt + VT), C = team_vrec_load<DV>(vt + 2 * VT),
+                                           D = team_vrec_load<DV>(vt + 3 * VT);
+                        two(A, B);
+                        two(C, D);
                         return;
                     }
                     for (; q + 1 < j1; q += 2) {
-                        const int *const vt = csc2csr + (size_t)q * kTeamVtab;
-                        const v8i A = *(const v8i *)vt, B = *(const v8i *)(vt + kTeamVtab);
-                        two(A, vt[8], B, vt[kTeamVtab + 8]);
+                        const int *const vt = csc2csr + (size_t)q * VT;
+                        const TeamVRec<DV> A = team_vrec_load<DV>(vt), B = team_vrec_load<DV>(vt + VT);
+                        two(A, B);
                     }
-                    for (; q < j1; ++q) {
-                        const int *const vt = csc2csr + (size_t)q * kTeamVtab;
-                        const v8i A = *(const v8i *)vt;
-                        const int pos0[4] = {A.s0, A.s1, A.s2, A.s3}, lrow0[4] = {A.s4, A.s5, A.s6, A.s7};
-                        single(vt[8], pos0, lrow0);
-                    }
+                    for (; q < j1; ++q) single(team_vrec_load<DV>(csc2csr + (size_t)q * VT));
                     return;
                 }
                 for (; tp.pairs && j + 1 < j1; j += 2) {           // two bits of the full degree: all 2 DV rows in flight at once

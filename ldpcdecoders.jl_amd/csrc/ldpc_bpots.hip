@@ -7,6 +7,7 @@
 // LDPC_ERR_UNSUPPORTED.  No CPU path.
 #include "../../include/ldpc_mi355x.h"
 #include "bpots_kernels.hpp"
+#include "host_env.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -137,7 +138,7 @@ ldpc_status ldpc_bpots_create(int64_t s, int64_t n, int64_t nnz, const int64_t *
         return set_error(LDPC_ERR_UNSUPPORTED, "BP-OTS kernels: check degree <= 32 and bit degree <= 16");
     }
     d->logS = -1;
-    const bool force_node = std::getenv("LDPC_BPOTS_FORCE_NODE") != nullptr;   // tests (read at create): small graphs through the node kernel
+    const bool force_node = exp_env("LDPC_BPOTS_FORCE_NODE") != nullptr;   // tests (read at create): small graphs through the node kernel
     if (!force_node && nnz < 65535 && s < 65535 && n < 65535)   // (uint16 graph copies in LDS)
         for (int l = 0; l <= 6; ++l) {
             const size_t b = ots_lds_bytes((int)s, (int)n, (int)nnz, 1 << l) + 8192;
@@ -287,7 +288,7 @@ ldpc_status ldpc_bpots_decode_batch(ldpc_bpots_decoder *d, int64_t batch, const 
     const size_t s = (size_t)d->s, n = (size_t)d->n, B = (size_t)batch;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o_err = up(B * s), o_conv = o_err + up(B * n), o_it = o_conv + up(B), total = o_it + up(B * 4);
-    static const bool lat_off = std::getenv("LDPC_NO_LATENCY_PATH") != nullptr;
+    static const bool lat_off = exp_env("LDPC_NO_LATENCY_PATH") != nullptr;
     const int64_t lat_groups = d->node_mode ? batch : (batch + (1ll << d->logS) - 1) >> d->logS;
     if (!d->node_mode && !lat_off && total <= ((size_t)256 << 10) && d->max_iters > 0 && lat_groups <= 2 * (int64_t)d->num_cus) {
         const size_t hdr = 256;

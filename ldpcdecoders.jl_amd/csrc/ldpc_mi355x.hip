@@ -10,12 +10,14 @@
 // There is deliberately no CPU path in this file: if HIP or the device is not
 // usable every compute entry fails with a status code.
 #include "../../include/ldpc_mi355x.h"
+#include "../../include/ldpc_mi355x_debug.h"
 #define LDPC_AUX_KERNELS 1
 #include "bp_kernels.hpp"
 #include "bp_lds_kernels.hpp"
 #include "bp_node_kernels.hpp"
 #include "bp_team_kernels.hpp"
 #include "pickers.hpp"
+#include "host_env.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -60,24 +62,46 @@ namespace {
         }                                                                                      \
     } while (0)
 
+// Current device of the calling thread, put back when the scope ends (pool eviction and the multi-device entries
+// switch devices; the caller's choice must survive them).
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; } }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 // A chunk group: physical chunks (hipMemCreate) mapped side by side -- each by ONE hipMemMap, access granted mapping by
 // mapping -- at an aligned base inside a virtual reservation of its own.  This is how every message array of >= 1 GiB is
-// backed (DESIGN.md "Workspace placement").  What it took to make ROCm 7.2's virtual-memory path dependable (round 2):
-//   * A kernel touching a freshly mapped group died of "Memory access fault ... Reason: Unknown" now and then -- in the
-//     LAST chunk of the group, in about one process out of six of tools/team_fault_hunt2.sh (decoders of growing size
-//     one after the other), three sessions out of three.  Not a race (a device synchronise and 3 ms of sleep after the
-//     mapping changed nothing), not release / create churn (it happened with the pool below, i.e. with nothing
-//     unmapped or released before).  What all incidents shared: the new reservation lay where hipMalloc'd buffers --
-//     torch's or the library's own -- had lived and been freed.  A range that has been mapped before is a RE-mapped
-//     range whoever mapped it first, and re-mapped ranges are what faulted in tools/vmm_probe2.hip too.  Reservations
-//     are therefore asked for in an address region of their own (hint: 16 TiB upwards, far below hipMalloc's arena; the
-//     runtime honours it) and never given back (hipMemAddressFree): 16 of 16 processes clean afterwards.  Address space
-//     is not memory: a reservation of an unmapped range costs nothing, and there are 47 bits of it.
+// backed (DESIGN.md "Workspace placement").  What it took to make ROCm 7.2's virtual-memory path dependable:
+//   * Round 2: a kernel touching a freshly mapped group died of "Memory access fault ... Reason: Unknown" in about one
+//     process out of six of tools/team_fault_hunt2.sh.  The faulting addresses (gpurun_out/s30, s33, s34 of round 2) are
+//     base + 1 GiB + 0xfb3000 of a 2-chunk group (32 slots: row 33,921 of slot 31) and base + 2 GiB + 0xfb3000 of a
+//     3-chunk group (64 slots: row 35,690 of slot 62), s35 base + 2 GiB + 0xe1f000: the SAME offset into the last chunk
+//     for different rows, slots and group sizes -- a property of a page of the address range, not of the kernel's
+//     indexing.  Not a race (a device synchronise and 3 ms of sleep after the mapping changed nothing).  What all
+//     incidents shared: the reservation lay where hipMalloc'd buffers of the same process -- the script's earlier,
+//     smaller workspaces and torch's tensors, whose sizes and hence addresses repeat from process to process -- had
+//     lived and been freed.  That is what a deferred unmap of a freed range does when it is applied AFTER the range has
+//     been mapped again: it clears the new mapping's entries from the old buffer's first page on.  A range that has
+//     been mapped before is a RE-mapped range whoever mapped it first (tools/vmm_probe2.hip faulted the same way on its
+//     own re-mappings).
+//   * Hence the rule this code ENFORCES (round 3): a group is only ever mapped into an address window of its own
+//     (16 ... 64 TiB, far below where hipMalloc and mmap hand out addresses), at addresses that a monotonic cursor
+//     hands out ONCE per process.  A reservation that does not land where it was asked for is given back and the
+//     buffer falls back to hipMalloc (big_alloc() -> LDPC_ERR_UNSUPPORTED); so does a request once the window is used
+//     up.  No un-hinted reservation is ever mapped.  Since no address is handed out twice, a destroyed group's
+//     reservation can be given back (hipMemAddressFree) without ever being mapped again: address space is bounded by
+//     the live groups, and the cursor (48 TiB) by ~1,900 workspaces of the C3 size per process.
 //   * Groups are POOLED per process: a buffer that is released hands its group, still mapped, to the pool, and the next
 //     buffer of that size takes it over -- a process that keeps using the same few sizes creates each group once, and a
-//     group that has been probed carries its grade, so a later workspace of that size skips the placement search.  The
-//     pool holds at most LDPC_POOL_GIB (64) GiB; beyond that the oldest group is really unmapped and released (with the
-//     device idle); an allocation that runs out of memory empties it, and so does ldpc_trim_memory().
+//     group that has been probed carries its grade, so a later workspace of that size skips the placement search.  A
+//     group enters the pool only after its device has been synchronised (nothing enqueued may still use it).  The
+//     pool holds at most 64 GiB; beyond that the oldest group is really unmapped and released; an allocation that
+//     runs out of memory empties it, and so does ldpc_trim_memory().
+constexpr uintptr_t kVmmWindowLo = (uintptr_t)16 << 40, kVmmWindowHi = (uintptr_t)64 << 40;
+
+static bool vmm_log() { static const bool v = exp_env("LDPC_VMM_LOG") != nullptr; return v; }
+
 struct ChunkGroup {
     void *resv = nullptr;
     size_t resv_size = 0;
@@ -89,14 +113,17 @@ struct ChunkGroup {
     size_t probe_bytes = 0;                  // ... of this many bytes
     size_t bytes() const { return chunk * mapped; }
     bool empty() const { return resv == nullptr; }
-    void destroy()                           // really give the memory back (device idle: see above)
+    void destroy()                           // really give the memory and the address range back (device idle: see above)
     {
         if (!resv) return;
+        DeviceGuard guard;
+        (void)hipSetDevice(device);
         (void)hipDeviceSynchronize();
-        if (std::getenv("LDPC_VMM_LOG")) std::fprintf(stderr, "[ldpc-vmm] unmap %p .. %p\n", (void *)base, (void *)(base + bytes()));
+        if (vmm_log()) std::fprintf(stderr, "[ldpc-vmm] unmap %p .. %p\n", (void *)base, (void *)(base + bytes()));
         for (size_t k = 0; k < mapped; ++k) (void)hipMemUnmap(base + k * chunk, chunk);   // one unmap per map
         for (auto q : h) (void)hipMemRelease(q);
         (void)hipDeviceSynchronize();
+        (void)hipMemAddressFree(resv, resv_size);   // never handed out again: the cursor only moves up
         (void)hipGetLastError();
         h.clear();
         resv = nullptr; base = nullptr;
@@ -110,7 +137,7 @@ std::vector<ChunkGroup> g_pool;   // oldest first
 
 size_t pool_cap_bytes()
 {
-    static const size_t v = [] { const char *e = std::getenv("LDPC_POOL_GIB"); return (size_t)(e ? std::max(0, std::atoi(e)) : 64) << 30; }();
+    static const size_t v = [] { const char *e = exp_env("LDPC_POOL_GIB"); return (size_t)(e ? std::max(0, std::atoi(e)) : 64) << 30; }();
     return v;
 }
 void pool_put(ChunkGroup &&g)
@@ -122,7 +149,6 @@ void pool_put(ChunkGroup &&g)
     for (const ChunkGroup &q : g_pool) total += q.bytes();
     while (total > pool_cap_bytes() && !g_pool.empty()) {
         total -= g_pool.front().bytes();
-        (void)hipSetDevice(g_pool.front().device);
         g_pool.front().destroy();
         g_pool.erase(g_pool.begin());
     }
@@ -147,8 +173,21 @@ bool pool_take(size_t bytes, size_t chunk, int device, ChunkGroup *out)
 void pool_drop_all()
 {
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    for (ChunkGroup &q : g_pool) { (void)hipSetDevice(q.device); q.destroy(); }
+    for (ChunkGroup &q : g_pool) q.destroy();
     g_pool.clear();
+}
+
+// The next address of the private window for a reservation of `bytes` (a multiple of `align`), or 0 when the window is
+// used up (or switched off: LDPC_VMM_HINT_TIB=0 in the experiments build) -- the caller then does without a chunk group.
+uintptr_t vmm_next_address(size_t bytes, size_t align)
+{
+    static const uintptr_t lo = [] { const char *e = exp_env("LDPC_VMM_HINT_TIB"); return e ? (uintptr_t)std::atoll(e) << 40 : kVmmWindowLo; }();
+    static std::atomic<uintptr_t> cursor{lo};
+    if (lo == 0) return 0;
+    const uintptr_t step = ((uintptr_t)bytes + 2 * align + align - 1) / align * align;   // (a gap between neighbours)
+    const uintptr_t at = cursor.fetch_add(step);
+    if (at < lo || at + step > std::max(kVmmWindowHi, lo + ((uintptr_t)1 << 40))) return 0;
+    return at;
 }
 }  // namespace
 
@@ -176,7 +215,8 @@ struct DevBuf {
     }
     // A chunk group of at least `bytes`: out of the pool (unless `fresh`: the placement search wants OTHER physical
     // memory than what it has seen) or newly created -- chunks of `chunk` bytes, base aligned to `align`; `shuffle` maps
-    // them in a scrambled order (experiments).
+    // them in a scrambled order (experiments).  LDPC_ERR_UNSUPPORTED: no chunk group to be had under the rules above
+    // (the caller uses hipMalloc).
     ldpc_status ensure_chunked(size_t bytes, size_t chunk, size_t align, bool shuffle, int device, bool fresh = false)
     {
         if (bytes <= cap) return LDPC_OK;
@@ -187,18 +227,20 @@ struct DevBuf {
             return LDPC_OK;
         }
         for (int attempt = 0; attempt < 2; ++attempt) {
-            const hipError_t e = create(bytes, chunk, align, shuffle, device);
+            bool refused = false;
+            const hipError_t e = create(bytes, chunk, align, shuffle, device, &refused);
             if (e == hipSuccess) return LDPC_OK;
             (void)hipGetLastError();
             grp.destroy();
             p = nullptr; cap = 0;
+            if (refused) return fail(LDPC_ERR_UNSUPPORTED, "chunk group: no address range of the private window to be had");
             if (e != hipErrorOutOfMemory || attempt == 1)
                 return fail(e == hipErrorOutOfMemory ? LDPC_ERR_OUT_OF_MEMORY : LDPC_ERR_HIP, std::string("chunk group: ") + hipGetErrorString(e));
             pool_drop_all();   // out of memory: what the pool holds may be what is missing
         }
         return LDPC_ERR_OUT_OF_MEMORY;
     }
-    hipError_t create(size_t bytes, size_t chunk, size_t align, bool shuffle, int device)
+    hipError_t create(size_t bytes, size_t chunk, size_t align, bool shuffle, int device, bool *refused)
     {
         hipMemAllocationProp prop = {};
         prop.type = hipMemAllocationTypePinned;
@@ -210,18 +252,22 @@ struct DevBuf {
         const size_t n = (bytes + chunk - 1) / chunk;
         grp = ChunkGroup();
         grp.device = device;
-        // Reservations are asked for in an address region of their own, far below where hipMalloc hands out
-        // addresses: a range that hipMalloc / hipFree (ours or torch's) has used before is a RE-mapped range too.
-        static std::atomic<uintptr_t> next_hint{[] { const char *e = std::getenv("LDPC_VMM_HINT_TIB"); return (uintptr_t)(e ? std::atoll(e) : 16) << 40; }()};
-        const uintptr_t hint = next_hint.fetch_add((n * chunk + 2 * align + align - 1) / align * align);
-        hipError_t e = hipMemAddressReserve(&grp.resv, n * chunk + align, 0, hint ? (void *)hint : nullptr, 0);
-        if (e != hipSuccess) {   // (the hint is a wish: without it the runtime picks)
+        // An address of the private window, used once; a reservation that lands anywhere else is given back unmapped.
+        const size_t want = n * chunk + align;
+        const uintptr_t hint = vmm_next_address(want, align);
+        if (!hint) { *refused = true; return hipErrorInvalidValue; }
+        void *got = nullptr;
+        hipError_t e = hipMemAddressReserve(&got, want, 0, (void *)hint, 0);
+        if (e != hipSuccess) { (void)hipGetLastError(); *refused = true; return e; }
+        if (vmm_log()) std::fprintf(stderr, "[ldpc-vmm] reserve hint %p -> %p\n", (void *)hint, got);
+        if ((uintptr_t)got != hint) {
+            (void)hipMemAddressFree(got, want);
             (void)hipGetLastError();
-            e = hipMemAddressReserve(&grp.resv, n * chunk + align, 0, nullptr, 0);
+            *refused = true;
+            return hipErrorInvalidValue;
         }
-        if (e != hipSuccess) { grp.resv = nullptr; return e; }
-        if (std::getenv("LDPC_VMM_LOG")) std::fprintf(stderr, "[ldpc-vmm] reserve hint %p -> %p\n", (void *)hint, grp.resv);
-        grp.resv_size = n * chunk + align;
+        grp.resv = got;
+        grp.resv_size = want;
         grp.chunk = chunk;
         grp.base = (char *)(((uintptr_t)grp.resv + align - 1) / align * align);
         for (size_t k = 0; k < n; ++k) {
@@ -242,7 +288,7 @@ struct DevBuf {
         }
         p = grp.base;
         cap = n * chunk;
-        if (std::getenv("LDPC_VMM_LOG")) std::fprintf(stderr, "[ldpc-vmm] map   %p .. %p (%zu chunks)\n", (void *)grp.base, (void *)(grp.base + cap), n);
+        if (vmm_log()) std::fprintf(stderr, "[ldpc-vmm] map   %p .. %p (%zu chunks)\n", (void *)grp.base, (void *)(grp.base + cap), n);
         return hipSuccess;
     }
     void swap(DevBuf &o)
@@ -253,8 +299,15 @@ struct DevBuf {
     }
     void release()
     {
-        if (!grp.empty()) pool_put(std::move(grp));
-        else if (p) (void)hipFree(p);
+        if (!grp.empty()) {
+            // hipFree waits for the device by itself; a group that goes to the pool still mapped must do so explicitly:
+            // kernels of earlier asynchronous calls may still be using it when the next owner takes it over
+            DeviceGuard guard;
+            (void)hipSetDevice(grp.device);
+            (void)hipDeviceSynchronize();
+            (void)hipGetLastError();
+            pool_put(std::move(grp));
+        } else if (p) (void)hipFree(p);
         grp = ChunkGroup();
         p = nullptr;
         cap = 0;
@@ -307,6 +360,7 @@ struct ldpc_bp_decoder {
     // the tables are built for the member count of the first persistent launch (team_rows_build())
     std::vector<int> h_csc2csr;
     bool team_rows_on = true;         // LDPC_TEAM_ROWS at create (0 = every row in the slot)
+    int rows_dc = 0, rows_dv = 0;     // the graph's (check, bit) degree when it is regular and has a rows-in-LDS instantiation
     int rows_G = 0, rows_R = 0;       // what the tables below were built for: members per team, LDS rows per member
     DevBuf rows_ctab, rows_vtab, rows_lds_edge;
     unsigned int *team_fault = nullptr, *team_fault_dev = nullptr;
@@ -369,7 +423,8 @@ struct ldpc_bp_decoder {
     // given: a call that arrives on another stream than its predecessor first waits for that one's last event.
     hipStream_t last_stream = nullptr;
     hipEvent_t last_ev = nullptr;  // one of ev[][] (not owned): completion of the most recent enqueued call
-    bool inject_fault = false;     // tests (LDPC_TEAM_INJECT_FAULT at create): team kernels raise the fault word at once
+    int inject_fault = 0;          // tests (experiments build, LDPC_TEAM_INJECT_FAULT at create): 1 = team kernels raise the fault word at once, 2 = a member misses the roll call
+    unsigned rollcall_ticks = 2000000u;   // 20 ms of the 100 MHz clock: how long the members of a team wait for each other at launch (team_rollcall)
 
     ~ldpc_bp_decoder()
     {
@@ -439,7 +494,7 @@ static size_t slot_pad_bytes()
 {
     static const size_t v = [] {
         size_t p = LDPC_SLOT_PAD;
-        if (const char *e = std::getenv("LDPC_SLOT_PAD_BYTES")) p = (size_t)std::atoll(e);
+        if (const char *e = exp_env("LDPC_SLOT_PAD_BYTES")) p = (size_t)std::atoll(e);
         return p & ~(size_t)511;
     }();
     return v;
@@ -456,7 +511,7 @@ static size_t slot_pad_bytes()
 // the caller then uses hipMalloc.
 static ldpc_status big_alloc(DevBuf &b, size_t bytes, int device, bool fresh = false)
 {
-    static const std::string ws_alloc = [] { const char *e = std::getenv("LDPC_WS_ALLOC"); return std::string(e ? e : ""); }();
+    static const std::string ws_alloc = [] { const char *e = exp_env("LDPC_WS_ALLOC"); return std::string(e ? e : ""); }();
     if (ws_alloc == "malloc" || bytes < ((size_t)1 << 30)) return LDPC_ERR_UNSUPPORTED;
     size_t chunk = (size_t)1 << 30;
     bool shuffle = false;
@@ -493,8 +548,8 @@ static ldpc_status ensure_workspace(ldpc_bp_decoder *d, size_t bytes, int grid, 
 {
     if (bytes <= d->msg.cap) return LDPC_OK;
     d->msg.release();
-    const bool verbose = std::getenv("LDPC_PLACEMENT_VERBOSE") != nullptr;
-    static const int max_rounds = [] { const char *e = std::getenv("LDPC_PLACEMENT_ROUNDS"); return e ? std::max(1, std::min(8, std::atoi(e))) : 5; }();
+    const bool verbose = exp_env("LDPC_PLACEMENT_VERBOSE") != nullptr;
+    static const int max_rounds = [] { const char *e = exp_env("LDPC_PLACEMENT_ROUNDS"); return e ? std::max(1, std::min(8, std::atoi(e))) : 5; }();
     d->placement_ms = 0.f;
     d->placement_candidates = 0;
     DevBuf first;
@@ -684,8 +739,12 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
         return st;
     }
 
-    if (d->max_cdeg == 8 && d->max_bdeg == 4 && nnz == 8 * s && nnz == 4 * n && nnz > 0) d->h_csc2csr = csc2csr;   // every check 8, every bit 4
-    if (const char *e = std::getenv("LDPC_TEAM_ROWS")) d->team_rows_on = std::atoi(e) != 0;
+    // regular graphs whose degree pair has a rows-in-LDS instantiation (every check max_cdeg edges, every bit max_bdeg)
+    if (nnz > 0 && nnz == (int64_t)d->max_cdeg * s && nnz == (int64_t)d->max_bdeg * n && team_rows_degrees_ok(d->max_cdeg, d->max_bdeg)) {
+        d->h_csc2csr = csc2csr;
+        d->rows_dc = d->max_cdeg; d->rows_dv = d->max_bdeg;
+    }
+    if (const char *e = exp_env("LDPC_TEAM_ROWS")) d->team_rows_on = std::atoi(e) != 0;
 
     // geometry: waves per tile (fixed by the caller or chosen per batch) and the workspace budget
     int wpt = options ? options->waves_per_tile : 0;
@@ -701,13 +760,14 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
         for (int &v : row) v = -1;
     d->variant = options ? options->kernel_variant : 0;
     if (d->variant < 0 || d->variant > 4) { delete d; return fail(LDPC_ERR_INVALID_ARGUMENT, "kernel_variant must be 0 ... 4"); }
-    d->inject_fault = std::getenv("LDPC_TEAM_INJECT_FAULT") != nullptr;   // (tests)
-    if (const char *e = std::getenv("LDPC_TEAM_CACHE_MIB")) d->team_cache = (size_t)std::max(0, std::atoi(e)) << 20;
-    if (const char *e = std::getenv("LDPC_TEAM_CACHE_KIB")) d->team_cache = (size_t)std::max(0, std::atoi(e)) << 10;   // (tests: persistent teams on small graphs)
-    if (const char *e = std::getenv("LDPC_TEAM_DYNAMIC")) d->team_dynamic = std::atoi(e) != 0;
-    if (const char *e = std::getenv("LDPC_TEAM_XCDS")) d->team_xcds = std::max(1, std::min(8, std::atoi(e)));
-    if (const char *e = std::getenv("LDPC_TEAM_PAIRS")) d->team_pairs = std::atoi(e) != 0;
-    if (const char *e = std::getenv("LDPC_TEAM_MAX")) { d->team_max = std::max(1, std::min(kTeamMaxMembers, std::atoi(e))); d->team_max_set = true; }
+    if (const char *e = exp_env("LDPC_TEAM_INJECT_FAULT")) d->inject_fault = std::max(1, std::atoi(e));   // (tests, experiments build: 1 = fault word at once, 2 = a member misses the roll call)
+    if (const char *e = exp_env("LDPC_TEAM_ROLLCALL_US")) d->rollcall_ticks = (unsigned)std::max(1, std::atoi(e)) * 100u;
+    if (const char *e = exp_env("LDPC_TEAM_CACHE_MIB")) d->team_cache = (size_t)std::max(0, std::atoi(e)) << 20;
+    if (const char *e = exp_env("LDPC_TEAM_CACHE_KIB")) d->team_cache = (size_t)std::max(0, std::atoi(e)) << 10;   // (tests: persistent teams on small graphs)
+    if (const char *e = exp_env("LDPC_TEAM_DYNAMIC")) d->team_dynamic = std::atoi(e) != 0;
+    if (const char *e = exp_env("LDPC_TEAM_XCDS")) d->team_xcds = std::max(1, std::min(8, std::atoi(e)));
+    if (const char *e = exp_env("LDPC_TEAM_PAIRS")) d->team_pairs = std::atoi(e) != 0;
+    if (const char *e = exp_env("LDPC_TEAM_MAX")) { d->team_max = std::max(1, std::min(kTeamMaxMembers, std::atoi(e))); d->team_max_set = true; }
     {
         void *fp = nullptr, *fd = nullptr;
         if (hipHostMalloc(&fp, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
@@ -723,7 +783,7 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     }
     d->lds_logS[0] = lds_logS(s, n, nnz, false);
     d->lds_logS[1] = lds_logS(s, n, nnz, true);
-    if (const char *e = std::getenv("LDPC_LDS_LOGS")) {   // tuning experiments only
+    if (const char *e = exp_env("LDPC_LDS_LOGS")) {   // tuning experiments only
         const int l = std::atoi(e);
         for (int q = 0; q < 2; ++q)
             if (d->lds_logS[q] >= 0 && l >= 0 && l <= 6 &&
@@ -736,11 +796,11 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     }
     d->node_ok = node_lds_bytes((int)s, (int)n) + 1024 <= (size_t)160 * 1024;
     d->node_msg_lds = d->node_ok && node_lds_bytes((int)s, (int)n) + (size_t)nnz * sizeof(double) + 1024 <= (size_t)160 * 1024;
-    if (const char *e = std::getenv("LDPC_NODE_MSG_LDS")) d->node_msg_lds = d->node_msg_lds && std::atoi(e) != 0;
-    if (d->node_ok && !d->node_msg_lds && !(std::getenv("LDPC_NODE_HYBRID") && std::atoi(std::getenv("LDPC_NODE_HYBRID")) == 0)) {
+    if (const char *e = exp_env("LDPC_NODE_MSG_LDS")) d->node_msg_lds = d->node_msg_lds && std::atoi(e) != 0;
+    if (d->node_ok && !d->node_msg_lds && !(exp_env("LDPC_NODE_HYBRID") && std::atoi(exp_env("LDPC_NODE_HYBRID")) == 0)) {
         // hybrid: as many leading checks as fit keep their messages in LDS
         size_t room = (size_t)160 * 1024 - 1024 - node_lds_bytes((int)s, (int)n);
-        const char *room_env = std::getenv("LDPC_NODE_LDS_ROOM");   // tests: bytes of LDS the messages may take
+        const char *room_env = exp_env("LDPC_NODE_LDS_ROOM");   // tests: bytes of LDS the messages may take
         if (room_env) room = std::min(room, (size_t)std::atoll(room_env));
         int64_t k = 0;
         while (k < s && (size_t)row_ptr[(size_t)k + 1] * sizeof(double) <= room) ++k;
@@ -756,12 +816,12 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     // The tile kernel needs ~one 64-syndrome tile per CU before it beats one workgroup per syndrome
     // (measured crossovers in DESIGN.md); LDPC_NODE_MAX_BATCH overrides for experiments.
     d->node_max_batch = (int64_t)d->num_cus * 8;
-    if (const char *e = std::getenv("LDPC_NODE_MAX_BATCH")) d->node_max_batch = std::atoll(e);
-    if (const char *e = std::getenv("LDPC_DEFER_T0")) d->defer_t0 = std::max(1, std::min(48, std::atoi(e)));
-    if (const char *e = std::getenv("LDPC_DEFER_T1")) d->defer_t1 = std::max(0, std::min(48, std::atoi(e)));
-    if (const char *e = std::getenv("LDPC_DEFER_CAP_TILES")) d->lvl_cap_force = std::max(0, std::atoi(e));
+    if (const char *e = exp_env("LDPC_NODE_MAX_BATCH")) d->node_max_batch = std::atoll(e);
+    if (const char *e = exp_env("LDPC_DEFER_T0")) d->defer_t0 = std::max(1, std::min(48, std::atoi(e)));
+    if (const char *e = exp_env("LDPC_DEFER_T1")) d->defer_t1 = std::max(0, std::min(48, std::atoi(e)));
+    if (const char *e = exp_env("LDPC_DEFER_CAP_TILES")) d->lvl_cap_force = std::max(0, std::atoi(e));
     d->node_take_max = (int64_t)d->num_cus * 8;
-    if (const char *e = std::getenv("LDPC_NODE_TAKE_MAX")) d->node_take_max = std::atoll(e);
+    if (const char *e = exp_env("LDPC_NODE_TAKE_MAX")) d->node_take_max = std::atoll(e);
     // keep the workspace inside a sane share of HBM (slots are nnz*512 B each)
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -841,13 +901,13 @@ hipEvent_t g_team_ev[64] = {};   // per device: completion of the most recent te
 // members per CU lands evenly.
 static size_t team_lds_bytes()
 {
-    static const size_t v = [] { const char *e = std::getenv("LDPC_TEAM_LDS_KIB"); return e ? (size_t)std::max(0, std::min(160, std::atoi(e))) * 1024 : (size_t)0; }();
+    static const size_t v = [] { const char *e = exp_env("LDPC_TEAM_LDS_KIB"); return e ? (size_t)std::max(0, std::min(160, std::atoi(e))) * 1024 : (size_t)0; }();
     return v;
 }
 
 static hipError_t launch_team_grid(ldpc_bp_decoder *d, team_kernel_t tk, int grid, void **args, hipStream_t stream, size_t lds)
 {
-    static const bool coop = std::getenv("LDPC_TEAM_COOP_LAUNCH") != nullptr;
+    static const bool coop = exp_env("LDPC_TEAM_COOP_LAUNCH") != nullptr;
     if (coop) return hipLaunchCooperativeKernel((const void *)tk, dim3((unsigned)grid), dim3(LDPC_TEAM_THREADS), args, (unsigned)lds, stream);
     std::lock_guard<std::mutex> lk(g_team_mu);
     hipEvent_t *gev = (d->device >= 0 && d->device < 64) ? &g_team_ev[d->device] : nullptr;
@@ -884,15 +944,15 @@ static bool takes_lds_kernel(const ldpc_bp_decoder *d, bool want_llr)
 static bool team_geometry(ldpc_bp_decoder *d, bool want_llr, int *per_xcd, int *gcap)
 {
     if (!(d->variant == 0 || d->variant == 4) || d->team_max < 2 || d->wpt_fixed || d->resident_fixed || d->nnz <= 0) return false;
-    static const int per_cu_want = [] { const char *e = std::getenv("LDPC_TEAM_PER_CU"); return e ? std::max(1, std::min(3, std::atoi(e))) : 2; }();
+    static const int per_cu_want = [] { const char *e = exp_env("LDPC_TEAM_PER_CU"); return e ? std::max(1, std::min(3, std::atoi(e))) : 2; }();
     // what this instantiation's registers admit (the wide-degree buckets: one 8-wave workgroup per CU), less one
     // as the margin where that leaves at least one
     int occ = 0;
     if (d->prepare_kernel((const void *)pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr), LDPC_TEAM_THREADS, team_lds_bytes(), &occ) != LDPC_OK) return false;
-    static const bool no_margin = std::getenv("LDPC_TEAM_NO_MARGIN") != nullptr;   // (experiments: fill the CUs exactly)
+    static const bool no_margin = exp_env("LDPC_TEAM_NO_MARGIN") != nullptr;   // (experiments: fill the CUs exactly)
     const int per_cu = no_margin ? std::min(per_cu_want, occ) : std::min(per_cu_want, occ >= 2 ? occ - (occ > per_cu_want ? 0 : 1) : occ);
     if (per_cu < 1) return false;
-    static const int64_t min_rows = [] { const char *e = std::getenv("LDPC_TEAM_MIN_ROWS"); return e ? std::max<int64_t>(1, std::atoll(e)) : (int64_t)2048; }();
+    static const int64_t min_rows = [] { const char *e = exp_env("LDPC_TEAM_MIN_ROWS"); return e ? std::max<int64_t>(1, std::atoll(e)) : (int64_t)2048; }();
     *per_xcd = per_cu * (d->num_cus / 8);
     *gcap = (int)std::min<int64_t>(d->team_max, std::max<int64_t>(1, d->nnz / min_rows));   // (LDPC_TEAM_MIN_ROWS=1: tests put teams on tiny graphs)
     return *per_xcd >= 1;
@@ -910,38 +970,43 @@ struct TeamPlanIn {
     int xcds_forced = 0;       // LDPC_TEAM_XCDS
     bool team_max_set = false; // LDPC_TEAM_MAX given: no teams over all XCDs for <= 4 tiles
     bool rows_possible = false;
+    int rows_dv = 4;           // bit degree of the regular graph (one edge per bit is a candidate for a row in LDS)
     int num_cus = 256;
     int per_xcd = 0, gcap = 0; // team_geometry(): team workgroups one XCD hosts, members per team at most
 };
 
-// What a member is expected to hold (a bit dealt to a member that owns one of its 4 checks: a quarter of the edges).
+// What a member is expected to hold (a bit dealt to a member that owns one of its dv checks: 1 / dv of the edges).
 static int team_rows_expected(const TeamPlanIn &in, int G)
 {
-    return in.rows_possible ? (int)std::min<int64_t>(kTeamRowsMax, in.nnz / 4 / std::max(G, 1)) : 0;
+    return in.rows_possible ? (int)std::min<int64_t>(kTeamRowsMax, in.nnz / std::max(in.rows_dv, 1) / std::max(G, 1)) : 0;
 }
 
-// The tables of TeamRows for teams of G members (kept until another G is asked for).  Checks are dealt as the kernel
-// deals them -- chunk c of 2 checks to member c % G -- and so are the POSITIONS of the bit order, in chunks of 4; the bits
-// are put into positions by the graph: a bit goes to the member, among the owners of its four checks, that has most
-// room left (any member once those are full).  Every edge whose check and bit then share the owner is a candidate; up
-// to kTeamRowsMax per member get a row in its LDS, numbered in check order.
+// The tables of TeamRows for teams of G members (kept until another G is asked for), for a regular graph whose checks
+// have dc edges each and whose bits dv.  Checks are dealt as the kernel deals them -- chunk c of 2 checks to member
+// c % G -- and so are the POSITIONS of the bit order, in chunks of 4; the bits are put into positions by the graph: a
+// bit goes to the member, among the owners of its dv checks, that has most room left (any member once those are
+// full).  Every edge whose check and bit then share the owner is a candidate; up to kTeamRowsMax per member get a row
+// in its LDS, numbered in check order.  Record of position p in vtab (vt = team_vtab_words(dv) words): CSR rows of the
+// bit's dv edges, their LDS rows or -1, the bit (| 1 << 31 when one of its edges is in LDS), padding.
 // (pure host code: ldpc_debug_team_rows() hands the tables to a CPU test)
 struct TeamRowTables {
     int R = 0;                    // LDS rows per member (the largest count; kTeamRowsMax at most)
+    int vt = 0;                   // words per position record of vtab
     size_t in_lds = 0;            // edges with a row in LDS
     std::vector<int> vtab, ctab, lds_edge;
 };
-static TeamRowTables team_rows_tables(int n, int s, int nnz, const std::vector<int> &c2r, int G)
+static TeamRowTables team_rows_tables(int n, int s, int nnz, int dc, int dv, const std::vector<int> &c2r, int G)
 {
     TeamRowTables out;
+    const int vt = team_vtab_words(dv);
     auto check_owner = [&](int i) { return (i / kTeamCheckChunk) % G; };
     std::vector<int> cap((size_t)G, 0), member_of_bit((size_t)n, -1);
     for (int p = 0; p < n; ++p) cap[(size_t)((p / 4) % G)]++;
     std::vector<int> room = cap;
     for (int j = 0; j < n; ++j) {
         int best = -1;
-        for (int k = 0; k < 4; ++k) {
-            const int m = check_owner(c2r[(size_t)4 * j + k] / 8);
+        for (int k = 0; k < dv; ++k) {
+            const int m = check_owner(c2r[(size_t)dv * j + k] / dc);
             if (room[(size_t)m] > 0 && (best < 0 || room[(size_t)m] > room[(size_t)best])) best = m;
         }
         if (best >= 0) { member_of_bit[(size_t)j] = best; room[(size_t)best]--; }
@@ -959,9 +1024,9 @@ static TeamRowTables team_rows_tables(int n, int s, int nnz, const std::vector<i
     // candidates per member, in check order; the first R of each get LDS rows
     std::vector<std::vector<int>> cand((size_t)G);
     for (int j = 0; j < n; ++j)
-        for (int k = 0; k < 4; ++k) {
-            const int q = c2r[(size_t)4 * j + k];
-            if (check_owner(q / 8) == member_of_bit[(size_t)j]) cand[(size_t)member_of_bit[(size_t)j]].push_back(q);
+        for (int k = 0; k < dv; ++k) {
+            const int q = c2r[(size_t)dv * j + k];
+            if (check_owner(q / dc) == member_of_bit[(size_t)j]) cand[(size_t)member_of_bit[(size_t)j]].push_back(q);
         }
     int R = 0;
     for (auto &v : cand) { std::sort(v.begin(), v.end()); if ((int)v.size() > kTeamRowsMax) v.resize(kTeamRowsMax); R = std::max(R, (int)v.size()); }
@@ -972,50 +1037,56 @@ static TeamRowTables team_rows_tables(int n, int s, int nnz, const std::vector<i
     std::vector<unsigned> cmask((size_t)s, 0u);
     for (int m = 0; m < G; ++m)
         for (int r = 0; r < (int)cand[(size_t)m].size(); ++r) {
-            const int q = cand[(size_t)m][(size_t)r], i = q / 8;
+            const int q = cand[(size_t)m][(size_t)r], i = q / dc;
             lds_row_of[(size_t)q] = r;
             lds_edge[(size_t)m * R + r] = q;
             if (cmask[(size_t)i] == 0u) cbase[(size_t)i] = r;   // (ascending q: the check's LDS edges follow each other)
-            cmask[(size_t)i] |= 1u << (q - 8 * i);
+            cmask[(size_t)i] |= 1u << (q - dc * i);
         }
     std::vector<int> &vtab = out.vtab, &ctab = out.ctab;
-    vtab.assign((size_t)n * kTeamVtab, 0);
+    vtab.assign((size_t)n * vt, 0);
     ctab.assign((size_t)s * 2, 0);
     for (int i = 0; i < s; ++i) { ctab[(size_t)2 * i] = (int)cmask[(size_t)i]; ctab[(size_t)2 * i + 1] = cbase[(size_t)i]; }
     for (int p = 0; p < n; ++p) {
         const int j = bit[(size_t)p];
         bool any = false;
-        for (int k = 0; k < 4; ++k) {
-            const int q = c2r[(size_t)4 * j + k];
-            vtab[(size_t)p * kTeamVtab + k] = q;
-            vtab[(size_t)p * kTeamVtab + 4 + k] = lds_row_of[(size_t)q];
+        for (int k = 0; k < dv; ++k) {
+            const int q = c2r[(size_t)dv * j + k];
+            vtab[(size_t)p * vt + k] = q;
+            vtab[(size_t)p * vt + dv + k] = lds_row_of[(size_t)q];
             any = any || lds_row_of[(size_t)q] >= 0;
         }
-        vtab[(size_t)p * kTeamVtab + 8] = any ? (j | (int)0x80000000u) : j;
+        vtab[(size_t)p * vt + 2 * dv] = any ? (j | (int)0x80000000u) : j;
     }
     out.R = R;
+    out.vt = vt;
     for (auto &v : cand) out.in_lds += v.size();
     return out;
 }
 
-// include/ldpc_mi355x.h: the tables above for a CPU test
+// include/ldpc_mi355x_debug.h: the tables above for a CPU test
 extern "C" ldpc_status ldpc_debug_team_rows(int64_t s, int64_t n, const int64_t *colptr, const int64_t *rowval, int32_t members,
-                                            int32_t *lds_rows, int32_t *vtab, int32_t *ctab, int32_t *lds_edge)
+                                            int32_t *degrees, int32_t *vt_words, int32_t *lds_rows, int32_t *vtab, int32_t *ctab,
+                                            int32_t *lds_edge)
 {
-    if (!colptr || !rowval || !lds_rows || !vtab || !ctab || !lds_edge) return fail(LDPC_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!colptr || !rowval || !degrees || !vt_words || !lds_rows || !vtab || !ctab || !lds_edge) return fail(LDPC_ERR_INVALID_ARGUMENT, "NULL argument");
     if (s <= 0 || n <= 0 || members < 1 || members > kTeamMaxMembers) return fail(LDPC_ERR_INVALID_ARGUMENT, "bad dimension");
     const int64_t nnz = colptr[n];
-    if (nnz != 8 * s || nnz != 4 * n || nnz >= INT32_MAX) return fail(LDPC_ERR_UNSUPPORTED, "not a (4,8)-regular graph");
+    if (nnz <= 0 || nnz % s != 0 || nnz % n != 0 || nnz >= INT32_MAX) return fail(LDPC_ERR_UNSUPPORTED, "not a regular graph");
+    const int dc = (int)(nnz / s), dv = (int)(nnz / n);
+    if (!team_rows_degrees_ok(dc, dv)) return fail(LDPC_ERR_UNSUPPORTED, "no rows-in-LDS instantiation for this degree pair");
     std::vector<int> fill((size_t)s, 0), c2r((size_t)nnz);
     for (int64_t j = 0; j < n; ++j) {
-        if (colptr[j + 1] - colptr[j] != 4) return fail(LDPC_ERR_UNSUPPORTED, "not a (4,8)-regular graph");
+        if (colptr[j + 1] - colptr[j] != dv) return fail(LDPC_ERR_UNSUPPORTED, "not a regular graph");
         for (int64_t k = colptr[j]; k < colptr[j + 1]; ++k) {
             const int64_t i = rowval[k];
-            if (i < 0 || i >= s || fill[(size_t)i] >= 8) return fail(LDPC_ERR_UNSUPPORTED, "not a (4,8)-regular graph");
-            c2r[(size_t)k] = (int)(8 * i + fill[(size_t)i]++);   // bits ascending inside a check, as ldpc_bp_create lays the rows out
+            if (i < 0 || i >= s || fill[(size_t)i] >= dc) return fail(LDPC_ERR_UNSUPPORTED, "not a regular graph");
+            c2r[(size_t)k] = (int)(dc * i + fill[(size_t)i]++);   // bits ascending inside a check, as ldpc_bp_create lays the rows out
         }
     }
-    const TeamRowTables t = team_rows_tables((int)n, (int)s, (int)nnz, c2r, members);
+    const TeamRowTables t = team_rows_tables((int)n, (int)s, (int)nnz, dc, dv, c2r, members);
+    degrees[0] = dc; degrees[1] = dv;
+    *vt_words = t.vt;
     *lds_rows = t.R;
     std::memcpy(vtab, t.vtab.data(), t.vtab.size() * sizeof(int));
     std::memcpy(ctab, t.ctab.data(), t.ctab.size() * sizeof(int));
@@ -1026,7 +1097,7 @@ extern "C" ldpc_status ldpc_debug_team_rows(int64_t s, int64_t n, const int64_t 
 static ldpc_status team_rows_build(ldpc_bp_decoder *d, int G)
 {
     if (d->rows_G == G) return LDPC_OK;
-    const TeamRowTables t = team_rows_tables((int)d->n, (int)d->s, (int)d->nnz, d->h_csc2csr, G);
+    const TeamRowTables t = team_rows_tables((int)d->n, (int)d->s, (int)d->nnz, d->rows_dc, d->rows_dv, d->h_csc2csr, G);
     const std::vector<int> &vtab = t.vtab, &ctab = t.ctab, &lds_edge = t.lds_edge;
     const int R = t.R;
     auto up = [&](DevBuf &b, const void *src, size_t bytes) -> ldpc_status {
@@ -1041,7 +1112,7 @@ static ldpc_status team_rows_build(ldpc_bp_decoder *d, int G)
         (st = up(d->rows_lds_edge, lds_edge.data(), lds_edge.size() * 4)) != LDPC_OK)
         return st;
     d->rows_G = G; d->rows_R = R;
-    if (std::getenv("LDPC_TEAM_DEBUG"))
+    if (exp_env("LDPC_TEAM_DEBUG"))
         std::fprintf(stderr, "[ldpc] team rows: %d members, %d LDS rows each at most, %zu of %d edges in LDS\n", G, R, t.in_lds, (int)d->nnz);
     return LDPC_OK;
 }
@@ -1061,7 +1132,7 @@ static bool team_fit(const TeamPlanIn &in, int64_t ntiles, bool rows, int *xcds,
     const int x_hi = in.xcds_forced ? in.xcds_forced : 8, x_lo = in.xcds_forced ? in.xcds_forced : 6;
     for (int x = x_hi; x >= x_lo; --x)
         for (int t = 1; t <= per_xcd / 3; ++t) {
-            if ((size_t)x * (size_t)t * (state - (rows ? state / 4 : 0)) > cache) break;   // (a quarter at most can be in LDS)
+            if ((size_t)x * (size_t)t * (state - (rows ? state / (size_t)std::max(in.rows_dv, 1) : 0)) > cache) break;   // (1 / dv at most can be in LDS)
             if (t > 1 && (int64_t)x * (t - 1) >= ntiles) break;            // no more teams than tiles
             const int g = std::min(gcap, per_xcd / t);
             if (g < 3) break;
@@ -1142,7 +1213,7 @@ static TeamPlanIn team_plan_in(const ldpc_bp_decoder *d, int per_xcd, int gcap)
 {
     TeamPlanIn in;
     in.nnz = d->nnz; in.max_iters = d->max_iters; in.cache = d->team_cache; in.xcds_forced = d->team_xcds;
-    in.team_max_set = d->team_max_set; in.rows_possible = team_rows_possible(d); in.num_cus = d->num_cus;
+    in.team_max_set = d->team_max_set; in.rows_possible = team_rows_possible(d); in.rows_dv = std::max(d->rows_dv, 1); in.num_cus = d->num_cus;
     in.per_xcd = per_xcd; in.gcap = gcap;
     return in;
 }
@@ -1154,13 +1225,13 @@ static TeamPlan team_plan(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
     return team_plan_pure(team_plan_in(d, per_xcd, gcap), batch);
 }
 
-// include/ldpc_mi355x.h: the plan for a CPU test (an MI355X's geometry: 256 CUs, one team workgroup per CU)
-extern "C" ldpc_status ldpc_debug_team_plan(int64_t nnz, int64_t max_iters, int64_t batch, int32_t cache_mib, int32_t regular_8_4,
+// include/ldpc_mi355x_debug.h: the plan for a CPU test (an MI355X's geometry: 256 CUs, one team workgroup per CU)
+extern "C" ldpc_status ldpc_debug_team_plan(int64_t nnz, int64_t max_iters, int64_t batch, int32_t cache_mib, int32_t rows_dv,
                                             int32_t out[6])
 {
     if (!out || nnz < 0 || batch < 0 || cache_mib < 0) return fail(LDPC_ERR_INVALID_ARGUMENT, "bad argument");
     TeamPlanIn in;
-    in.nnz = nnz; in.max_iters = max_iters; in.cache = (size_t)cache_mib << 20; in.rows_possible = regular_8_4 != 0;
+    in.nnz = nnz; in.max_iters = max_iters; in.cache = (size_t)cache_mib << 20; in.rows_possible = rows_dv > 0; in.rows_dv = std::max(rows_dv, 1);
     in.num_cus = 256; in.per_xcd = 32;
     in.gcap = (int)std::min<int64_t>(32, std::max<int64_t>(1, nnz / 2048));
     const TeamPlan pl = team_plan_pure(in, batch);
@@ -1214,11 +1285,14 @@ static ldpc_status report_team_fault(ldpc_bp_decoder *d)
     }
     __atomic_store_n(d->team_fault, 0u, __ATOMIC_RELEASE);
     d->team_max = 1;
-    // the ticket holds the low 31 bits of the call number (counting from 1)
+    // the ticket holds the low 31 bits of the call number (counting from 1); bit 31: the roll call failed
     uint64_t first = (d->ncalls & ~(uint64_t)0x7fffffff) | (uint64_t)(ticket & 0x7fffffffu);
     if (first > d->ncalls && first >= ((uint64_t)1 << 31)) first -= (uint64_t)1 << 31;
-    return fail(LDPC_ERR_HIP, "call #" + std::to_string(first) + " on this decoder lost a workgroup of a team (team barrier timed out): "
-                "the results of that call and of every team-kernel call enqueued after it (up to call #" + std::to_string(d->ncalls) +
+    const bool rollcall = (ticket & kTeamRollcallFailed) != 0u;
+    return fail(LDPC_ERR_HIP, "call #" + std::to_string(first) + " on this decoder " +
+                (rollcall ? "found a team of workgroups incomplete at launch (roll call timed out: the GPU is shared with other work)"
+                          : "lost a workgroup of a team (team barrier timed out)") +
+                ": the results of that call and of every team-kernel call enqueued after it (up to call #" + std::to_string(d->ncalls) +
                 ") are invalid; teams are off for this decoder from here on");
 }
 
@@ -1429,7 +1503,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     // dealt over all XCDs (scatter mode: team = block / G) its sweeps run 1.4x faster and the barriers (now with
     // the L2 write-back) twice as long -- 6.1 -> 5.4 ms for 64 syndromes of the C3 code, all 50 iterations.
     // (The environment switch is read per call: a test turns it on and off.)
-    const bool team_scatter = team > 1 && (std::getenv("LDPC_TEAM_SCATTER") || plan.scatter);
+    const bool team_scatter = team > 1 && (exp_env("LDPC_TEAM_SCATTER") || plan.scatter);
     // scatter mode launches exactly the members (8 * team blocks for <= 4 tiles would be up to 512 workgroups,
     // more than the wide-degree instantiations can keep resident: one 8-wave workgroup per CU)
     const int team_grid = team > 1 ? (team_scatter ? plan.nteams * team : plan.grid) : 0;
@@ -1571,7 +1645,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     hipLaunchKernelGGL(store_cold_kernel, dim3(1), dim3(64), 0, stream, cold[0], cold[1], cold[2], d_cold);
     HIP_TRY(hipGetLastError());
     bp_kernel_t kfn = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, threads);
-    static const int always_release = std::getenv("LDPC_TEAM_ALWAYS_RELEASE") ? 1 : 0;
+    static const int always_release = exp_env("LDPC_TEAM_ALWAYS_RELEASE") ? 1 : 0;
     auto team_params = [&](DevBuf &wsbuf, int nteams, int tiles, TeamParams &tp) -> ldpc_status {
         const size_t ctl_bytes = ((size_t)nteams + 1) * kTeamCtlWords * sizeof(unsigned int);   // + the block of the tile queue
         const size_t mism_stride = ((size_t)d->max_iters + 31) & ~(size_t)31;
@@ -1592,6 +1666,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         tp.count_max = 0;
         tp.inject_fault = 0;
         tp.ticket = ticket;
+        tp.rollcall_ticks = d->rollcall_ticks;
         return LDPC_OK;
     };
     bool team_ran = team > 1;
@@ -1602,16 +1677,16 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         tp.G = team;
         tp.xcds = plan.xcds;
         tp.scatter = team_scatter ? 1 : 0;
-        tp.inject_fault = d->inject_fault ? 1 : 0;   // (tests)
+        tp.inject_fault = d->inject_fault;   // (tests; the kernel only looks at it in the experiments build)
         team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr);
         size_t team_lds = team_lds_bytes();
         const int *t_col = a_col, *t_c2r = a_c2r;
         if (plan.rows && team_rows_build(d, team) == LDPC_OK) {   // (also with LDPC_TEAM_SCATTER: members over all XCDs, a test)
             // rows that only one member touches live in its LDS (TeamRows)
-            team_kernel_t tkr = pick_team_kernel_rows(want_llr);
+            team_kernel_t tkr = pick_team_kernel_rows(d->rows_dc, d->rows_dv, want_llr);
             const size_t need = (size_t)d->rows_R * kTile * sizeof(double);
             int occ_rows = 0;
-            if (d->prepare_kernel((const void *)tkr, LDPC_TEAM_THREADS, need, &occ_rows) == LDPC_OK && occ_rows >= 1) {
+            if (tkr && d->prepare_kernel((const void *)tkr, LDPC_TEAM_THREADS, need, &occ_rows) == LDPC_OK && occ_rows >= 1) {
                 tk = tkr; team_lds = need;
                 tp.rows.lds_edge = (const int *)d->rows_lds_edge.p;
                 tp.rows.R = d->rows_R;
@@ -1634,7 +1709,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             kfn = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, threads);
             team_ran = false;
         }
-        if (team_ran && std::getenv("LDPC_TEAM_DEBUG")) {   // diagnostics: which XCDs did the teams land on?
+        if (team_ran && exp_env("LDPC_TEAM_DEBUG")) {   // diagnostics: which XCDs did the teams land on?
             const int nt = std::min(plan.nteams, ntiles);
             std::vector<unsigned> xm((size_t)nt);
             (void)hipStreamSynchronize(stream);
@@ -1809,7 +1884,7 @@ static ldpc_status decode_batch_host_impl(ldpc_bp_decoder *d, int64_t batch, con
         // Tiny batches on the two kernels that read their input once (a plain decode! above all): the
         // kernel works on a host-mapped image directly and raises a flag in it when the last workgroup
         // is through -- ONE runtime call (the launch) instead of nine, no copies, no stream synchronisation.
-        static const bool lat_off = std::getenv("LDPC_NO_LATENCY_PATH") != nullptr;
+        static const bool lat_off = exp_env("LDPC_NO_LATENCY_PATH") != nullptr;
         const bool lds_k = takes_lds_kernel(d, llr != nullptr);
         const int64_t lat_groups = lds_k ? ((batch + (1ll << d->lds_logS[llr ? 1 : 0]) - 1) >> d->lds_logS[llr ? 1 : 0]) : batch;
         if (!lat_off && total <= ((size_t)256 << 10) && d->max_iters > 0 && lat_groups <= 2 * (int64_t)d->num_cus &&
@@ -1886,7 +1961,7 @@ static ldpc_status decode_batch_host_impl(ldpc_bp_decoder *d, int64_t batch, con
         const size_t bps = s + n + 1 + sizeof(int32_t) + (llr ? n * sizeof(double) : 0);   // bytes per syndrome
         const bool lds_path = d->variant != 1 && d->lds_logS[llr ? 1 : 0] >= 0;
         size_t chunk_mb = 24;
-        if (const char *e = std::getenv("LDPC_PIPE_CHUNK_MB")) chunk_mb = std::max<long>(1, std::atol(e));
+        if (const char *e = exp_env("LDPC_PIPE_CHUNK_MB")) chunk_mb = std::max<long>(1, std::atol(e));
         size_t cb = (chunk_mb << 20) / std::max<size_t>(bps, 1);
         cb = std::max<size_t>(cb, lds_path ? 32768 : 65536);      // enough syndromes to fill the chip
         cb = (cb + 4095) & ~(size_t)4095;

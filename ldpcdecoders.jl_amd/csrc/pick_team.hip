@@ -29,11 +29,23 @@ team_kernel_t team_pick_dc(int dc, int dv)
 #define LDPC_TEAM_ROWS 0
 #endif
 #if LDPC_TEAM_ROWS
-// (a third compilation: -DLDPC_TEAM_ROWS=1) rows in LDS: regular graphs of the (8,4) bucket, fresh tiles
-team_kernel_t pick_team_kernel_rows(bool llr)
+// (a third compilation: -DLDPC_TEAM_ROWS=1) rows in LDS: regular graphs, EXACT degrees (team_rows_degrees_ok()), fresh
+// tiles.  nullptr: no instantiation for this pair.
+namespace {
+template <int DC, int DV>
+team_kernel_t rows_pick(bool llr)
 {
-    if (llr) return bp_team_kernel<8, 4, true, LDPC_TEAM_THREADS, false, true>;
-    return bp_team_kernel<8, 4, false, LDPC_TEAM_THREADS, false, true>;
+    static_assert(team_rows_degrees_ok(DC, DV), "keep team_rows_degrees_ok() and the instantiations in step");
+    if (llr) return bp_team_kernel<DC, DV, true, LDPC_TEAM_THREADS, false, true>;
+    return bp_team_kernel<DC, DV, false, LDPC_TEAM_THREADS, false, true>;
+}
+}  // namespace
+team_kernel_t pick_team_kernel_rows(int dc, int dv, bool llr)
+{
+    if (dc == 8 && dv == 4) return rows_pick<8, 4>(llr);
+    if (dc == 6 && dv == 3) return rows_pick<6, 3>(llr);
+    if (dc == 10 && dv == 5) return rows_pick<10, 5>(llr);
+    return nullptr;
 }
 #elif LDPC_TEAM_RESUMED
 team_kernel_t pick_team_kernel_resumed(int dc, int dv, bool llr)

@@ -17,7 +17,7 @@ file only marshals arrays.  Matrices keep the reference's orientation:
 from __future__ import annotations
 
 import ctypes
-from typing import Optional, Tuple
+from typing import Optional, Sequence, Tuple
 
 import numpy as np
 import scipy.sparse as sp
@@ -91,12 +91,17 @@ class BeliefPropagationDecoder(AbstractDecoder):
     """Drop-in for `BeliefPropagationDecoder(H, per::Float64, max_iters::Int)`.
 
     Extra keyword arguments select the device and tuning knobs; defaults give
-    the reference behaviour.
+    the reference behaviour.  ``devices=[0, 1, ...]`` makes ``batchdecode_`` / ``decode_batch_host`` /
+    ``decode_batch_device`` partition the batch over those GPUs from this one process
+    (ldpc_bp_create_multi: contiguous shards, one handle and stream per device; ``exchange`` picks how the
+    root-device form moves shards: 0 auto, 1 hipMemcpyPeer, 2 RCCL).  ``experiments=True`` binds the build of
+    the library that reads the environment knobs (default: only when one of them is set).
     """
 
     def __init__(self, H, per: float, max_iters: int, *, device: Optional[int] = None,
+                 devices: Optional[Sequence[int]] = None, exchange: int = 0,
                  waves_per_tile: int = 0, resident_tiles: int = 0, kernel_variant: int = 0,
-                 defer_threshold: int = 0):
+                 defer_threshold: int = 0, experiments: Optional[bool] = None):
         if not isinstance(per, float):
             raise TypeError("per must be a Float64 (reference signature: per::Float64)")
         if isinstance(max_iters, bool) or not isinstance(max_iters, (int, np.integer)):
@@ -118,16 +123,36 @@ class BeliefPropagationDecoder(AbstractDecoder):
         opts.kernel_variant = int(kernel_variant)   # 0 auto, 1 HBM-streaming, 2 LDS-resident, 3 node-parallel, 4 team
         opts.defer_threshold = int(defer_threshold)  # 0 auto (16), -1 off: straggler hand-off of the streaming kernel
         self._h = ctypes.c_void_p()
-        L = _capi.lib()
-        _capi.check(L.ldpc_bp_create(self.s, self.n, int(self._rowval.size), self._colptr.ctypes.data,
-                                     self._rowval.ctypes.data, self.per, self.max_iters,
-                                     ctypes.byref(opts), ctypes.byref(self._h)))
+        self._m = None                         # the multi-device handle when devices= is given
+        self._L = L = _capi.lib_for(experiments)
+        if devices is not None:
+            if device is not None:
+                raise TypeError("give device= or devices=, not both")
+            devs = (ctypes.c_int32 * len(devices))(*[int(x) for x in devices])
+            m = ctypes.c_void_p()
+            self._check(L.ldpc_bp_create_multi(len(devices), devs, int(exchange), self.s, self.n, int(self._rowval.size),
+                                               self._colptr.ctypes.data, self._rowval.ctypes.data, self.per, self.max_iters,
+                                               ctypes.byref(opts), ctypes.byref(m)))
+            self._m = m
+            self._h = ctypes.c_void_p(L.ldpc_bp_multi_handle(m, 0))   # info / timing: the root's handle
+            self.devices = [int(x) for x in devices]
+        else:
+            self._check(L.ldpc_bp_create(self.s, self.n, int(self._rowval.size), self._colptr.ctypes.data,
+                                         self._rowval.ctypes.data, self.per, self.max_iters,
+                                         ctypes.byref(opts), ctypes.byref(self._h)))
+            self.devices = None
+
+    def _check(self, status: int) -> None:
+        _capi.check(status, self._L)
 
     # -- lifetime ---------------------------------------------------------
     def close(self) -> None:
         h, self._h = getattr(self, "_h", None), None
-        if h:
-            _capi.lib().ldpc_bp_destroy(h)
+        m, self._m = getattr(self, "_m", None), None
+        if m:
+            self._L.ldpc_bp_destroy_multi(m)
+        elif h:
+            self._L.ldpc_bp_destroy(h)
 
     def __del__(self):
         try:
@@ -138,26 +163,36 @@ class BeliefPropagationDecoder(AbstractDecoder):
     # -- introspection ------------------------------------------------------
     def info(self) -> _capi.BPInfo:
         info = _capi.BPInfo()
-        _capi.check(_capi.lib().ldpc_bp_get_info(self._h, ctypes.byref(info)))
+        self._check(self._L.ldpc_bp_get_info(self._h, ctypes.byref(info)))
+        return info
+
+    def multi_info(self) -> _capi.BPMultiInfo:
+        """devices, exchange kind and the scatter / decode / gather times of the most recent root-device call
+        (ldpc_bp_multi_get_info); only with devices=."""
+        assert self._m, "not a multi-device decoder"
+        info = _capi.BPMultiInfo()
+        self._check(self._L.ldpc_bp_multi_get_info(self._m, ctypes.byref(info)))
         return info
 
     def last_status(self) -> None:
         """Wait for everything enqueued on the handle and raise LdpcError if a team of workgroups lost a
         member in one of those calls (ldpc_bp_last_status): their outputs must then be decoded again."""
-        _capi.check(_capi.lib().ldpc_bp_last_status(self._h))
+        if self._m:
+            self._check(self._L.ldpc_bp_multi_last_status(self._m))
+        else:
+            self._check(self._L.ldpc_bp_last_status(self._h))
 
     def last_timing(self, calls_back: int = 0) -> Tuple[float, float, int]:
         """(sweep_ms, total_ms, sum_iters) of a recent batch call (0 = the latest), from HIP
         events recorded on the stream the kernels ran on."""
         a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
-        _capi.check(_capi.lib().ldpc_bp_call_timing(self._h, calls_back, ctypes.byref(a), ctypes.byref(b),
-                                                    ctypes.byref(c)))
+        self._check(self._L.ldpc_bp_call_timing(self._h, calls_back, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return a.value, b.value, c.value
 
     def phase_ticks(self, calls_back: int = 0) -> Tuple[int, int, int]:
         """Diagnostics: 100 MHz ticks in (check sweep, variable sweep, convergence test), summed over workgroups."""
         t = (ctypes.c_uint64 * 3)()
-        _capi.check(_capi.lib().ldpc_bp_call_phase_ticks(self._h, calls_back, ctypes.byref(t)))
+        self._check(self._L.ldpc_bp_call_phase_ticks(self._h, calls_back, ctypes.byref(t)))
         return int(t[0]), int(t[1]), int(t[2])
 
     # -- raw ABI calls ------------------------------------------------------
@@ -178,9 +213,9 @@ class BeliefPropagationDecoder(AbstractDecoder):
             conv = np.empty(B, dtype=np.uint8)
         llr = np.empty((B, self.n), dtype=np.float64) if want_llr else None
         its = np.empty(B, dtype=np.int32) if want_iters else None
-        _capi.check(_capi.lib().ldpc_bp_decode_batch(
-            self._h, B, syn_bs.ctypes.data, err.ctypes.data, conv.ctypes.data,
-            llr.ctypes.data if want_llr else None, its.ctypes.data if want_iters else None))
+        entry, handle = (self._L.ldpc_bp_decode_batch_multi, self._m) if self._m else (self._L.ldpc_bp_decode_batch, self._h)
+        self._check(entry(handle, B, syn_bs.ctypes.data, err.ctypes.data, conv.ctypes.data,
+                          llr.ctypes.data if want_llr else None, its.ctypes.data if want_iters else None))
         return err, conv, llr, its
 
     def decode_batch_device(self, syn, err, conv, llr=None, iters=None, stream: Optional[int] = None) -> None:
@@ -200,10 +235,11 @@ class BeliefPropagationDecoder(AbstractDecoder):
             assert iters.is_cuda and iters.dtype == torch.int32 and iters.is_contiguous() and iters.numel() == B
         if stream is None:
             stream = torch.cuda.current_stream(syn.device).cuda_stream
-        _capi.check(_capi.lib().ldpc_bp_decode_batch_device(
-            self._h, B, syn.data_ptr(), err.data_ptr(), conv.data_ptr(),
-            llr.data_ptr() if llr is not None else None,
-            iters.data_ptr() if iters is not None else None, ctypes.c_void_p(stream)))
+        entry, handle = ((self._L.ldpc_bp_decode_batch_multi_device, self._m) if self._m
+                         else (self._L.ldpc_bp_decode_batch_device, self._h))   # multi: the tensors live on devices[0]
+        self._check(entry(handle, B, syn.data_ptr(), err.data_ptr(), conv.data_ptr(),
+                          llr.data_ptr() if llr is not None else None,
+                          iters.data_ptr() if iters is not None else None, ctypes.c_void_p(stream)))
 
     # -- reference interface (methods; free functions below) ----------------
     def decode_(self, syndrome):

@@ -171,11 +171,22 @@ def batchdecode_sharded(decode_fn: Callable, syndromes: Optional[torch.Tensor], 
 
 
 def gpu_decode_fn(decoder) -> Callable:
-    """decode_fn for batchdecode_sharded backed by a BeliefPropagationDecoder handle (HBM-resident I/O,
-    asynchronous on torch's current stream: the exchange that follows is ordered behind it by the stream)."""
+    """decode_fn for batchdecode_sharded backed by a BeliefPropagationDecoder handle (HBM-resident I/O on torch's
+    current stream).  The decode is asynchronous, but every rank must know that ITS shard is good before it takes
+    part in the gather: a team of workgroups that was incomplete at launch or lost a member (other work on the GPU:
+    ldpc_bp_last_status) leaves invalid outputs, and a rank that found out only at its next call would drop out of
+    that step's exchange while the root waits for it.  So the rank waits for its decode, and on a fault decodes the
+    shard once more -- the handle keeps teams off from then on, so the second pass cannot fail the same way."""
+    from ._capi import LdpcError
 
     def fn(syn: torch.Tensor, out):
         err, conv, its = out
-        decoder.decode_batch_device(syn.contiguous(), err, conv, None, its)
+        syn = syn.contiguous()
+        decoder.decode_batch_device(syn, err, conv, None, its)
+        try:
+            decoder.last_status()
+        except LdpcError:
+            decoder.decode_batch_device(syn, err, conv, None, its)
+            decoder.last_status()
 
     return fn

@@ -12,20 +12,44 @@ import ldpcdecoders_jl_amd as ldpc
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_functions():
-    txt = open(os.path.join(ROOT, "include", "ldpc_mi355x.h")).read()
+def _declared_functions(header="ldpc_mi355x.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(ldpc_[a-z0-9_]+)\s*\(", txt)))
 
 
-def test_every_declared_symbol_is_exported():
-    lib = ldpc._capi.lib()
+@pytest.mark.parametrize("experiments", [False, True])
+def test_every_declared_symbol_is_exported(experiments):
+    lib = ldpc._capi.lib(experiments)
     declared = _declared_functions()
     assert len(declared) >= 10
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/ldpc_mi355x.h but not exported"
     assert sorted(ldpc._capi.EXPORTED_SYMBOLS) == declared
-    assert lib.ldpc_abi_version() == 2 and lib.ldpc_build_target() == b"gfx950"
+    assert lib.ldpc_abi_version() == 3 and lib.ldpc_build_target() == b"gfx950"
+    # the test hooks live in a header of their own, outside the drop-in boundary
+    hooks = _declared_functions("ldpc_mi355x_debug.h")
+    assert sorted(ldpc._capi.DEBUG_SYMBOLS) == hooks and not set(hooks) & set(declared)
+    for name in hooks:
+        assert hasattr(lib, name)
+
+
+def test_product_build_reads_no_environment_and_has_no_fault_injection():
+    """The knobs of DESIGN.md's "Environment knobs" table exist in the experiments build only (host_env.hpp): the
+    product library holds none of their names and does not import getenv at all."""
+    import subprocess
+
+    prod = open(ldpc._capi.LIB_PATH, "rb").read()
+    exp = open(ldpc._capi.EXP_LIB_PATH, "rb").read()
+    for knob in (b"LDPC_TEAM_INJECT_FAULT", b"LDPC_TEAM_CACHE_MIB", b"LDPC_DEFER_T0", b"LDPC_VMM_HINT_TIB", b"LDPC_NODE_MSG_LDS",
+                 b"LDPC_BPOTS_FORCE_NODE", b"LDPC_WS_ALLOC"):
+        assert knob not in prod, knob
+        assert knob in exp, knob
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", ldpc._capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in undefined
+    # the multi-GPU exchange binds RCCL at run time: no link-time dependency for single-GPU users
+    needed = subprocess.run(["readelf", "-d", ldpc._capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rccl" not in needed.lower()
 
 
 def test_code_object_is_gfx950_only():
@@ -49,6 +73,16 @@ def test_argument_validation_happens_before_any_device_work():
     assert st == 1
     assert lib.ldpc_bp_decode_batch(None, 1, None, None, None, None, None) == 1
     assert lib.ldpc_bp_destroy(None) == 0
+    # the multi-device constructor checks its own arguments first, too
+    m = ctypes.c_void_p()
+    good = np.array([0, 1], dtype=np.int64)
+    devs = (ctypes.c_int32 * 2)(0, 0)
+    assert lib.ldpc_bp_create_multi(0, devs, 0, 2, 2, 2, colptr.ctypes.data, good.ctypes.data, 0.1, 5, None, ctypes.byref(m)) == 1
+    assert lib.ldpc_bp_create_multi(17, devs, 0, 2, 2, 2, colptr.ctypes.data, good.ctypes.data, 0.1, 5, None, ctypes.byref(m)) == 1
+    assert lib.ldpc_bp_create_multi(2, devs, 7, 2, 2, 2, colptr.ctypes.data, good.ctypes.data, 0.1, 5, None, ctypes.byref(m)) == 1
+    assert lib.ldpc_bp_decode_batch_multi(None, 1, None, None, None, None, None) == 1
+    assert lib.ldpc_bp_decode_batch_multi_device(None, 1, None, None, None, None, None, None) == 1
+    assert lib.ldpc_bp_destroy_multi(None) == 0 and not lib.ldpc_bp_multi_handle(None, 0)
 
 
 def test_no_cpu_fallback():
@@ -83,7 +117,8 @@ def _build_driver(tmp_path):
     exe = str(tmp_path / "abi_driver")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "abi_driver.c"), "-o", exe,
-                           ldpc._capi.LIB_PATH, "-Wl,-rpath," + os.path.dirname(ldpc._capi.LIB_PATH)])
+                           ldpc._capi.LIB_PATH, "-Wl,-rpath," + os.path.dirname(ldpc._capi.LIB_PATH),
+                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
     return exe
 
 
@@ -103,6 +138,19 @@ def test_c_host_decodes_on_the_gpu(tmp_path, gpu):
     exe = _build_driver(tmp_path)
     out = subprocess.run([exe, "gpu"], capture_output=True, text=True)
     assert out.returncode == 0 and "gpu ok" in out.stdout, (out.returncode, out.stdout, out.stderr)
+
+
+@pytest.mark.gpu
+def test_c_host_multi_device_entries_equal_the_single_device_entry(tmp_path, gpu):
+    """tests/abi_driver.c "multi": ldpc_bp_create_multi / ldpc_bp_decode_batch_multi[_device] from a plain-C host --
+    ndev = 1 (the degenerate case: bit-equal to ldpc_bp_decode_batch_device), two logical devices on GPU 0 (shards
+    exchanged with hipMemcpyPeerAsync) in the host and the root-device form, and ndev = 1 with the shard sent to
+    itself through RCCL (ncclCommInitAll, grouped ncclSend / ncclRecv: the calls an 8-GPU run makes)."""
+    import subprocess
+
+    exe = _build_driver(tmp_path)
+    out = subprocess.run([exe, "multi"], capture_output=True, text=True)
+    assert out.returncode == 0 and "multi ok" in out.stdout, (out.returncode, out.stdout, out.stderr)
 
 
 def test_hot_kernels_keep_their_register_budget(tmp_path):

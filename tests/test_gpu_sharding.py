@@ -77,3 +77,23 @@ def test_two_ranks_scatter_decode_gather_with_the_hip_decoder(gpu):
     assert x["sharded_matches_local"] is True
     assert x["scatter_bytes_per_peer"] == 3000 * 8192 and x["scatter_ms"] > 0 and x["gather_ms"] > 0 and x["decode_ms_max_rank"] > 0
     assert abs(d["value"] - 6000 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
+def test_bench_cabi_mode_two_logical_devices_one_process(gpu):
+    """bench.py --gpus 2 --mode cabi --rehearse-on-one-gpu: ONE process, ldpc_bp_create_multi with two logical devices on
+    GPU 0 -- the root-held 2 x 3000 batch is scattered, decoded on both handles' streams and gathered through the C ABI;
+    the same `exchange` fields as the torch.distributed mode; --verify compares with a single-device decoder."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", "cabi", "--rehearse-on-one-gpu",
+           "--workload", "c3_realistic", "--batch", "3000", "--steps", "1", "--warmup", "1", "--verify", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 6000 and d["config"]["mode"] == "cabi"
+    x = d["exchange"]
+    assert x["sharded_matches_local"] is True
+    assert x["scatter_bytes_per_peer"] == 3000 * 8192 and x["gather_bytes_per_peer"] == 3000 * (16384 + 1 + 4)
+    assert x["scatter_ms"] >= 0 and x["gather_ms"] > 0 and x["decode_ms_max_rank"] > 0
+    assert abs(d["value"] - 6000 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]

@@ -13,36 +13,41 @@ import ldpcdecoders_jl_amd as ldpc
 RMAX = 312
 
 
-def tables(n, members):
-    H = ldpc.codes.parity_check_csc(n, 8, 4)
+def tables(n, members, wr=8, wc=4):
+    H = ldpc.codes.parity_check_csc(n, wr, wc)
     s = H.shape[0]
     colptr = np.ascontiguousarray(H.indptr, dtype=np.int64)
     rowval = np.ascontiguousarray(H.indices, dtype=np.int64)
-    R = ctypes.c_int32()
+    R, vt = ctypes.c_int32(), ctypes.c_int32()
+    deg = (ctypes.c_int32 * 2)()
     vtab = np.zeros((n, 16), dtype=np.int32)
     ctab = np.zeros((s, 2), dtype=np.int32)
     lds_edge = np.full(members * RMAX, -7, dtype=np.int32)
-    st = ldpc._capi.lib().ldpc_debug_team_rows(s, n, colptr.ctypes.data, rowval.ctypes.data, members, ctypes.byref(R),
-                                               vtab.ctypes.data, ctab.ctypes.data, lds_edge.ctypes.data)
+    st = ldpc._capi.lib().ldpc_debug_team_rows(s, n, colptr.ctypes.data, rowval.ctypes.data, members, ctypes.byref(deg),
+                                               ctypes.byref(vt), ctypes.byref(R), vtab.ctypes.data, ctab.ctypes.data,
+                                               lds_edge.ctypes.data)
     ldpc._capi.check(st)
+    assert list(deg) == [wr, wc] and vt.value == (8 if 2 * wc + 1 <= 8 else 16)
+    vtab = vtab.reshape(-1)[: n * vt.value].reshape(n, vt.value)
     return H, R.value, vtab, ctab, lds_edge[: members * R.value].reshape(members, R.value)
 
 
-@pytest.mark.parametrize("n,members", [(4096, 8), (16384, 32), (16384, 28), (1024, 3), (32768, 32)])
-def test_row_tables_describe_the_graph(n, members):
-    H, R, vtab, ctab, lds_edge = tables(n, members)
+@pytest.mark.parametrize("n,members,wr,wc", [(4096, 8, 8, 4), (16384, 32, 8, 4), (16384, 28, 8, 4), (1024, 3, 8, 4), (32768, 32, 8, 4),
+                                             (16380, 32, 6, 3), (1008, 5, 6, 3), (16000, 32, 10, 5), (4000, 7, 10, 5)])
+def test_row_tables_describe_the_graph(n, members, wr, wc):
+    H, R, vtab, ctab, lds_edge = tables(n, members, wr, wc)
     s, nnz = H.shape[0], H.nnz
     assert 1 <= R <= RMAX
-    # CSR row of every CSC edge, as ldpc_bp_create lays the rows out: 8 * check + place among the check's bits
+    # CSR row of every CSC edge, as ldpc_bp_create lays the rows out: wr * check + place among the check's bits
     csr = H.tocsr()
     csr.sort_indices()
     place = {}
     for i in range(s):
         for k, j in enumerate(csr.indices[csr.indptr[i]:csr.indptr[i + 1]]):
-            place[(i, int(j))] = 8 * i + k
-    bits = vtab[:, 8] & 0x7FFFFFFF
+            place[(i, int(j))] = wr * i + k
+    bits = vtab[:, 2 * wc] & 0x7FFFFFFF
     assert np.array_equal(np.sort(bits), np.arange(n)), "the dealt bit order must be a permutation of the bits"
-    flagged = vtab[:, 8] < 0
+    flagged = vtab[:, 2 * wc] < 0
     member_of_pos = (np.arange(n) // 4) % members                  # how the kernel deals positions: chunks of 4
     member_of_check = (np.arange(s) // 2) % members                # ... and checks: chunks of 2
     seen_slots = set()
@@ -50,15 +55,15 @@ def test_row_tables_describe_the_graph(n, members):
     for p in range(n):
         j = int(bits[p])
         rows = [place[(int(i), j)] for i in H.indices[H.indptr[j]:H.indptr[j + 1]]]
-        assert list(vtab[p, 0:4]) == rows, "a position must carry the four message rows of its bit, checks ascending"
-        lrows = vtab[p, 4:8]
+        assert list(vtab[p, 0:wc]) == rows, "a position must carry the message rows of its bit, checks ascending"
+        lrows = vtab[p, wc:2 * wc]
         assert bool(flagged[p]) == bool((lrows >= 0).any())
         for q, lr in zip(rows, lrows):
             if lr < 0:
                 continue
             in_lds += 1
             m = int(member_of_pos[p])
-            assert member_of_check[q // 8] == m, "a row in LDS must belong to ONE member in both sweeps"
+            assert member_of_check[q // wr] == m, "a row in LDS must belong to ONE member in both sweeps"
             assert 0 <= lr < R and (m, int(lr)) not in seen_slots
             seen_slots.add((m, int(lr)))
             assert lds_edge[m, lr] == q, "the member's write-back list must name the same row"
@@ -67,30 +72,40 @@ def test_row_tables_describe_the_graph(n, members):
     for i in range(s):
         mask, base = int(ctab[i, 0]) & 0xFFFFFFFF, int(ctab[i, 1])
         m = int(member_of_check[i])
-        want = [k for k in range(8) if (lds_edge[m] == 8 * i + k).any()]
-        assert [k for k in range(8) if (mask >> k) & 1] == want
+        want = [k for k in range(wr) if (lds_edge[m] == wr * i + k).any()]
+        assert [k for k in range(32) if (mask >> k) & 1] == want
         for t, k in enumerate(want):
-            assert lds_edge[m, base + t] == 8 * i + k
-    # what it is for: about a quarter of the edges are candidates, the LDS holds up to 312 rows per member
-    assert in_lds >= min(0.15 * nnz, 0.9 * RMAX * members) * 0.9
+            assert lds_edge[m, base + t] == wr * i + k
+    # what it is for: one edge per bit (1 / wc of the edges) is a candidate, the LDS holds up to 312 rows per member
+    assert in_lds >= min(0.6 / wc * nnz, 0.9 * RMAX * members) * 0.9
     per_member = (lds_edge >= 0).sum(axis=1)
-    assert per_member.max() == R and per_member.min() >= 0.8 * min(R, nnz // 4 // members * 0.9)
+    assert per_member.max() == R and per_member.min() >= 0.8 * min(R, nnz // wc // members * 0.9)
 
 
-def test_only_4_8_regular_graphs():
-    H = ldpc.codes.parity_check_csc(1008, 6, 3)
-    colptr = np.ascontiguousarray(H.indptr, dtype=np.int64)
-    rowval = np.ascontiguousarray(H.indices, dtype=np.int64)
-    R = ctypes.c_int32()
+def test_only_regular_graphs_with_an_instantiation():
     buf = np.zeros(1 << 20, dtype=np.int32)
-    st = ldpc._capi.lib().ldpc_debug_team_rows(H.shape[0], 1008, colptr.ctypes.data, rowval.ctypes.data, 8, ctypes.byref(R),
-                                               buf.ctypes.data, buf.ctypes.data, buf.ctypes.data)
-    assert st == 5      # LDPC_ERR_UNSUPPORTED
+    R, vt, deg = ctypes.c_int32(), ctypes.c_int32(), (ctypes.c_int32 * 2)()
+
+    def status(H):
+        H = H.tocsc()
+        H.sort_indices()
+        colptr = np.ascontiguousarray(H.indptr, dtype=np.int64)
+        rowval = np.ascontiguousarray(H.indices, dtype=np.int64)
+        return ldpc._capi.lib().ldpc_debug_team_rows(H.shape[0], H.shape[1], colptr.ctypes.data, rowval.ctypes.data, 8,
+                                                     ctypes.byref(deg), ctypes.byref(vt), ctypes.byref(R), buf.ctypes.data,
+                                                     buf.ctypes.data, buf.ctypes.data)
+
+    assert status(ldpc.codes.parity_check_csc(1008, 6, 3)) == 0
+    assert status(ldpc.codes.parity_check_csc(1000, 10, 9)) == 5      # LDPC_ERR_UNSUPPORTED: no (10,9) instantiation
+    H = ldpc.codes.parity_check_csc(1008, 6, 3).tolil()
+    i, j = H.nonzero()
+    H[i[0], j[0]] = 0                                                  # one edge less: not regular any more
+    assert status(H.tocsc()) == 5
 
 
-def plan(nnz, batch, cache_mib=240, max_iters=50, regular=1):
+def plan(nnz, batch, cache_mib=240, max_iters=50, regular=1, dv=4):
     out = (ctypes.c_int32 * 6)()
-    ldpc._capi.check(ldpc._capi.lib().ldpc_debug_team_plan(nnz, max_iters, batch, cache_mib, regular, ctypes.byref(out)))
+    ldpc._capi.check(ldpc._capi.lib().ldpc_debug_team_plan(nnz, max_iters, batch, cache_mib, dv if regular else 0, ctypes.byref(out)))
     return dict(zip(("members", "teams", "grid", "xcds", "scatter", "rows"), list(out)))
 
 
