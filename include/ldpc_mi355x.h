@@ -61,6 +61,9 @@ typedef struct ldpc_bp_info {
     int32_t last_kernel;      /* kernel the most recent batch call ran: 0 none yet, 1 HBM-streaming tile kernel,
                                  2 LDS-resident, 3 node-parallel, 4 team (numbered like kernel_variant) */
     int32_t last_team_size;   /* workgroups per tile of that call (1 unless last_kernel == 4) */
+    int32_t last_lds_rows;    /* team kernel: message rows each member kept in its LDS in that call (0 = every row in the
+                                 team's slot; regular graphs with a rows-in-LDS instantiation keep up to 312) */
+    int32_t reserved_info[3];
 } ldpc_bp_info;
 
 /* Optional knobs; pass NULL to ldpc_bp_create for defaults.  Zero = default. */

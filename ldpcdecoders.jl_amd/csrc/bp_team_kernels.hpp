@@ -137,6 +137,17 @@ struct TeamParams {
                                 // handle (low 31 bits, never 0), so that the report can name the first call that was hit;
                                 // bit 31 set = the ROLL CALL failed: the call wrote no output at all
     unsigned int rollcall_ticks;   // how long (100 MHz ticks) the members of a team wait for each other at launch
+    // Running ahead (fresh tiles): with the convergence test of an iteration under way a member goes straight on to the
+    // NEXT iteration's check sweep -- the sweep does not depend on the test's outcome, only on the messages -- and the
+    // barrier after that sweep serves the test too: two team barriers an iteration instead of three (C3 full-50:
+    // 909 -> 882 ms).  The variable sweep after it must not overwrite the decision words the test's verdict still
+    // captures from, hence a second set of them (errmask_alt: odd iterations).  A sweep ahead is wasted when the
+    // verdict stops every lane, and it delays a straggler hand-off by an iteration (the messages are half an iteration
+    // on); so a team only runs ahead while its tile is QUIET -- the previous verdict stopped no lane -- and at least
+    // ahead_min lanes are active: tiles whose lanes have begun to converge take the three-barrier iteration
+    // (per 0.02, ~3 iterations a tile: running ahead on lane count alone cost 13 %).
+    u64 *errmask_alt;           // [ntiles][n] or nullptr (no running ahead: passes over packed levels)
+    int ahead_min;              // active lanes from which on a quiet tile's team runs ahead (0 = never)
 };
 constexpr unsigned int kTeamRollcallFailed = 0x80000000u;
 
@@ -374,7 +385,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     double *const Mt = p.msg + (size_t)(resumed ? tile : team) * (size_t)p.slot_stride + lane;
     u64 *const mw = tp.mism + (size_t)tile * (size_t)tp.mism_stride;
     const u64 *syn = synmask + (size_t)tile * s;
-    u64 *em = p.errmask + (size_t)tile * n;
+    u64 *em = p.errmask + (size_t)tile * n;   // decision words of the iteration in hand (see em_even / em_odd)
     u64 *fin = p.finmask + (size_t)tile * n;
     const long long b0 = (long long)tile * kTile;
     const long long left = batch - b0;
@@ -386,157 +397,149 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     const int it0 = (resumed && ((valid >> lane) & 1ull)) ? cd->it0[b0 + lane] : 0;
     int my_iters = 0, my_conv = 0, it = 0;
 
-    while (active != 0) {   // (every lane retires at the latest when its total reaches max_iters)
-        ++it;
-        const bool first = (it == 1) && !resumed;
-        const u64 t0 = wall_clock64();
-        // ---- check-node sweep  (:135-150) in chunks of kTeamCheckChunk checks
-        {
-            const int nch = (s + kTeamCheckChunk - 1) / kTeamCheckChunk;
-            auto chunk = [&](int c) {
-                const int i1 = min(s, (c + 1) * kTeamCheckChunk);
-                if constexpr (LROWS) {
-                    // every check has the full degree (the host instantiates this only for such graphs); col_ptr is ctab.
-                    // (Pairs of checks / bits with rows in LDS loaded together measured slower, not faster.)
-                    typedef int v4i __attribute__((ext_vector_type(4)));
-                    const int i = c * kTeamCheckChunk;
-                    if (kTeamCheckChunk == 2 && i + 2 == i1) {
-                        const v4i ct = *(const v4i *)(col_ptr + 2 * i);   // both checks' masks and bases in one scalar load
-                        const u64 s0 = syn[i], s1 = syn[i + 1];
-                        const double sg0 = ((s0 >> lane) & 1ull) ? -1.0 : 1.0, sg1 = ((s1 >> lane) & 1ull) ? -1.0 : 1.0;
-                        double *const M0 = Mt + (size_t)i * DC * kTile, *const M1 = M0 + (size_t)DC * kTile;
-                        if ((ct.x | ct.z) == 0 && !first && tp.pairs) {
-                            check_update_pair<DC>(M0, M1, sg0, sg1);
-                        } else if (first) {
-                            check_update_mixed<DC, true>(M0, Lr + (size_t)ct.y * kTile, (unsigned int)ct.x, sg0, r);
-                            check_update_mixed<DC, true>(M1, Lr + (size_t)ct.w * kTile, (unsigned int)ct.z, sg1, r);
-                        } else {
-                            if (ct.x == 0) check_update_exact<DC, false>(M0, sg0, r);
-                            else check_update_mixed<DC, false>(M0, Lr + (size_t)ct.y * kTile, (unsigned int)ct.x, sg0, r);
-                            if (ct.z == 0) check_update_exact<DC, false>(M1, sg1, r);
-                            else check_update_mixed<DC, false>(M1, Lr + (size_t)ct.w * kTile, (unsigned int)ct.z, sg1, r);
-                        }
-                        return;
-                    }
-                    for (int ii = i; ii < i1; ++ii) {
-                        const unsigned int mask = (unsigned int)col_ptr[2 * ii];
-                        const double sigma = ((syn[ii] >> lane) & 1ull) ? -1.0 : 1.0;
-                        double *const M = Mt + (size_t)ii * DC * kTile;
-                        double *const L = Lr + (size_t)col_ptr[2 * ii + 1] * kTile;
-                        if (first) check_update_mixed<DC, true>(M, L, mask, sigma, r);
-                        else check_update_mixed<DC, false>(M, L, mask, sigma, r);
+    // running ahead (TeamParams::errmask_alt): decision words of odd iterations live in the second set
+    const bool can_run_ahead = !resumed && tp.errmask_alt != nullptr && tp.ahead_min > 0;
+    u64 *const em_even = em, *const em_odd = can_run_ahead ? tp.errmask_alt + (size_t)tile * n : em;
+    bool have_check = false;                                   // this iteration's check sweep was done ahead, with the last test
+    bool quiet = true;                                         // the last verdict stopped no lane (running ahead: TeamParams)
+
+    // ---- check-node sweep  (:135-150) in chunks of kTeamCheckChunk checks
+    auto check_sweep = [&](const bool first) {
+        const int nch = (s + kTeamCheckChunk - 1) / kTeamCheckChunk;
+        auto chunk = [&](int c) {
+            const int i1 = min(s, (c + 1) * kTeamCheckChunk);
+            if constexpr (LROWS) {
+                // every check has the full degree (the host instantiates this only for such graphs); col_ptr is ctab.
+                // (Pairs of checks / bits with rows in LDS loaded together measured slower, not faster.)
+                typedef int v4i __attribute__((ext_vector_type(4)));
+                const int i = c * kTeamCheckChunk;
+                if (kTeamCheckChunk == 2 && i + 2 == i1) {
+                    const v4i ct = *(const v4i *)(col_ptr + 2 * i);   // both checks' masks and bases in one scalar load
+                    const u64 s0 = syn[i], s1 = syn[i + 1];
+                    const double sg0 = ((s0 >> lane) & 1ull) ? -1.0 : 1.0, sg1 = ((s1 >> lane) & 1ull) ? -1.0 : 1.0;
+                    double *const M0 = Mt + (size_t)i * DC * kTile, *const M1 = M0 + (size_t)DC * kTile;
+                    if ((ct.x | ct.z) == 0 && !first && tp.pairs) {
+                        check_update_pair<DC>(M0, M1, sg0, sg1);
+                    } else if (first) {
+                        check_update_mixed<DC, true>(M0, Lr + (size_t)ct.y * kTile, (unsigned int)ct.x, sg0, r);
+                        check_update_mixed<DC, true>(M1, Lr + (size_t)ct.w * kTile, (unsigned int)ct.z, sg1, r);
+                    } else {
+                        if (ct.x == 0) check_update_exact<DC, false>(M0, sg0, r);
+                        else check_update_mixed<DC, false>(M0, Lr + (size_t)ct.y * kTile, (unsigned int)ct.x, sg0, r);
+                        if (ct.z == 0) check_update_exact<DC, false>(M1, sg1, r);
+                        else check_update_mixed<DC, false>(M1, Lr + (size_t)ct.w * kTile, (unsigned int)ct.z, sg1, r);
                     }
                     return;
                 }
-                if (kTeamCheckChunk == 2 && !first && tp.pairs && i1 == c * 2 + 2) {
-                    // the usual case, two checks of the full degree: all 2 DC rows in flight at once
-                    const int i = c * 2;
-                    const int e0 = row_ptr[i], e1 = row_ptr[i + 1], e2 = row_ptr[i + 2];
-                    if (e1 - e0 == DC && e2 - e1 == DC) {
-                        const double sg0 = ((syn[i] >> lane) & 1ull) ? -1.0 : 1.0, sg1 = ((syn[i + 1] >> lane) & 1ull) ? -1.0 : 1.0;
-                        check_update_pair<DC>(Mt + (size_t)e0 * kTile, Mt + (size_t)e1 * kTile, sg0, sg1);
-                        return;
-                    }
+                for (int ii = i; ii < i1; ++ii) {
+                    const unsigned int mask = (unsigned int)col_ptr[2 * ii];
+                    const double sigma = ((syn[ii] >> lane) & 1ull) ? -1.0 : 1.0;
+                    double *const M = Mt + (size_t)ii * DC * kTile;
+                    double *const L = Lr + (size_t)col_ptr[2 * ii + 1] * kTile;
+                    if (first) check_update_mixed<DC, true>(M, L, mask, sigma, r);
+                    else check_update_mixed<DC, false>(M, L, mask, sigma, r);
                 }
-                for (int i = c * kTeamCheckChunk; i < i1; ++i) {
-                    const int e0 = row_ptr[i];
-                    const int deg = row_ptr[i + 1] - e0;
-                    const double sigma = ((syn[i] >> lane) & 1ull) ? -1.0 : 1.0;
-                    if (first) check_update<DC, true>(Mt + (size_t)e0 * kTile, deg, sigma, r);
-                    else check_update<DC, false>(Mt + (size_t)e0 * kTile, deg, sigma, r);
-                }
-            };
-            // this member's share is chunks rank, rank + G, ...; its waves take them from the counter in LDS
-            const int mine = (nch - rank + G - 1) / G;
-            for (int l = w; l < mine;) {
-                chunk(l * G + rank);
-                l = tp.dynamic ? W + team_deal(&sh_deal[0], lane) : l + W;
+                return;
             }
-        }
-        const u64 t1 = wall_clock64();
-        if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd, sh_deal)) return;
-        if (!placed) {
-            if (threadIdx.x == 0)
-                sh_one_xcd = __popc(__hip_atomic_load(xccs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 1;
-            __syncthreads();
-            one_xcd = sh_one_xcd != 0 && !tp.always_release;
-            placed = true;
-        }
-        const u64 t2 = wall_clock64();
-        // ---- variable-node sweep  (:152-178).  Across XCDs a chunk is 16 consecutive bits, so that a 128-byte line of
-        //      decision words has one writer; inside one XCD (one L2) 4 bits, for an even finish
-        {
-            const int vb = (one_xcd || LROWS) ? 4 : 16;     // (LROWS: the host dealt the bits in chunks of 4)
-            const int nch = (n + vb - 1) / vb;
-            auto decide = [&](int j, double T) {
-                const u64 dec = __ballot(T >= 1.0);                                // :164-168
-                if (WANT_LLR) {
-                    if ((active >> lane) & 1ull) p.llr[((size_t)tile * n + j) * kTile + lane] = log(1.0 / T);  // :163
-                }
-                if (lane == 0) em[j] = dec;   // every lane; the stopped ones' decisions were captured when they stopped
-            };
-            auto chunk = [&](int c) {
-                const int j1 = min(n, (c + 1) * vb);
-                int j = c * vb;
-                if constexpr (LROWS) {
-                    // positions of the dealt bit order; every bit has the full degree; csc2csr is vtab.  Everything the
-                    // table says about the four positions of a chunk is asked for at once (one scalar round trip per chunk)
-                    constexpr int VT = team_vtab_words(DV);
-                    auto single = [&](const TeamVRec<DV> &a) {
-                        if (a.bit >= 0) decide(a.bit, bit_update_exact_v<DV>(Mt, a.pos, r));
-                        else decide(a.bit & 0x7fffffff, bit_update_mixed<DV>(Mt, Lr, a.pos, a.lrow, r));
-                    };
-                    auto two = [&](const TeamVRec<DV> &a, const TeamVRec<DV> &b) {
-                        if ((a.bit | b.bit) >= 0 && tp.pairs) {   // neither has a row in LDS: both loaded together
-                            double T0, T1;
-                            bit_update_pair_v<DV>(Mt, a.pos, b.pos, r, T0, T1);
-                            decide(a.bit, T0);
-                            decide(b.bit, T1);
-                        } else {
-                            single(a);
-                            single(b);
-                        }
-                    };
-                    int q = j;
-                    if (q + 4 == j1) {                          // the usual chunk: the table rows of all four positions at once
-                        const int *const vt = csc2csr + (size_t)q * VT;
-                        const TeamVRec<DV> A = team_vrec_load<DV>(vt), B = team_vrec_load<DV>(vt + VT), C = team_vrec_load<DV>(vt + 2 * VT),
-                                           D = team_vrec_load<DV>(vt + 3 * VT);
-                        two(A, B);
-                        two(C, D);
-                        return;
-                    }
-                    for (; q + 1 < j1; q += 2) {
-                        const int *const vt = csc2csr + (size_t)q * VT;
-                        const TeamVRec<DV> A = team_vrec_load<DV>(vt), B = team_vrec_load<DV>(vt + VT);
-                        two(A, B);
-                    }
-                    for (; q < j1; ++q) single(team_vrec_load<DV>(csc2csr + (size_t)q * VT));
+            if (kTeamCheckChunk == 2 && !first && tp.pairs && i1 == c * 2 + 2) {
+                // the usual case, two checks of the full degree: all 2 DC rows in flight at once
+                const int i = c * 2;
+                const int e0 = row_ptr[i], e1 = row_ptr[i + 1], e2 = row_ptr[i + 2];
+                if (e1 - e0 == DC && e2 - e1 == DC) {
+                    const double sg0 = ((syn[i] >> lane) & 1ull) ? -1.0 : 1.0, sg1 = ((syn[i + 1] >> lane) & 1ull) ? -1.0 : 1.0;
+                    check_update_pair<DC>(Mt + (size_t)e0 * kTile, Mt + (size_t)e1 * kTile, sg0, sg1);
                     return;
                 }
-                for (; tp.pairs && j + 1 < j1; j += 2) {           // two bits of the full degree: all 2 DV rows in flight at once
-                    const int c0 = col_ptr[j], c1 = col_ptr[j + 1], c2 = col_ptr[j + 2];
-                    if (c1 - c0 != DV || c2 - c1 != DV) break;
-                    double T0, T1;
-                    bit_update_pair<DV>(Mt, csc2csr + c0, csc2csr + c1, r, T0, T1);
-                    decide(j, T0);
-                    decide(j + 1, T1);
-                }
-                for (; j < j1; ++j) {
-                    const int c0 = col_ptr[j];
-                    const int deg = col_ptr[j + 1] - c0;
-                    decide(j, bit_update<DV>(Mt, csc2csr + c0, deg, r));
-                }
-            };
-            const int mine = (nch - rank + G - 1) / G;
-            for (int l = w; l < mine;) {
-                chunk(l * G + rank);
-                l = tp.dynamic ? W + team_deal(&sh_deal[1], lane) : l + W;
             }
+            for (int i = c * kTeamCheckChunk; i < i1; ++i) {
+                const int e0 = row_ptr[i];
+                const int deg = row_ptr[i + 1] - e0;
+                const double sigma = ((syn[i] >> lane) & 1ull) ? -1.0 : 1.0;
+                if (first) check_update<DC, true>(Mt + (size_t)e0 * kTile, deg, sigma, r);
+                else check_update<DC, false>(Mt + (size_t)e0 * kTile, deg, sigma, r);
+            }
+        };
+        // this member's share is chunks rank, rank + G, ...; its waves take them from the counter in LDS
+        const int mine = (nch - rank + G - 1) / G;
+        for (int l = w; l < mine;) {
+            chunk(l * G + rank);
+            l = tp.dynamic ? W + team_deal(&sh_deal[0], lane) : l + W;
         }
-        const u64 t3 = wall_clock64();
-        if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd, sh_deal)) return;
-        // ---- convergence test (:180-184): lane = check, words = 64 syndromes; the team ORs into mw[it-1]
+    };
+    // ---- variable-node sweep  (:152-178).  Across XCDs a chunk is 16 consecutive bits, so that a 128-byte line of
+    //      decision words has one writer; inside one XCD (one L2) 4 bits, for an even finish
+    auto var_sweep = [&]() {
+        const int vb = (one_xcd || LROWS) ? 4 : 16;     // (LROWS: the host dealt the bits in chunks of 4)
+        const int nch = (n + vb - 1) / vb;
+        auto decide = [&](int j, double T) {
+            const u64 dec = __ballot(T >= 1.0);                                // :164-168
+            if (WANT_LLR) {
+                if ((active >> lane) & 1ull) p.llr[((size_t)tile * n + j) * kTile + lane] = log(1.0 / T);  // :163
+            }
+            if (lane == 0) em[j] = dec;   // every lane; the stopped ones' decisions were captured when they stopped
+        };
+        auto chunk = [&](int c) {
+            const int j1 = min(n, (c + 1) * vb);
+            int j = c * vb;
+            if constexpr (LROWS) {
+                // positions of the dealt bit order; every bit has the full degree; csc2csr is vtab.  Everything the
+                // table says about the four positions of a chunk is asked for at once (one scalar round trip per chunk)
+                constexpr int VT = team_vtab_words(DV);
+                auto single = [&](const TeamVRec<DV> &a) {
+                    if (a.bit >= 0) decide(a.bit, bit_update_exact_v<DV>(Mt, a.pos, r));
+                    else decide(a.bit & 0x7fffffff, bit_update_mixed<DV>(Mt, Lr, a.pos, a.lrow, r));
+                };
+                auto two = [&](const TeamVRec<DV> &a, const TeamVRec<DV> &b) {
+                    if ((a.bit | b.bit) >= 0 && tp.pairs) {   // neither has a row in LDS: both loaded together
+                        double T0, T1;
+                        bit_update_pair_v<DV>(Mt, a.pos, b.pos, r, T0, T1);
+                        decide(a.bit, T0);
+                        decide(b.bit, T1);
+                    } else {
+                        single(a);
+                        single(b);
+                    }
+                };
+                int q = j;
+                if (q + 4 == j1) {                          // the usual chunk: the table rows of all four positions at once
+                    const int *const vt = csc2csr + (size_t)q * VT;
+                    const TeamVRec<DV> A = team_vrec_load<DV>(vt), B = team_vrec_load<DV>(vt + VT), C = team_vrec_load<DV>(vt + 2 * VT),
+                                       D = team_vrec_load<DV>(vt + 3 * VT);
+                    two(A, B);
+                    two(C, D);
+                    return;
+                }
+                for (; q + 1 < j1; q += 2) {
+                    const int *const vt = csc2csr + (size_t)q * VT;
+                    const TeamVRec<DV> A = team_vrec_load<DV>(vt), B = team_vrec_load<DV>(vt + VT);
+                    two(A, B);
+                }
+                for (; q < j1; ++q) single(team_vrec_load<DV>(csc2csr + (size_t)q * VT));
+                return;
+            }
+            for (; tp.pairs && j + 1 < j1; j += 2) {           // two bits of the full degree: all 2 DV rows in flight at once
+                const int c0 = col_ptr[j], c1 = col_ptr[j + 1], c2 = col_ptr[j + 2];
+                if (c1 - c0 != DV || c2 - c1 != DV) break;
+                double T0, T1;
+                bit_update_pair<DV>(Mt, csc2csr + c0, csc2csr + c1, r, T0, T1);
+                decide(j, T0);
+                decide(j + 1, T1);
+            }
+            for (; j < j1; ++j) {
+                const int c0 = col_ptr[j];
+                const int deg = col_ptr[j + 1] - c0;
+                decide(j, bit_update<DV>(Mt, csc2csr + c0, deg, r));
+            }
+        };
+        const int mine = (nch - rank + G - 1) / G;
+        for (int l = w; l < mine;) {
+            chunk(l * G + rank);
+            l = tp.dynamic ? W + team_deal(&sh_deal[1], lane) : l + W;
+        }
+    };
+    // ---- convergence test (:180-184) of iteration it_t on the decision words em_t: lane = check, words = 64 syndromes;
+    //      the team ORs into mw[it_t - 1]
+    auto run_test = [&](const int it_t, const u64 *em_t) {
         u64 mism = 0;
         for (int i = gw * 64 + lane; i < s; i += GW * 64) {
             u64 par = 0;
@@ -547,7 +550,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
                 for (int q = 0; q < 8; ++q) jb[q] = (e + q < e1) ? edge_bit[e + q] : -1;
                 u64 wv[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) wv[q] = (jb[q] >= 0) ? em[jb[q]] : 0ull;
+                for (int q = 0; q < 8; ++q) wv[q] = (jb[q] >= 0) ? em_t[jb[q]] : 0ull;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) par ^= wv[q];
             }
@@ -560,24 +563,65 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
             u64 part = 0;
 #pragma unroll
             for (int q = 0; q < W; ++q) part |= sh_mism[q];
-            if (part) __hip_atomic_fetch_or(&mw[it - 1], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (part) __hip_atomic_fetch_or(&mw[it_t - 1], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd, sh_deal)) return;
-        const u64 U = uniform64(never | __hip_atomic_load(&mw[it - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        const int total = it0 + it;                            // iterations of this lane's syndrome so far
+    };
+    // ---- the verdict of that test (after a team barrier): who stopped, and with which decisions
+    auto verdict = [&](const int it_t, const u64 *em_t) {
+        const u64 U = uniform64(never | __hip_atomic_load(&mw[it_t - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const int total = it0 + it_t;                           // iterations of this lane's syndrome so far
         const u64 newly = active & ~U;
         if ((newly >> lane) & 1ull) { my_iters = total; my_conv = 1; }
         active &= U;
         const u64 spent = __ballot(total >= p.max_iters) & active;   // out of iterations: retires unconverged
         if ((spent >> lane) & 1ull) { my_iters = total; my_conv = 0; }
         active &= ~spent;
-        // capture the stopping lanes' decisions of this iteration (every member its share of the bits; the decision
-        // words were made visible by the barrier before the test, and nobody rewrites them before the barrier
-        // after the next check sweep, which this member only joins when it is through here)
+        // capture the stopping lanes' decisions of that iteration (every member its share of the bits; the decision
+        // words were made visible by the barrier before the test, and nobody rewrites them before a team barrier
+        // that this member only joins when it is through here: the next variable sweep writes the OTHER set of
+        // words when the team runs ahead, and comes after the barrier of the next check sweep when it does not)
         const u64 stopped = newly | spent;
         if (stopped != 0) {
-            for (int j = gw * 64 + lane; j < n; j += GW * 64) fin[j] = (fin[j] & ~stopped) | (em[j] & stopped);
+            for (int j = gw * 64 + lane; j < n; j += GW * 64) fin[j] = (fin[j] & ~stopped) | (em_t[j] & stopped);
         }
+        quiet = stopped == 0;
+        return total;
+    };
+
+    while (active != 0) {   // (every lane retires at the latest when its total reaches max_iters)
+        ++it;
+        em = (it & 1) ? em_odd : em_even;
+        const u64 t0 = wall_clock64();
+        if (!have_check) check_sweep((it == 1) && !resumed);
+        const u64 t1 = wall_clock64();
+        if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd, sh_deal)) return;
+        if (!placed) {
+            if (threadIdx.x == 0)
+                sh_one_xcd = __popc(__hip_atomic_load(xccs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 1;
+            __syncthreads();
+            one_xcd = sh_one_xcd != 0 && !tp.always_release;
+            placed = true;
+        }
+        if (have_check) {                                      // the test of iteration it - 1 rode with that sweep: its verdict
+            have_check = false;
+            verdict(it - 1, ((it - 1) & 1) ? em_odd : em_even);
+            if (active == 0) break;                            // (every lane stopped: the sweep ahead was for nothing)
+        }
+        const u64 t2 = wall_clock64();
+        var_sweep();
+        const u64 t3 = wall_clock64();
+        if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd, sh_deal)) return;
+        run_test(it, em);
+        if (can_run_ahead && quiet && it < p.max_iters && (int)__popcll(active) >= tp.ahead_min) {
+            const u64 t3b = wall_clock64();
+            check_sweep(false);                                // iteration it + 1; the barrier at the top of the loop closes both
+            have_check = true;
+            const u64 t4 = wall_clock64();
+            tk_check += (t1 - t0) + (t4 - t3b); tk_var += t3 - t2; tk_rest += (t2 - t1) + (t3b - t3);
+            continue;
+        }
+        if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd, sh_deal)) return;
+        const int total = verdict(it, em);
         const u64 t4 = wall_clock64();
         tk_check += t1 - t0; tk_var += t3 - t2; tk_rest += (t2 - t1) + (t4 - t3);   // rest = barriers + test
         // few stragglers left: hand them, with their messages, to the next level (decided alike by every member;

@@ -345,6 +345,7 @@ struct ldpc_bp_decoder {
     int resident_fixed = 0;   // workspace slots requested by the caller, 0 = fill the chip
     int last_threads = 512, last_grid = 0;   // geometry of the most recent streaming launch (info)
     int last_kernel = 0, last_team = 1;      // which kernel the most recent call ran (info)
+    int last_lds_rows = 0;                   // ... and how many message rows each team member kept in LDS
     size_t ws_budget = 0;     // bytes the message workspace may take
     int blocks_cache[2][17];  // [want_llr][waves per tile] -> resident workgroups per CU, -1 = not queried yet
     int variant = 0;          // 0 auto, 1 HBM-streaming tile kernel, 2 LDS-resident kernel, 3 node-parallel kernel
@@ -371,6 +372,8 @@ struct ldpc_bp_decoder {
     int team_xcds = 0;        // LDPC_TEAM_XCDS: XCDs that host persistent teams, fixed (experiments; 0 = team_fit() chooses)
     int team_dynamic = 1;     // LDPC_TEAM_DYNAMIC: a member's waves take its chunks from a counter in LDS (0: every W-th)
     int team_pairs = 1;       // LDPC_TEAM_PAIRS: two nodes of the full degree are loaded together
+    int team_ahead = 32;      // LDPC_TEAM_AHEAD: active lanes from which on a team starts the next check sweep with the convergence
+                              // test still under way (two team barriers an iteration instead of three); 0 = never
     // latency mode of the host-pointer entry (tiny batches, a plain decode!): the kernel reads and writes a
     // host-mapped staging image and raises a flag in it; no copies, no events, no stream synchronisation
     DevBuf done_ctr;          // one device word, zero between launches
@@ -767,6 +770,7 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     if (const char *e = exp_env("LDPC_TEAM_DYNAMIC")) d->team_dynamic = std::atoi(e) != 0;
     if (const char *e = exp_env("LDPC_TEAM_XCDS")) d->team_xcds = std::max(1, std::min(8, std::atoi(e)));
     if (const char *e = exp_env("LDPC_TEAM_PAIRS")) d->team_pairs = std::atoi(e) != 0;
+    if (const char *e = exp_env("LDPC_TEAM_AHEAD")) d->team_ahead = std::max(0, std::min(65, std::atoi(e)));
     if (const char *e = exp_env("LDPC_TEAM_MAX")) { d->team_max = std::max(1, std::min(kTeamMaxMembers, std::atoi(e))); d->team_max_set = true; }
     {
         void *fp = nullptr, *fd = nullptr;
@@ -875,6 +879,7 @@ ldpc_status ldpc_bp_get_info(const ldpc_bp_decoder *d, ldpc_bp_info *info)
     for (const DevBuf *b : all) info->workspace_bytes += (int64_t)b->cap;
     info->last_kernel = d->last_kernel;
     info->last_team_size = d->last_team;
+    info->last_lds_rows = d->last_lds_rows;
     return LDPC_OK;
 }
 
@@ -1346,7 +1351,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         const int logS = d->lds_logS[want_llr_early ? 1 : 0];
         const int64_t ngroups64 = (batch + (1ll << logS) - 1) >> logS;
         if (ngroups64 > (1ll << 30)) return fail(LDPC_ERR_UNSUPPORTED, "batch too large for one call");
-        d->last_kernel = 2; d->last_team = 1;
+        d->last_kernel = 2; d->last_team = 1; d->last_lds_rows = 0;
         LdsParams lp{};
         lp.s = (int)s; lp.n = (int)n; lp.nnz = (int)d->nnz; lp.max_iters = (int)d->max_iters;
         lp.logS = logS; lp.ngroups = (int)ngroups64; lp.batch = batch;
@@ -1414,7 +1419,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         const size_t stride = (std::max<size_t>((size_t)d->nnz, 1) + 63) & ~(size_t)63;   // 512-byte aligned slots
         ldpc_status nst = d->node_msg.ensure(mlds ? 64 : (size_t)ngrid * stride * sizeof(double));
         if (nst != LDPC_OK) return nst;
-        d->last_kernel = 3; d->last_team = 1;
+        d->last_kernel = 3; d->last_team = 1; d->last_lds_rows = 0;
         NodeParams np{};
         np.s = (int)s; np.n = (int)n; np.nnz = (int)d->nnz; np.max_iters = (int)d->max_iters;
         np.batch = batch; np.r = d->per / (1 - d->per);
@@ -1462,7 +1467,8 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     ldpc_status st;
     if ((st = d->synmask.ensure(std::max<size_t>((size_t)ntiles * s, 1) * sizeof(u64))) != LDPC_OK) return st;
     if ((st = d->nevermask.ensure((size_t)ntiles * sizeof(u64))) != LDPC_OK) return st;
-    if ((st = d->errmask.ensure(std::max<size_t>((size_t)ntiles * n, 1) * sizeof(u64))) != LDPC_OK) return st;
+    // (two sets of decision words: a team that runs ahead -- bp_team_kernels.hpp -- writes those of odd iterations into the second)
+    if ((st = d->errmask.ensure(2 * std::max<size_t>((size_t)ntiles * n, 1) * sizeof(u64))) != LDPC_OK) return st;
     if ((st = d->finmask.ensure(std::max<size_t>((size_t)ntiles * n, 1) * sizeof(u64))) != LDPC_OK) return st;
     if (want_llr && (st = d->llr_t.ensure(std::max<size_t>((size_t)ntiles * n, 1) * kTile * sizeof(double))) != LDPC_OK)
         return st;
@@ -1510,6 +1516,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     d->last_grid = team > 1 ? plan.nteams * team : grid;   // (teams: the workgroups that take part; on an XCD that hosts no team the blocks leave at once)
     d->last_kernel = team > 1 ? 4 : 1;
     d->last_team = team;
+    d->last_lds_rows = 0;
     const size_t slot_stride_bytes = std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double) + slot_pad_bytes();
     if ((st = ensure_workspace(d, (size_t)grid * slot_stride_bytes, grid, slot_stride_bytes, stream)) != LDPC_OK)
         return st;
@@ -1667,6 +1674,8 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         tp.inject_fault = 0;
         tp.ticket = ticket;
         tp.rollcall_ticks = d->rollcall_ticks;
+        tp.errmask_alt = nullptr;
+        tp.ahead_min = 0;
         return LDPC_OK;
     };
     bool team_ran = team > 1;
@@ -1678,6 +1687,8 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         tp.xcds = plan.xcds;
         tp.scatter = team_scatter ? 1 : 0;
         tp.inject_fault = d->inject_fault;   // (tests; the kernel only looks at it in the experiments build)
+        tp.errmask_alt = (u64 *)d->errmask.p + std::max<size_t>((size_t)ntiles * n, 1);
+        tp.ahead_min = d->team_ahead;
         team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr);
         size_t team_lds = team_lds_bytes();
         const int *t_col = a_col, *t_c2r = a_c2r;
@@ -1688,6 +1699,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             int occ_rows = 0;
             if (tkr && d->prepare_kernel((const void *)tkr, LDPC_TEAM_THREADS, need, &occ_rows) == LDPC_OK && occ_rows >= 1) {
                 tk = tkr; team_lds = need;
+                d->last_lds_rows = d->rows_R;
                 tp.rows.lds_edge = (const int *)d->rows_lds_edge.p;
                 tp.rows.R = d->rows_R;
                 t_col = (const int *)d->rows_ctab.p;     // (this instantiation reads its tables through these two arguments)
@@ -1703,7 +1715,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             (void)hipGetLastError();
             d->team_max = 1;
             threads = tile_threads; grid = tile_grid;
-            d->last_kernel = 1; d->last_team = 1; d->last_grid = grid; d->last_threads = threads;
+            d->last_kernel = 1; d->last_team = 1; d->last_lds_rows = 0; d->last_grid = grid; d->last_threads = threads;
             if ((st = ensure_workspace(d, (size_t)grid * slot_stride_bytes, grid, slot_stride_bytes, stream)) != LDPC_OK) return st;
             p.msg = (double *)d->msg.p;
             kfn = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, threads);
@@ -1719,13 +1731,23 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             for (unsigned v : xm) single += __builtin_popcount(v) == 1;
             std::fprintf(stderr, "[ldpc] team kernel: %d tiles, %d teams x %d workgroups, grid %d; %d teams on one XCD (first masks %x %x %x)\n",
                          ntiles, plan.nteams, team, team_grid, single, xm[0], nt > 1 ? xm[1] : 0u, nt > 2 ? xm[2] : 0u);
-            // per member: its own check / variable sweep time (100 MHz ticks, whole call) and HW_ID (CU in bits 8-11, SH 12, SE 13-15)
-            for (int t = 0; t < std::min(nt, 2); ++t) {
+            // per team: its members' own check / variable sweep times (100 MHz ticks over the whole call: mean, fastest,
+            // slowest, and where the slowest ran: XCC_ID is not stored, HW_ID gives CU (bits 8-11), SH (12), SE (13-15))
+            for (int t = 0; t < nt; ++t) {
                 std::vector<unsigned> ml((size_t)team * 32);
                 (void)hipMemcpy(ml.data(), tp.ctl + (size_t)t * kTeamCtlWords + kTeamCtlMember, ml.size() * sizeof(unsigned), hipMemcpyDeviceToHost);
-                for (int m = 0; m < team; ++m)
-                    std::fprintf(stderr, "[ldpc]   team %d member %2d: check %8u var %8u  cu %2u sh %u se %u\n", t, m, ml[(size_t)m * 32 + 1], ml[(size_t)m * 32 + 2],
-                                 (ml[(size_t)m * 32 + 3] >> 8) & 15u, (ml[(size_t)m * 32 + 3] >> 12) & 1u, (ml[(size_t)m * 32 + 3] >> 13) & 7u);
+                double sc = 0, sv = 0; unsigned cmin = ~0u, cmax = 0, vmin = ~0u, vmax = 0; int cm = 0, vm = 0;
+                for (int m = 0; m < team; ++m) {
+                    const unsigned c = ml[(size_t)m * 32 + 1], v = ml[(size_t)m * 32 + 2];
+                    sc += c; sv += v;
+                    if (c < cmin) cmin = c;
+                    if (c > cmax) { cmax = c; cm = m; }
+                    if (v < vmin) vmin = v;
+                    if (v > vmax) { vmax = v; vm = m; }
+                }
+                const unsigned hc = ml[(size_t)cm * 32 + 3], hv = ml[(size_t)vm * 32 + 3];
+                std::fprintf(stderr, "[ldpc]   team %d (xcc mask %x): check mean %.0f min %u max %u (member %d cu %u se %u)  var mean %.0f min %u max %u (member %d cu %u se %u)\n",
+                             t, xm[(size_t)t], sc / team, cmin, cmax, cm, (hc >> 8) & 15u, (hc >> 13) & 7u, sv / team, vmin, vmax, vm, (hv >> 8) & 15u, (hv >> 13) & 7u);
             }
         }
     }

@@ -54,14 +54,24 @@ mutable struct MI355XBeliefPropagationDecoder <: AbstractDecoder
     sparse_H::SparseMatrixCSC{Bool,Int}
     sparse_HT::SparseMatrixCSC{Bool,Int}
     scratch::MI355XScratch
-    handle::Ptr{Cvoid}
+    handle::Ptr{Cvoid}       # ldpc_bp_decoder* (with `devices`: the root's, owned by `multi`)
+    multi::Ptr{Cvoid}        # ldpc_bp_multi* when the decoder partitions its batches over several GPUs, else C_NULL
     # reusable staging (column-major Julia matrices already have the ABI's [B][s] image)
     syn_u8::Vector{UInt8}
     err_u8::Vector{UInt8}
     conv_u8::Vector{UInt8}
 end
 
-function MI355XBeliefPropagationDecoder(H, per::Float64, max_iters::Int; device::Integer=-1)
+"""
+    MI355XBeliefPropagationDecoder(H, per, max_iters; device=-1, devices=nothing, exchange=0)
+
+`devices = 0:7` makes `batchdecode!` one call that partitions the columns of its `syndromes` matrix over those GPUs
+(`ldpc_bp_create_multi`: contiguous shards, one handle and stream per GPU; the host arrays go pinned host -> each
+shard's own GPU and back).  `exchange` only matters for device-resident batches (`ldpc_bp_decode_batch_multi_device`:
+0 auto = RCCL send/recv from `devices[1]`, 1 hipMemcpyPeer, 2 RCCL).
+"""
+function MI355XBeliefPropagationDecoder(H, per::Float64, max_iters::Int; device::Integer=-1,
+                                        devices::Union{Nothing,AbstractVector{<:Integer}}=nothing, exchange::Integer=0)
     s, n = size(H)
     sparse_H = SparseMatrixCSC{Bool,Int}(sparse(H))          # :63
     sparse_HT = SparseMatrixCSC{Bool,Int}(sparse(H'))        # :64
@@ -69,17 +79,41 @@ function MI355XBeliefPropagationDecoder(H, per::Float64, max_iters::Int; device:
     rowval = Int64.(rowvals(sparse_H) .- 1)
     opts = zeros(Int32, 16); opts[1] = Int32(device)
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:ldpc_bp_create, libldpc), Cint,
-                (Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Float64, Int64, Ptr{Int32}, Ptr{Ptr{Cvoid}}),
-                s, n, length(rowval), colptr, rowval, per, max_iters, opts, h))
+    m = C_NULL
+    if devices === nothing
+        check(ccall((:ldpc_bp_create, libldpc), Cint,
+                    (Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Float64, Int64, Ptr{Int32}, Ptr{Ptr{Cvoid}}),
+                    s, n, length(rowval), colptr, rowval, per, max_iters, opts, h))
+    else
+        devs = Int32.(collect(devices))
+        mr = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:ldpc_bp_create_multi, libldpc), Cint,
+                    (Int32, Ptr{Int32}, Int32, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Float64, Int64, Ptr{Int32}, Ptr{Ptr{Cvoid}}),
+                    length(devs), devs, exchange, s, n, length(rowval), colptr, rowval, per, max_iters, opts, mr))
+        m = mr[]
+        h[] = ccall((:ldpc_bp_multi_handle, libldpc), Ptr{Cvoid}, (Ptr{Cvoid}, Int32), m, 0)
+    end
     d = MI355XBeliefPropagationDecoder(per, max_iters, s, n, sparse_H, sparse_HT,
-            MI355XScratch(zeros(n), fill(per, n), zeros(n)), h[], UInt8[], UInt8[], UInt8[])
+            MI355XScratch(zeros(n), fill(per, n), zeros(n)), h[], m, UInt8[], UInt8[], UInt8[])
     finalizer(d) do x
-        x.handle != C_NULL && ccall((:ldpc_bp_destroy, libldpc), Cint, (Ptr{Cvoid},), x.handle)
-        x.handle = C_NULL
+        if x.multi != C_NULL
+            ccall((:ldpc_bp_destroy_multi, libldpc), Cint, (Ptr{Cvoid},), x.multi)   # (owns every per-GPU handle)
+        elseif x.handle != C_NULL
+            ccall((:ldpc_bp_destroy, libldpc), Cint, (Ptr{Cvoid},), x.handle)
+        end
+        x.handle = C_NULL; x.multi = C_NULL
     end
     return d
 end
+
+# the host-buffer entry: one GPU, or the batch partitioned over `devices` (same argument list, belief_propagation.jl:220-231)
+host_decode(d::MI355XBeliefPropagationDecoder, B, llr) = d.multi != C_NULL ?
+    ccall((:ldpc_bp_decode_batch_multi, libldpc), Cint,
+          (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{UInt8}, Ptr{UInt8}, Ptr{Float64}, Ptr{Int32}),
+          d.multi, B, d.syn_u8, d.err_u8, d.conv_u8, llr, C_NULL) :
+    ccall((:ldpc_bp_decode_batch, libldpc), Cint,
+          (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{UInt8}, Ptr{UInt8}, Ptr{Float64}, Ptr{Int32}),
+          d.handle, B, d.syn_u8, d.err_u8, d.conv_u8, llr, C_NULL)
 
 """
     last_status(d)
@@ -88,7 +122,8 @@ Waits for everything enqueued on the handle and throws if a team of workgroups l
 those calls (`ldpc_bp_last_status`, include/ldpc_mi355x.h).  Only callers of the asynchronous device entry
 need it; `decode!` / `batchdecode!` above use the synchronous host entry, which repairs such a call itself.
 """
-last_status(d::MI355XBeliefPropagationDecoder) =
+last_status(d::MI355XBeliefPropagationDecoder) = d.multi != C_NULL ?
+    check(ccall((:ldpc_bp_multi_last_status, libldpc), Cint, (Ptr{Cvoid},), d.multi)) :
     check(ccall((:ldpc_bp_last_status, libldpc), Cint, (Ptr{Cvoid},), d.handle))
 
 "`(-1)^x` only needs the parity; anything but 0/1 must never match the convergence `==` (:136,:181)."
@@ -111,9 +146,7 @@ function decode!(d::MI355XBeliefPropagationDecoder, syndrome::AbstractVector)   
     @inbounds for i in 1:d.s
         d.syn_u8[i] = syndrome_byte(syndrome[i])
     end
-    check(ccall((:ldpc_bp_decode_batch, libldpc), Cint,
-                (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{UInt8}, Ptr{UInt8}, Ptr{Float64}, Ptr{Int32}),
-                d.handle, 1, d.syn_u8, d.err_u8, d.conv_u8, d.scratch.log_probabs, C_NULL))
+    check(host_decode(d, 1, d.scratch.log_probabs))
     @inbounds for j in 1:d.n
         d.scratch.err[j] = d.err_u8[j]
     end
@@ -134,9 +167,7 @@ function batchdecode!(d::MI355XBeliefPropagationDecoder, syndromes::AbstractMatr
     @inbounds for i in 1:B, r in 1:d.s
         d.syn_u8[(i - 1) * d.s + r] = syndrome_byte(syndromes[r, i])
     end
-    check(ccall((:ldpc_bp_decode_batch, libldpc), Cint,
-                (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{UInt8}, Ptr{UInt8}, Ptr{Float64}, Ptr{Int32}),
-                d.handle, B, d.syn_u8, d.err_u8, d.conv_u8, C_NULL, C_NULL))
+    check(host_decode(d, B, Ptr{Float64}(C_NULL)))            # one call, one matrix -- on one GPU or partitioned over `devices`
     @inbounds for i in 1:B
         success[i] = d.conv_u8[i] != 0                        # :226
         for j in 1:d.n
@@ -202,9 +233,7 @@ function batchdecode!(d::MI355XBeliefPropagationOSDDecoder, syndromes::AbstractM
         bp.syn_u8[(i - 1) * bp.s + r] = syndrome_byte(syndromes[r, i])
     end
     llr = Vector{Float64}(undef, bp.n * B)
-    check(ccall((:ldpc_bp_decode_batch, libldpc), Cint,
-                (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{UInt8}, Ptr{UInt8}, Ptr{Float64}, Ptr{Int32}),
-                bp.handle, B, bp.syn_u8, bp.err_u8, bp.conv_u8, llr, C_NULL))
+    check(host_decode(bp, B, llr))
     out = Vector{UInt8}(undef, bp.n * B)
     check(ccall((:ldpc_osd_postprocess_batch, libldpc), Cint,
                 (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{UInt8}, Ptr{Float64}, Ptr{UInt8}, Int32),

@@ -13,8 +13,15 @@
 # and nothing else.  Because the TYPE is untouched, everything that holds one keeps working without an edit:
 # `BeliefPropagationOSDDecoder` (its field is concretely typed, belief_propagation_osd.jl:19, and it reads
 # `bp_decoder.scratch.log_probabs`, :52 -- filled here), the generic 3-argument `batchdecode!`
-# (abstract_decoder.jl:44-48), QuantumClifford's extension.  `reset!` stays the reference's (:83-91): it clears the
-# host scratch, which decode! below refills; the device state is reset inside every call.
+# (abstract_decoder.jl:44-48), QuantumClifford's extension.  `reset!` stays the reference's (:83-91) for whoever calls
+# it, but the methods below do NOT: it fills the two dense s x n Float64 matrices of the scratch (2 GiB at n = 16384),
+# which nobody reads here -- the messages live in HBM, and the device state is reset inside every call; the library
+# overwrites `scratch.log_probabs` and this file `scratch.err` completely on every decode!.  What stays of the
+# reference's cost is its CONSTRUCTOR, which still allocates those 2 * s * n * 8 bytes on the host once
+# (belief_propagation.jl:20-22); LDPCDecodersMI355X.jl next to this file has types of its own and avoids that too.
+#
+#     LDPCDecodersMI355XDropIn.set_devices!(0:7)      # optional: batchdecode! partitions its columns over these GPUs
+#                                                     # (ldpc_bp_create_multi; decoders created afterwards)
 #
 # NOT EXECUTED in this repository's pipeline (no Julia runtime in the image); LDPCDecodersMI355X.jl next to it is the
 # conservative alternative with types of its own.  Overwriting another module's methods is deliberate here; Julia
@@ -35,34 +42,61 @@ function check(status::Cint)
 end
 
 mutable struct Handle
-    ptr::Ptr{Cvoid}
+    ptr::Ptr{Cvoid}          # ldpc_bp_decoder* (one GPU) or ldpc_bp_multi* (several)
+    multi::Bool
     syn_u8::Vector{UInt8}
     err_u8::Vector{UInt8}
     conv_u8::Vector{UInt8}
 end
 
-# one library handle per reference decoder object, created at its first decode and destroyed with it
-const HANDLES = WeakKeyDict{BeliefPropagationDecoder,Handle}()
+# GPUs that decoders created from now on partition their batches over (empty: the current device)
+const DEVICES = Int32[]
+set_devices!(devs) = (empty!(DEVICES); append!(DEVICES, Int32.(collect(devs))); DEVICES)
+
+# One library handle per reference decoder object, created at its first decode.  The reference's decoder is an
+# IMMUTABLE struct (belief_propagation.jl:38): it has no identity of its own and cannot carry a finalizer (a
+# WeakKeyDict keyed on it throws on first use), so the table is keyed on a mutable object every decoder owns exactly
+# one of -- its `scratch.log_probabs` vector -- and the handle lives as long as that vector does.
+const HANDLES = WeakKeyDict{Vector{Float64},Handle}()
 const HANDLES_LOCK = ReentrantLock()
 
 function handle_of(d::BeliefPropagationDecoder)
     lock(HANDLES_LOCK) do
-        get!(HANDLES, d) do
+        get!(HANDLES, d.scratch.log_probabs) do
             colptr = Int64.(d.sparse_H.colptr .- 1)          # zero-based CSC pattern of sparse(H) (:63)
             rowval = Int64.(rowvals(d.sparse_H) .- 1)
             h = Ref{Ptr{Cvoid}}(C_NULL)
-            check(ccall((:ldpc_bp_create, libldpc), Cint,
-                        (Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Float64, Int64, Ptr{Int32}, Ptr{Ptr{Cvoid}}),
-                        d.s, d.n, length(rowval), colptr, rowval, d.per, d.max_iters, C_NULL, h))
-            hd = Handle(h[], UInt8[], UInt8[], UInt8[])
+            multi = !isempty(DEVICES)
+            if multi
+                check(ccall((:ldpc_bp_create_multi, libldpc), Cint,
+                            (Int32, Ptr{Int32}, Int32, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Float64, Int64, Ptr{Int32}, Ptr{Ptr{Cvoid}}),
+                            length(DEVICES), DEVICES, 0, d.s, d.n, length(rowval), colptr, rowval, d.per, d.max_iters, C_NULL, h))
+            else
+                check(ccall((:ldpc_bp_create, libldpc), Cint,
+                            (Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Float64, Int64, Ptr{Int32}, Ptr{Ptr{Cvoid}}),
+                            d.s, d.n, length(rowval), colptr, rowval, d.per, d.max_iters, C_NULL, h))
+            end
+            hd = Handle(h[], multi, UInt8[], UInt8[], UInt8[])
             finalizer(hd) do x
-                x.ptr != C_NULL && ccall((:ldpc_bp_destroy, libldpc), Cint, (Ptr{Cvoid},), x.ptr)
+                if x.ptr != C_NULL
+                    x.multi ? ccall((:ldpc_bp_destroy_multi, libldpc), Cint, (Ptr{Cvoid},), x.ptr) :
+                              ccall((:ldpc_bp_destroy, libldpc), Cint, (Ptr{Cvoid},), x.ptr)
+                end
                 x.ptr = C_NULL
             end
             hd
         end
     end
 end
+
+# the host-buffer entry of a handle: one GPU or the batch partitioned over several (same argument list)
+decode_batch(h::Handle, B, llr) = h.multi ?
+    ccall((:ldpc_bp_decode_batch_multi, libldpc), Cint,
+          (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{UInt8}, Ptr{UInt8}, Ptr{Float64}, Ptr{Int32}),
+          h.ptr, B, h.syn_u8, h.err_u8, h.conv_u8, llr, C_NULL) :
+    ccall((:ldpc_bp_decode_batch, libldpc), Cint,
+          (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{UInt8}, Ptr{UInt8}, Ptr{Float64}, Ptr{Int32}),
+          h.ptr, B, h.syn_u8, h.err_u8, h.conv_u8, llr, C_NULL)
 
 @inline function syndrome_byte(x)::UInt8                      # (-1)^x needs the parity only (:136); 0/1 alone can match (:181)
     v = Int(x)
@@ -71,15 +105,14 @@ end
 
 function LDPCDecoders.decode!(d::BeliefPropagationDecoder, syndrome::AbstractVector)       # overwrites :121-188
     length(syndrome) == d.s || throw(BoundsError(syndrome, d.s))
-    LDPCDecoders.reset!(d)                                                                 # :122
+    # (:122 calls reset! here; its dense fills are not needed -- see the header -- and both result vectors are
+    # overwritten completely below)
     h = handle_of(d)
     resize!(h.syn_u8, d.s); resize!(h.err_u8, d.n); resize!(h.conv_u8, 1)
     @inbounds for i in 1:d.s
         h.syn_u8[i] = syndrome_byte(syndrome[i])
     end
-    check(ccall((:ldpc_bp_decode_batch, libldpc), Cint,
-                (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{UInt8}, Ptr{UInt8}, Ptr{Float64}, Ptr{Int32}),
-                h.ptr, 1, h.syn_u8, h.err_u8, h.conv_u8, d.scratch.log_probabs, C_NULL))
+    check(decode_batch(h, 1, d.scratch.log_probabs))
     @inbounds for j in 1:d.n
         d.scratch.err[j] = h.err_u8[j]
     end
@@ -97,18 +130,19 @@ function LDPCDecoders.batchdecode!(d::BeliefPropagationDecoder, syndromes::Abstr
     @inbounds for i in 1:B, r in 1:d.s
         h.syn_u8[(i - 1) * d.s + r] = syndrome_byte(syndromes[r, i])
     end
-    check(ccall((:ldpc_bp_decode_batch, libldpc), Cint,
-                (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{UInt8}, Ptr{UInt8}, Ptr{Float64}, Ptr{Int32}),
-                h.ptr, B, h.syn_u8, h.err_u8, h.conv_u8, C_NULL, C_NULL))
+    check(decode_batch(h, B, Ptr{Float64}(C_NULL)))
     @inbounds for i in 1:B
         success[i] = h.conv_u8[i] != 0                                                     # :226
         for j in 1:d.n
             errors[j, i] = h.err_u8[(i - 1) * d.n + j]                                     # :227
         end
     end
-    # the reference leaves the scratch holding the last column's state; callers that read it after a batch
-    # (none in the reference) get it from one more single decode of that column
-    LDPCDecoders.decode!(d, view(syndromes, :, B))
+    # the reference leaves the scratch holding the last column's state: `scratch.err` gets that column's decision
+    # here; `scratch.log_probabs` is NOT refreshed by a batch call (nothing in the reference reads it after one, and
+    # shipping 8 n bytes per column back for it would double the call's I/O) -- decode!(d, syndromes[:, end]) gives it
+    @inbounds for j in 1:d.n
+        d.scratch.err[j] = h.err_u8[(B - 1) * d.n + j]
+    end
     return errors, success                                                                 # :230
 end
 

@@ -15,7 +15,9 @@
 # (iteration counts are not observable in the reference and are not compared).
 # Exit status 0 = every case agrees: the oracle -- today "parity unpinned" -- is then pinned by the reference
 # itself.  Set LDPC_REPLAY_IMPL=mi355x to replay through the ccall shim (ldpcdecoders.jl_amd/julia) instead,
-# i.e. through libldpc_mi355x.so on a machine with an MI355X.
+# i.e. through libldpc_mi355x.so on a machine with an MI355X; LDPC_REPLAY_IMPL=dropin replays through the SAME-NAME
+# drop-in (LDPCDecodersMI355XDropIn.jl: the reference's own decoder type with decode! / batchdecode! overwritten) --
+# both equally unexecuted here.
 using SparseArrays
 using TOML
 import LDPCDecoders
@@ -23,6 +25,10 @@ import LDPCDecoders
 const IMPL = get(ENV, "LDPC_REPLAY_IMPL", "reference")
 if IMPL == "mi355x"
     include(joinpath(@__DIR__, "..", "..", "ldpcdecoders.jl_amd", "julia", "LDPCDecodersMI355X.jl"))
+elseif IMPL == "dropin"
+    # from here on LDPCDecoders.decode!(::BeliefPropagationDecoder, ...) runs on the GPU: make_decoder below keeps
+    # building the reference's own type
+    include(joinpath(@__DIR__, "..", "..", "ldpcdecoders.jl_amd", "julia", "LDPCDecodersMI355XDropIn.jl"))
 end
 
 const ELTYPES = Dict("UInt8" => UInt8, "Int32" => Int32, "Int64" => Int64, "Float64" => Float64)

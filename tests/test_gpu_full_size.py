@@ -123,3 +123,69 @@ def test_c3_code_team_kernel_is_bit_identical_to_the_tile_kernel(ldpc, gpu, Bp):
         dec.close()
     for v in (4, 0):
         assert all(torch.equal(a, b) for a, b in zip(res[1], res[v]))
+
+
+def _syndromes_on_device(H, wr, batch, per, seed):
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    csr = H.tocsr()
+    csr.sort_indices()
+    n = H.shape[1]
+    cols = torch.from_numpy(csr.indices.astype(np.int64)).to(dev)
+    syn = torch.empty((batch, csr.shape[0]), dtype=torch.uint8, device=dev)
+    for b0 in range(0, batch, 4096):
+        e = (torch.rand((4096, n), generator=g, device=dev) < per).to(torch.uint8)
+        syn[b0:b0 + 4096] = e[:, cols].view(4096, csr.shape[0], wr).sum(dim=2, dtype=torch.int32).remainder(2).to(torch.uint8)
+    return syn, cols
+
+
+@pytest.mark.parametrize("n,wr,wc,batch,per", [(16380, 6, 3, 65536, 0.10), (16380, 6, 3, 65536, 0.055),
+                                              (16000, 10, 5, 32768, 0.10), (16000, 10, 5, 32768, 0.05)])
+def test_other_regular_codes_keep_rows_in_lds_full_batch(ldpc, gpu, n, wr, wc, batch, per):
+    """Rows in LDS beyond the (4,8) code: a (3,6)-regular code of the C3 size and bench.py's wide_16000_10_5
+    ((5,10)-regular, the 16-wide register bucket) at full batch through the default path -- persistent teams whose
+    members keep the message rows only they touch in LDS (instantiations <6,3> and <10,5>).  Whole-batch properties,
+    bit-equality with the tile kernel (no teams, no hand-off), and the oracle on 1,024 syndromes; per above the
+    threshold (every syndrome runs all 50 iterations) and below it (early exit, stragglers through the levels)."""
+    H = ldpc.codes.parity_check_csc(n, wr, wc)
+    syn, cols = _syndromes_on_device(H, wr, batch, per, seed=n + int(per * 1000))
+    dec = ldpc.BeliefPropagationDecoder(H, per, ITERS)
+    err = torch.empty((batch, n), dtype=torch.uint8, device=syn.device)
+    conv = torch.empty(batch, dtype=torch.uint8, device=syn.device)
+    its = torch.empty(batch, dtype=torch.int32, device=syn.device)
+    dec.decode_batch_device(syn, err, conv, None, its)
+    dec.last_status()
+    info = dec.info()
+    assert info.last_kernel == 4 and info.last_team_size >= 16 and info.last_lds_rows >= 200, (info.last_kernel, info.last_team_size, info.last_lds_rows)
+    dec.close()
+    conv_b = conv.bool()
+    for b0 in range(0, batch, 4096):
+        s2 = err[b0:b0 + 4096][:, cols].view(4096, H.shape[0], wr).sum(dim=2, dtype=torch.int32).remainder(2).to(torch.uint8)
+        ok = (s2 == syn[b0:b0 + 4096]).all(dim=1)
+        assert bool((ok == conv_b[b0:b0 + 4096]).all()), "converged flag must equal 'syndrome reproduced'"
+    assert bool((its[~conv_b] == ITERS).all()) and bool((its >= 1).all()) and bool((its <= ITERS).all())
+    if per >= 0.10:
+        assert conv_b.float().mean().item() < 0.01      # above threshold: (nearly) everything runs all 50 iterations
+    else:
+        assert conv_b.float().mean().item() > 0.9
+    tile = ldpc.BeliefPropagationDecoder(H, per, ITERS, kernel_variant=1, defer_threshold=-1)
+    e2 = torch.empty_like(err); c2 = torch.empty_like(conv); i2 = torch.empty_like(its)
+    tile.decode_batch_device(syn, e2, c2, None, i2)
+    tile.last_status()
+    assert tile.info().last_kernel == 1
+    tile.close()
+    assert torch.equal(e2, err) and torch.equal(c2, conv) and torch.equal(i2, its)
+    del e2, c2, i2
+    idx = np.sort(np.random.default_rng(n).choice(batch, 1024, replace=False))
+    tidx = torch.from_numpy(idx).to(syn.device)
+
+    def work(chunk):
+        oc = BPOracle(csc=(H.indptr, H.indices), shape=H.shape, per=per, max_iters=ITERS)
+        return oc.batchdecode(chunk, want_llr=False)
+
+    with cf.ThreadPoolExecutor(12) as ex:
+        res = list(ex.map(work, np.array_split(syn[tidx].cpu().numpy(), 12)))
+    oerr, oconv, oits = (np.concatenate([r[k] for r in res]) for k in (0, 1, 3))
+    assert np.array_equal(conv[tidx].cpu().numpy(), oconv) and np.array_equal(its[tidx].cpu().numpy(), oits)
+    assert np.array_equal(err[tidx].cpu().numpy(), oerr)

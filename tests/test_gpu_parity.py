@@ -266,6 +266,32 @@ def test_team_rows_in_lds_change_nothing(ldpc, gpu, per, monkeypatch):
         assert all(torch.equal(a, b) for a, b in zip(res[0], other))
 
 
+@pytest.mark.parametrize("per,ahead", [(0.04, "1"), (0.04, "32"), (0.065, "1"), (0.065, "20"), (0.10, "64"), (0.10, "0")])
+def test_team_running_ahead_changes_nothing(ldpc, gpu, per, ahead, monkeypatch):
+    """Two team barriers an iteration instead of three: with at least LDPC_TEAM_AHEAD lanes active a team starts the next
+    check sweep while the convergence test is still under way and reads the verdict after that sweep's barrier
+    (bp_team_kernels.hpp, TeamParams::ahead_min; the decision words are double-buffered for it).  1 = always (every tile
+    that was quiet so far may end with a sweep that was for nothing or hand off an iteration late), 64 = only full tiles, 0 = never: the
+    oracle's bits every time -- hard decisions, flags, iteration counts, LLRs -- on a code with rows in LDS (persistent
+    teams on a small graph through the cache budget) at error rates where tiles finish early, hand stragglers on, or
+    run all iterations."""
+    n, B = 4096, 2500
+    H = ldpc.codes.parity_check_csc(n, 8, 4)
+    syn = ldpc.codes.syndromes_of(H, ldpc.codes.random_errors(n, B, per, seed=55))
+    oc = BPOracle(csc=(H.indptr, H.indices), shape=H.shape, per=per, max_iters=25)
+    oerr, oconv, ollr, oits = oc.batchdecode(syn)
+    monkeypatch.setenv("LDPC_TEAM_AHEAD", ahead)
+    monkeypatch.setenv("LDPC_TEAM_CACHE_KIB", "40000")     # 8 MiB a slot: four persistent teams for the 40 tiles
+    monkeypatch.setenv("LDPC_TEAM_MIN_ROWS", "512")
+    dec = ldpc.BeliefPropagationDecoder(H, per, 25, kernel_variant=4)
+    err, conv, llr, its = dec.decode_batch_host(syn, want_llr=True, want_iters=True)
+    assert dec.info().last_kernel == 4
+    dec.close()
+    assert np.array_equal(err, oerr) and np.array_equal(conv, oconv) and np.array_equal(its, oits)
+    fin = np.isfinite(ollr)
+    assert np.array_equal(llr[~fin], ollr[~fin]) and np.max(np.abs(llr[fin] - ollr[fin])) <= 1e-5
+
+
 def test_auto_dispatch_picks_the_kernel_by_code_and_batch(ldpc, gpu, monkeypatch):
     """kernel_variant 0: LDS-resident kernel for a code that fits the LDS; node-parallel kernel with the messages
     in LDS at every batch size for a code whose messages alone fit it (n = 4096); beyond that the node-parallel
@@ -385,6 +411,49 @@ def test_lost_team_is_reported_or_repaired_never_silent(ldpc, gpu, monkeypatch):
         dec.last_status()                                                    # (synchronises the handle itself)
     dec.last_status()                                                        # reported exactly once
     dec.decode_batch_device(d_syn, d_err, d_conv)
+    dec.last_status()
+    assert np.array_equal(d_err.cpu().numpy(), oerr) and np.array_equal(d_conv.cpu().numpy(), oconv)
+    dec.close()
+    monkeypatch.delenv("LDPC_TEAM_INJECT_FAULT")
+
+
+def test_team_that_is_incomplete_at_launch_costs_milliseconds_not_seconds(ldpc, gpu, monkeypatch):
+    """Launch-time roll call (bp_team_kernels.hpp team_rollcall): a member that never gets its CU -- injected: the last
+    member of team 0 stays away -- makes the team give up within the roll call's bound (20 ms), before anything has
+    been read or written; the synchronous host entry then decodes the batch with the tile kernel at once, where a
+    timed-out team barrier would have cost 10 s.  The asynchronous entry reports it like any other team fault."""
+    import time
+
+    import torch
+
+    n = 16384
+    H = ldpc.codes.parity_check_csc(n, 8, 4)
+    syn = ldpc.codes.syndromes_of(H, ldpc.codes.random_errors(n, 640, 0.04, seed=19))
+    oc = BPOracle(csc=(H.indptr, H.indices), shape=H.shape, per=0.04, max_iters=12)
+    oerr, oconv, _, oits = oc.batchdecode(syn, want_llr=False)
+    monkeypatch.setenv("LDPC_TEAM_INJECT_FAULT", "2")
+    dec = ldpc.BeliefPropagationDecoder(H, 0.04, 12, kernel_variant=4)
+    dec.decode_batch_host(syn[:64])                                          # (first call: allocations, module load)
+    dec.close()
+    dec = ldpc.BeliefPropagationDecoder(H, 0.04, 12, kernel_variant=4)
+    t0 = time.perf_counter()
+    err, conv, _, its = dec.decode_batch_host(syn, want_iters=True)          # team grid, roll call fails, tile kernel
+    dt = time.perf_counter() - t0
+    assert np.array_equal(err, oerr) and np.array_equal(conv, oconv) and np.array_equal(its, oits)
+    assert dec.info().last_kernel == 1                                       # teams are off for this decoder now
+    assert dt < 3.0, f"the fallback took {dt:.2f} s: the roll call did not bound the wait"
+    dec.close()
+    dec = ldpc.BeliefPropagationDecoder(H, 0.04, 12, kernel_variant=4)
+    d_syn = torch.from_numpy(syn).cuda()
+    d_err = torch.full((640, n), 7, dtype=torch.uint8, device="cuda")
+    d_conv = torch.full((640,), 7, dtype=torch.uint8, device="cuda")
+    dec.decode_batch_device(d_syn, d_err, d_conv)
+    t0 = time.perf_counter()
+    with pytest.raises(ldpc.LdpcError, match=r"call #1 on this decoder found a team of workgroups incomplete at launch"):
+        dec.last_status()
+    assert time.perf_counter() - t0 < 3.0
+    assert bool((d_conv[:64] == 7).all())          # the incomplete team (it starts on tile 0) wrote nothing at all
+    dec.decode_batch_device(d_syn, d_err, d_conv)                            # teams are off: the tile kernel
     dec.last_status()
     assert np.array_equal(d_err.cpu().numpy(), oerr) and np.array_equal(d_conv.cpu().numpy(), oconv)
     dec.close()

@@ -9,7 +9,7 @@ import torch
 import ldpcdecoders_jl_amd as ldpc
 
 n, per = int(os.environ.get("N", "16384")), 0.10
-H = ldpc.codes.parity_check_csc(n, 8, 4)
+H = ldpc.codes.parity_check_csc(n, int(os.environ.get("WR", "8")), int(os.environ.get("WC", "4")))
 variant = int(os.environ.get("VARIANT", "4"))
 dec = ldpc.BeliefPropagationDecoder(H, per, 50, kernel_variant=variant)
 for batch in [int(x) for x in os.environ.get("BATCHES", "64,256,384,512,768,1024,2048").split(",")]:
@@ -31,7 +31,7 @@ for batch in [int(x) for x in os.environ.get("BATCHES", "64,256,384,512,768,1024
     ck, vr, rs = dec.phase_ticks()
     nt = (batch + 63) // 64
     inf = dec.info()
-    ph = f"per team and iteration: check {ck / nt / iters / 100:6.1f} us  var {vr / nt / iters / 100:6.1f} us  barriers+test {rs / nt / iters / 100:6.1f} us  (k{inf.last_kernel} G{inf.last_team_size})"
+    ph = f"per team and iteration: check {ck / nt / iters / 100:6.1f} us  var {vr / nt / iters / 100:6.1f} us  barriers+test {rs / nt / iters / 100:6.1f} us  (k{inf.last_kernel} G{inf.last_team_size} slots {inf.resident_tiles // max(inf.last_team_size, 1)} lds_rows {inf.last_lds_rows})"
     if os.environ.get("DIAG3"):   # library built with -DLDPC_TEAM_DIAG=3: max / min over the members' own sweep times
         ph = f"slowest member: check {ck / iters / 100:6.1f} us  var {vr / iters / 100:6.1f} us per iteration; fastest member's check {((1 << 64) - 1 - rs) / iters / 100:6.1f} us  (k{inf.last_kernel} G{inf.last_team_size})"
     print(f"batch {batch:5d} ({(batch + 63) // 64:3d} tiles): wall {ms:8.3f} ms  kernel {kernel_ms:8.3f} ms  mean iterations {iters:5.1f}  {tb:5.2f} TB/s algorithmic  {ph}", flush=True)
