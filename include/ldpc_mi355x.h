@@ -290,8 +290,9 @@ ldpc_status ldpc_osd_postprocess_batch(const ldpc_osd *osd, int64_t batch, const
  * BP-OTS decoder: LLR-domain tanh/atanh BP with oscillation-driven prior biasing.
  * Graphs whose messages fit one CU's LDS (every code of the reference's BP-OTS tests) take an LDS-resident
  * kernel; larger ones a node-parallel kernel with the messages in global memory, as long as s + 3n bytes of
- * decisions and 4s bytes of parities fit the LDS (n up to ~30,000 at rate 1/2).  Check degree <= 32, bit
- * degree <= 16.  Anything beyond returns LDPC_ERR_UNSUPPORTED (the reference's BPOTSDecoder has no such limit).
+ * decisions and 4s bytes of parities fit the LDS (n up to ~30,000 at rate 1/2) and no check has more than 32 or bit
+ * more than 16 edges; anything beyond that a third kernel that keeps everything of a syndrome in global memory and
+ * takes nodes of any degree -- like the reference's BPOTSDecoder, which takes any H.
  * ------------------------------------------------------------------------ */
 typedef struct ldpc_bpots_decoder ldpc_bpots_decoder;
 
@@ -302,7 +303,8 @@ ldpc_status ldpc_bpots_create(int64_t s, int64_t n, int64_t nnz, const int64_t *
                               int32_t device, ldpc_bpots_decoder **out);
 ldpc_status ldpc_bpots_destroy(ldpc_bpots_decoder *dec);
 /* Which kernel this decoder's graph takes (numbered like ldpc_bp_options.kernel_variant): 2 = LDS-resident (S syndromes
- * per workgroup), 3 = node-parallel with the messages in a global slot (graphs beyond one CU's LDS); 0 for NULL. */
+ * per workgroup), 3 = node-parallel with the messages in a global slot (graphs beyond one CU's LDS), 5 = the same with
+ * everything of a syndrome in the global slot and nodes of any degree (no size or degree limit); 0 for NULL. */
 int32_t ldpc_bpots_kernel(const ldpc_bpots_decoder *dec);
 
 /* Replaces `decode!(decoder::BPOTSDecoder, syndrome)` (:225-340, with its `reset!` :142-154) for a

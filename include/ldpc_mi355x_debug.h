@@ -22,17 +22,23 @@ extern "C" {
 ldpc_status ldpc_debug_team_plan(int64_t nnz, int64_t max_iters, int64_t batch, int32_t cache_mib, int32_t rows_dv,
                                  int32_t out[6]);
 
-/* The tables with which the team kernel keeps message rows in LDS, for a REGULAR graph (every check dc edges, every
-   bit dv) whose degree pair has an instantiation -- (6,3), (8,4), (10,5); LDPC_ERR_UNSUPPORTED otherwise -- and teams
-   of `members` workgroups.  Out: degrees = {dc, dv}; *vt_words = words per position record (8 or 16); *lds_rows = R,
-   rows per member (at most 312); vtab [n][vt_words] = per position of the dealt bit order the CSR rows of its dv edges
-   (row = dc * check + place among the check's bits), their LDS rows or -1, the bit (| 1 << 31 when one of its edges is
-   in LDS), padding; ctab [s][2] = per check the mask of its edges in LDS and the LDS row of the first of them;
-   lds_edge [members][R] = the CSR rows each member holds, -1 beyond a member's count (pass room for members * 312).
+/* The tables with which the team kernel keeps message rows ON CHIP -- in the members' LDS and in the registers of
+   their waves -- for a REGULAR graph (every check dc edges, every bit dv) whose degree pair has an instantiation --
+   (6,3), (8,4), (10,5); LDPC_ERR_UNSUPPORTED otherwise -- and teams of `members` workgroups of 8 waves.
+   In: regs_per_wave (0 ... 32) rows a wave may keep in registers; static_quarters (0 ... 4): the share of a member's
+   chunks per sweep that its waves own by right (only edges between such chunks of ONE wave can live in its registers).
+   Out: degrees = {dc, dv}; shape = {words per position record (8 or 16), R = LDS rows per member (at most 312),
+   static check chunks, static position chunks per member, register rows per wave in effect};
+   vtab [n][shape[0]] = per position of the dealt bit order the CSR rows of its dv edges (row = dc * check + place among
+   the check's bits), where each lives (>= 0: that LDS row of the member; -1: the team's slot; <= -2: register row
+   -2 - x of the wave), the bit (| 1 << 31 when one of its edges is not in the slot), padding; ctab [s][4] = per check
+   the mask of its edges in LDS, the LDS row of the first of them, the mask of its edges in registers, the register
+   row of the first of them; lds_edge [members][R] and reg_edge [members][8][regs_per_wave] = the CSR rows held, -1
+   beyond the count (pass room for members * 312 and members * 8 * 32).
    No reference counterpart: the reference keeps every message in one dense matrix (belief_propagation.jl:83-91). */
 ldpc_status ldpc_debug_team_rows(int64_t s, int64_t n, const int64_t *colptr, const int64_t *rowval, int32_t members,
-                                 int32_t *degrees, int32_t *vt_words, int32_t *lds_rows, int32_t *vtab, int32_t *ctab,
-                                 int32_t *lds_edge);
+                                 int32_t regs_per_wave, int32_t static_quarters, int32_t *degrees, int32_t *shape,
+                                 int32_t *vtab, int32_t *ctab, int32_t *lds_edge, int32_t *reg_edge);
 
 #ifdef __cplusplus
 }

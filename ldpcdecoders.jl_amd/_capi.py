@@ -156,7 +156,7 @@ def lib(experiments: bool = False) -> ctypes.CDLL:
     L.ldpc_debug_team_plan.restype = i32
     L.ldpc_debug_team_plan.argtypes = [i64, i64, i64, i32, i32, ctypes.POINTER(i32 * 6)]
     L.ldpc_debug_team_rows.restype = i32
-    L.ldpc_debug_team_rows.argtypes = [i64, i64, vp, vp, i32, ctypes.POINTER(i32 * 2), ctypes.POINTER(i32), ctypes.POINTER(i32), vp, vp, vp]
+    L.ldpc_debug_team_rows.argtypes = [i64, i64, vp, vp, i32, i32, i32, ctypes.POINTER(i32 * 2), ctypes.POINTER(i32 * 5), vp, vp, vp, vp]
     L.ldpc_bp_create_multi.restype = i32
     L.ldpc_bp_create_multi.argtypes = [i32, ctypes.POINTER(i32), i32, i64, i64, i64, vp, vp, f64, i64, ctypes.POINTER(BPOptions), ctypes.POINTER(vp)]
     L.ldpc_bp_destroy_multi.restype = i32

@@ -156,8 +156,13 @@ __device__ __forceinline__ u64 wave_or(u64 v)
 // belief_propagation.jl:136-149.  `M` points at the check's first row + lane.
 // D is the EXACT degree: straight-line code, all D row loads issued back to back.
 // ---------------------------------------------------------------------------
-// the arithmetic of a check once its D factors a[k] = 2/(1+m[k]) - 1 are known: ordered prefix and suffix products
-template <int D>
+// the arithmetic of a check once its D factors a[k] = 2/(1+m[k]) - 1 are known: ordered prefix and suffix products.
+// TF ("t form"): store the product t itself and leave the division (1 - t) / (1 + t) of :147 to whoever loads the
+// row next -- the variable sweep of the SAME kernel and iteration (bp_team_kernels.hpp: the check sweep of the
+// persistent teams is bound by its 16 fp64 divisions per check, the variable sweep has arithmetic to spare).  The
+// same operations on the same operands, so the same bits; what a sweep leaves behind at an iteration boundary (and
+// hands to other kernels) is never in t form.
+template <int D, bool TF = false>
 __device__ __forceinline__ void check_finish_exact(double *M, const double (&a)[D], double sigma)
 {
     double pre[D];
@@ -168,14 +173,14 @@ __device__ __forceinline__ void check_finish_exact(double *M, const double (&a)[
 #pragma unroll
     for (int k = D - 1; k >= 0; --k) {
         const double t = pre[k] * S;                      // :146
-        stm(M + (size_t)k * kTile, (1.0 - t) / (1.0 + t));  // :147
+        stm(M + (size_t)k * kTile, TF ? t : (1.0 - t) / (1.0 + t));  // :147
         S = S * a[k];                                     // :148
     }
 }
 
 // ... the same with the D new messages handed back instead of stored (rows that do not lie k * 64 doubles apart:
 // bp_team_kernels.hpp keeps some in LDS)
-template <int D>
+template <int D, bool TF = false>
 __device__ __forceinline__ void check_compute_exact(const double (&a)[D], double sigma, double (&out)[D])
 {
     double pre[D];
@@ -186,12 +191,12 @@ __device__ __forceinline__ void check_compute_exact(const double (&a)[D], double
 #pragma unroll
     for (int k = D - 1; k >= 0; --k) {
         const double t = pre[k] * S;                      // :146
-        out[k] = (1.0 - t) / (1.0 + t);                   // :147
+        out[k] = TF ? t : (1.0 - t) / (1.0 + t);          // :147
         S = S * a[k];                                     // :148
     }
 }
 
-template <int D, bool FIRST>
+template <int D, bool FIRST, bool TF = false>
 __device__ __forceinline__ void check_update_exact(double *M, double sigma, double r)
 {
     double a[D];
@@ -206,12 +211,12 @@ __device__ __forceinline__ void check_update_exact(double *M, double sigma, doub
 #pragma unroll
         for (int k = 0; k < D; ++k) a[k] = 2.0 / (1.0 + m[k]) - 1.0;   // :140 / :148 (same value both times)
     }
-    check_finish_exact<D>(M, a, sigma);
+    check_finish_exact<D, TF>(M, a, sigma);
 }
 
 // Two checks of degree D at once: all 2 D row loads are issued before anything is computed (twice the bytes in
 // flight per wave; used where there are registers to spare: bp_team_kernels.hpp).  Same arithmetic per check.
-template <int D>
+template <int D, bool TF = false>
 __device__ __forceinline__ void check_update_pair(double *M0, double *M1, double sigma0, double sigma1)
 {
     double m0[D], m1[D];
@@ -222,10 +227,10 @@ __device__ __forceinline__ void check_update_pair(double *M0, double *M1, double
     double a[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) a[k] = 2.0 / (1.0 + m0[k]) - 1.0;
-    check_finish_exact<D>(M0, a, sigma0);
+    check_finish_exact<D, TF>(M0, a, sigma0);
 #pragma unroll
     for (int k = 0; k < D; ++k) a[k] = 2.0 / (1.0 + m1[k]) - 1.0;
-    check_finish_exact<D>(M1, a, sigma1);
+    check_finish_exact<D, TF>(M1, a, sigma1);
 }
 
 // Any degree, O(deg^2) recomputation of the prefix, still in place (position k is
@@ -320,8 +325,8 @@ __device__ __forceinline__ double bit_compute_exact(const double (&c)[D], double
     return F;
 }
 
-// (pos as values already in registers)
-template <int D>
+// (pos as values already in registers; TF: the rows hold the check sweep's products t, see check_finish_exact)
+template <int D, bool TF = false>
 __device__ __forceinline__ double bit_update_exact_v(double *Mt, const int (&pos)[D], double r)
 {
     double c[D];
@@ -330,10 +335,14 @@ __device__ __forceinline__ double bit_update_exact_v(double *Mt, const int (&pos
     for (int k = 0; k < D; ++k) at[k] = (size_t)pos[k] * kTile;
 #pragma unroll
     for (int k = 0; k < D; ++k) c[k] = ldm(Mt + at[k]);
+    if (TF) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) c[k] = (1.0 - c[k]) / (1.0 + c[k]);   // :147
+    }
     return bit_finish_exact<D>(Mt, at, c, r);
 }
 
-template <int D>
+template <int D, bool TF = false>
 __device__ __forceinline__ void bit_update_pair_v(double *Mt, const int (&pos0)[D], const int (&pos1)[D], double r, double &T0, double &T1)
 {
     double c0[D], c1[D];
@@ -344,6 +353,10 @@ __device__ __forceinline__ void bit_update_pair_v(double *Mt, const int (&pos0)[
     for (int k = 0; k < D; ++k) c0[k] = ldm(Mt + at0[k]);
 #pragma unroll
     for (int k = 0; k < D; ++k) c1[k] = ldm(Mt + at1[k]);
+    if (TF) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) { c0[k] = (1.0 - c0[k]) / (1.0 + c0[k]); c1[k] = (1.0 - c1[k]) / (1.0 + c1[k]); }   // :147
+    }
     T0 = bit_finish_exact<D>(Mt, at0, c0, r);
     T1 = bit_finish_exact<D>(Mt, at1, c1, r);
 }

@@ -44,6 +44,9 @@
 #ifndef LDPC_TEAM_ROWS_WIDE   // 1 = the rows-in-LDS instantiation may use 256 VGPRs (it runs one workgroup per CU)
 #define LDPC_TEAM_ROWS_WIDE 1
 #endif
+#ifndef LDPC_TEAM_TFORM   // 1 = the rows-on-chip instantiations make the division of :147 in the variable sweep (0: experiments)
+#define LDPC_TEAM_TFORM 0
+#endif
 #ifndef LDPC_TEAM_SLEEP   // s_sleep argument between two polls of the arrival counter (x64 cycles)
 #define LDPC_TEAM_SLEEP 16
 #endif
@@ -105,9 +108,63 @@ __device__ __forceinline__ TeamVRec<DV> team_vrec_load(const int *__restrict__ v
     rc.bit = w[2 * DV];
     return rc;
 }
+// Rows in REGISTERS (instantiations with RR > 0, on top of the rows in LDS).  The LDS of a member holds 312 of the ~512
+// rows that only it touches; the rest of them can live in the registers of ONE wave if that wave, and no other, updates
+// both the row's check and its bit in every iteration.  So a part of every member's share of a sweep belongs to its
+// waves BY RIGHT (the first static_c check chunks / static_v position chunks: chunk l of the share to wave l % W; the
+// rest is dealt from the counter in LDS as before), and the host puts a bit whose owning check is such a wave's into
+// a position that is the same wave's (team_rows_tables()).  A wave keeps up to kTeamRegRows rows in the TOP of its
+// register file: row x in v[192 + 2x], v[193 + 2x], addressed with the wave-uniform row number through the VGPR index
+// mode (s_set_gpr_idx_on + v_mov_b32).  The rows-on-chip instantiations run one 8-wave workgroup per CU (156 KB of
+// LDS), i.e. two waves per SIMD: 256 registers a lane are theirs anyway, and the compiler needs about 130 of them and
+// hands registers out from v0 upwards -- v192 ... v255 are free for the taking.  It only learns, from the clobber
+// lists, that the kernel needs 256 registers; tests/test_abi_cpu.py checks in the built code object that nothing
+// but these accessors touches v192 and up.  What did NOT work (all tried, all in the commit history of round 3):
+//   * a C++ register array with a run-time index: arrays of more than 32 registers go to scratch memory; so does any
+//     array whose address ends up in a select or phi, and "this register row or that memory row" is folded into
+//     exactly that; kept in registers by force the arrays become SSA values of 32 registers that are copied at every
+//     join (256 VGPRs and 888 bytes of spills);
+//   * accumulator registers a0 ... a63 through the same index mode (gfx950 honours it for v_accvgpr_read / _write:
+//     tools/agpr_index_probe.hip): once a kernel has accumulator registers at all, the register allocator parks its
+//     own values in them between the asm statements -- 1,207 such moves, wrong results, the check sweep 20 us slower.
+// With them 25 % of the rows of a (4,8)-regular tile are on chip instead of 15 %.
+constexpr int kTeamRegRows = 32;
+#define LDPC_TEAM_TOP_VGPRS                                                                                                      \
+    "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207",     \
+        "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", \
+        "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", \
+        "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
+static_assert(192 + 2 * kTeamRegRows == 256, "the clobber list names the registers of kTeamRegRows rows");
+// (every lane of the wave is active wherever these are used; row is wave-uniform.  s_nop: one wait state between the
+// scalar write of M0 and a vector instruction that uses the index)
+__device__ __forceinline__ double team_reg_get(const int row)
+{
+#ifdef LDPC_TEAM_FAKE_REGS   // (timing experiment: the code around the accessors without the accessors; results are wrong)
+    return 0.5 + 1e-3 * row;
+#endif
+    unsigned int lo, hi;
+    const int q = __builtin_amdgcn_readfirstlane(2 * row);
+    asm volatile("s_set_gpr_idx_on %2, 0x1\n\ts_nop 0\n\tv_mov_b32 %0, v192\n\tv_mov_b32 %1, v193\n\ts_set_gpr_idx_off"
+                 : "=v"(lo), "=v"(hi) : "s"(q) : LDPC_TEAM_TOP_VGPRS);
+    return __hiloint2double((int)hi, (int)lo);
+}
+__device__ __forceinline__ void team_reg_put(const int row, const double v)
+{
+#ifdef LDPC_TEAM_FAKE_REGS
+    return;
+#endif
+    const unsigned int lo = (unsigned int)__double2loint(v), hi = (unsigned int)__double2hiint(v);
+    const int q = __builtin_amdgcn_readfirstlane(2 * row);
+    asm volatile("s_set_gpr_idx_on %2, 0x8\n\ts_nop 0\n\tv_mov_b32 v192, %0\n\tv_mov_b32 v193, %1\n\ts_set_gpr_idx_off"
+                 : : "v"(lo), "v"(hi), "s"(q) : LDPC_TEAM_TOP_VGPRS);
+}
 struct TeamRows {
     const int *lds_edge;        // [G][R]  CSR rows held by each member, -1 beyond its count (write-back before a hand-off)
     int R;                      // LDS rows per member
+    const int *reg_edge;        // [G][W][regs]  CSR rows held by each wave in registers, -1 beyond its count
+    int regs;                   // register rows per wave (0 ... kTeamRegRows)
+    int static_c, static_v;     // chunks of a member's share of the check / variable sweep that its waves own by right
+                                // (multiples of W, at least W, at most the smallest member's share)
 };
 
 struct TeamParams {
@@ -260,7 +317,7 @@ __device__ __forceinline__ int team_deal(unsigned int *counter, int lane)
 }
 
 // Check / bit updates with some rows in LDS: generic pointers, the hardware routes each access.  Same arithmetic.
-template <int D, bool FIRST>
+template <int D, bool FIRST, bool TF = false>
 __device__ __forceinline__ void check_update_mixed(double *M, double *L, unsigned int mask, double sigma, double r)
 {
     double *ptr[D];
@@ -283,12 +340,12 @@ __device__ __forceinline__ void check_update_mixed(double *M, double *L, unsigne
 #pragma unroll
         for (int k = 0; k < D; ++k) a[k] = 2.0 / (1.0 + m[k]) - 1.0;
     }
-    check_compute_exact<D>(a, sigma, out);
+    check_compute_exact<D, TF>(a, sigma, out);
 #pragma unroll
     for (int k = D - 1; k >= 0; --k) *ptr[k] = out[k];
 }
 
-template <int D>
+template <int D, bool TF = false>
 __device__ __forceinline__ double bit_update_mixed(double *Mt, double *L, const int (&pos)[D], const int (&lrow)[D], double r)
 {
     double *ptr[D];
@@ -300,9 +357,89 @@ __device__ __forceinline__ double bit_update_mixed(double *Mt, double *L, const 
     double c[D], out[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) c[k] = *ptr[k];
+    if (TF) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) c[k] = (1.0 - c[k]) / (1.0 + c[k]);   // :147
+    }
     const double F = bit_compute_exact<D>(c, r, out);
 #pragma unroll
     for (int k = D - 1; k >= 0; --k) *ptr[k] = out[k];
+    return F;
+}
+
+// ... and with some rows in the wave's registers (rget(row) reads register row `row`, rput(on, row, v) writes it when
+// `on`; row numbers are wave-uniform): rmask = the check's edges that live there, from register row rbase on.  A
+// row that lives in registers is neither loaded from nor stored to memory.  Same arithmetic.
+template <int D, bool FIRST, bool TF, class RGet, class RPut>
+__device__ __forceinline__ void check_update_onchip(double *M, double *L, unsigned int mask, unsigned int rmask, int rbase,
+                                                    double sigma, double r, RGet &&rget, RPut &&rput)
+{
+    double *ptr[D];
+    int nl = 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const bool in_lds = (mask >> k) & 1u;
+        ptr[k] = in_lds ? L + (size_t)nl * kTile : M + (size_t)k * kTile;
+        nl += in_lds ? 1 : 0;
+    }
+    double a[D], out[D];
+    if (FIRST) {
+        const double a0 = 2.0 / (1.0 + r) - 1.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) a[k] = a0;
+    } else {
+        double m[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {                          // the rows in memory first: all their loads in flight
+            m[k] = 0.0;
+            if (!((rmask >> k) & 1u)) m[k] = *ptr[k];
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            if ((rmask >> k) & 1u) m[k] = rget(rbase + __builtin_popcount(rmask & ((1u << k) - 1u)));
+#pragma unroll
+        for (int k = 0; k < D; ++k) a[k] = 2.0 / (1.0 + m[k]) - 1.0;
+    }
+    check_compute_exact<D, TF>(a, sigma, out);
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) {
+        const bool in_reg = (rmask >> k) & 1u;
+        if (!in_reg) *ptr[k] = out[k];
+        rput(in_reg, rbase + __builtin_popcount(rmask & ((1u << k) - 1u)), out[k]);
+    }
+}
+
+// loc[k]: >= 0 that LDS row, -1 the slot (row pos[k]), <= -2 register row -2 - loc[k] of this wave
+template <int D, bool TF, class RGet, class RPut>
+__device__ __forceinline__ double bit_update_onchip(double *Mt, double *L, const int (&pos)[D], const int (&loc)[D], double r,
+                                                    RGet &&rget, RPut &&rput)
+{
+    double *ptr[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const bool in_lds = loc[k] >= 0;
+        ptr[k] = (in_lds ? L : Mt) + (size_t)(in_lds ? loc[k] : pos[k]) * kTile;
+    }
+    double c[D], out[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        c[k] = 0.0;
+        if (loc[k] > -2) c[k] = *ptr[k];
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+        if (loc[k] <= -2) c[k] = rget(-2 - loc[k]);
+    if (TF) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) c[k] = (1.0 - c[k]) / (1.0 + c[k]);   // :147
+    }
+    const double F = bit_compute_exact<D>(c, r, out);
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) {
+        const bool in_reg = loc[k] <= -2;
+        if (!in_reg) *ptr[k] = out[k];
+        rput(in_reg, -2 - loc[k], out[k]);
+    }
     return F;
 }
 
@@ -317,7 +454,7 @@ constexpr int team_min_waves_per_simd()
 
 // RESUMED: the pass over a packed level (the messages are in the packed tiles, every lane has iterations behind it)
 // is an instantiation of its own -- it shows under its own name in a profile, and the fresh pass loses the tests.
-template <int DC, int DV, bool WANT_LLR, int THREADS, bool RESUMED, bool LROWS = false>
+template <int DC, int DV, bool WANT_LLR, int THREADS, bool RESUMED, bool LROWS = false, int RR = 0>
 __global__ void
 __launch_bounds__(THREADS, (team_min_waves_per_simd<DC, DV, THREADS, LROWS>()))
 bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const int *__restrict__ edge_bit,
@@ -325,6 +462,23 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
                const u64 *__restrict__ synmask, const u64 *__restrict__ nevermask)
 {
     static_assert(!(LROWS && RESUMED), "packed tiles are decoded where they lie, all rows in global memory");
+    static_assert(RR == 0 || (LROWS && RR == kTeamRegRows), "rows in registers come on top of the rows in LDS");
+    // Where the division (1 - t) / (1 + t) of :147 is made (check_finish_exact): the rows-on-chip instantiations leave
+    // it to the variable sweep.  A check costs 16 fp64 divisions (two per edge) and the check sweep of the persistent
+    // teams is bound by them, not by the memory side; the variable sweep has no division at all and waits for its
+    // scattered rows.  One division per edge in either sweep: the same operations on the same operands, the same
+    // bits -- and at every iteration boundary (hand-off, write-back) the rows are bit -> check messages as ever.
+    constexpr bool TF = LROWS && (LDPC_TEAM_TFORM != 0);
+    // rows in registers (RR > 0): v[192 + 2 * row], v[193 + 2 * row] of this wave (team_reg_get / team_reg_put)
+    auto rget = [&](const int row) -> double {
+        if constexpr (RR > 0) return team_reg_get(row);
+        else return 0.0;
+    };
+    auto rput = [&](const bool on, const int row, const double v) {   // on: this edge lives in a register row (else nothing happens)
+        if constexpr (RR > 0) {
+            if (on) team_reg_put(row, v);
+        }
+    };
     extern __shared__ double lds_rows[];   // LROWS: [tp.rows.R][64]
     double *const Lr = lds_rows + (threadIdx.x & 63);
     __shared__ int sh_ok;
@@ -409,35 +563,40 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
         auto chunk = [&](int c) {
             const int i1 = min(s, (c + 1) * kTeamCheckChunk);
             if constexpr (LROWS) {
-                // every check has the full degree (the host instantiates this only for such graphs); col_ptr is ctab.
+                // every check has the full degree (the host instantiates this only for such graphs); col_ptr is ctab
+                // [s][4] = {edges in LDS, first LDS row, edges in registers, first register row}.
                 // (Pairs of checks / bits with rows in LDS loaded together measured slower, not faster.)
                 typedef int v4i __attribute__((ext_vector_type(4)));
+                typedef int v8i __attribute__((ext_vector_type(8)));
+                auto one = [&](double *const M, const v4i ct, const double sg) {
+                    if (RR > 0 && ct.z != 0) {
+                        if (first) check_update_onchip<DC, true, TF>(M, Lr + (size_t)ct.y * kTile, (unsigned int)ct.x, (unsigned int)ct.z, ct.w, sg, r, rget, rput);
+                        else check_update_onchip<DC, false, TF>(M, Lr + (size_t)ct.y * kTile, (unsigned int)ct.x, (unsigned int)ct.z, ct.w, sg, r, rget, rput);
+                    } else if (first) {
+                        check_update_mixed<DC, true, TF>(M, Lr + (size_t)ct.y * kTile, (unsigned int)ct.x, sg, r);
+                    } else if (ct.x == 0) {
+                        check_update_exact<DC, false, TF>(M, sg, r);
+                    } else {
+                        check_update_mixed<DC, false, TF>(M, Lr + (size_t)ct.y * kTile, (unsigned int)ct.x, sg, r);
+                    }
+                };
                 const int i = c * kTeamCheckChunk;
                 if (kTeamCheckChunk == 2 && i + 2 == i1) {
-                    const v4i ct = *(const v4i *)(col_ptr + 2 * i);   // both checks' masks and bases in one scalar load
+                    const v8i ct = *(const v8i *)(col_ptr + 4 * i);   // both checks' table rows in one scalar load
                     const u64 s0 = syn[i], s1 = syn[i + 1];
                     const double sg0 = ((s0 >> lane) & 1ull) ? -1.0 : 1.0, sg1 = ((s1 >> lane) & 1ull) ? -1.0 : 1.0;
                     double *const M0 = Mt + (size_t)i * DC * kTile, *const M1 = M0 + (size_t)DC * kTile;
-                    if ((ct.x | ct.z) == 0 && !first && tp.pairs) {
-                        check_update_pair<DC>(M0, M1, sg0, sg1);
-                    } else if (first) {
-                        check_update_mixed<DC, true>(M0, Lr + (size_t)ct.y * kTile, (unsigned int)ct.x, sg0, r);
-                        check_update_mixed<DC, true>(M1, Lr + (size_t)ct.w * kTile, (unsigned int)ct.z, sg1, r);
+                    if ((ct.s0 | ct.s2 | ct.s4 | ct.s6) == 0 && !first && tp.pairs) {
+                        check_update_pair<DC, TF>(M0, M1, sg0, sg1);
                     } else {
-                        if (ct.x == 0) check_update_exact<DC, false>(M0, sg0, r);
-                        else check_update_mixed<DC, false>(M0, Lr + (size_t)ct.y * kTile, (unsigned int)ct.x, sg0, r);
-                        if (ct.z == 0) check_update_exact<DC, false>(M1, sg1, r);
-                        else check_update_mixed<DC, false>(M1, Lr + (size_t)ct.w * kTile, (unsigned int)ct.z, sg1, r);
+                        one(M0, v4i{ct.s0, ct.s1, ct.s2, ct.s3}, sg0);
+                        one(M1, v4i{ct.s4, ct.s5, ct.s6, ct.s7}, sg1);
                     }
                     return;
                 }
                 for (int ii = i; ii < i1; ++ii) {
-                    const unsigned int mask = (unsigned int)col_ptr[2 * ii];
-                    const double sigma = ((syn[ii] >> lane) & 1ull) ? -1.0 : 1.0;
-                    double *const M = Mt + (size_t)ii * DC * kTile;
-                    double *const L = Lr + (size_t)col_ptr[2 * ii + 1] * kTile;
-                    if (first) check_update_mixed<DC, true>(M, L, mask, sigma, r);
-                    else check_update_mixed<DC, false>(M, L, mask, sigma, r);
+                    const v4i ct = *(const v4i *)(col_ptr + 4 * ii);
+                    one(Mt + (size_t)ii * DC * kTile, ct, ((syn[ii] >> lane) & 1ull) ? -1.0 : 1.0);
                 }
                 return;
             }
@@ -459,11 +618,13 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
                 else check_update<DC, false>(Mt + (size_t)e0 * kTile, deg, sigma, r);
             }
         };
-        // this member's share is chunks rank, rank + G, ...; its waves take them from the counter in LDS
+        // this member's share is chunks rank, rank + G, ...: the first `stat` of them belong to its waves by right (chunk
+        // l to wave l % W -- at least each wave's first), the rest they take from the counter in LDS
         const int mine = (nch - rank + G - 1) / G;
+        const int stat = LROWS ? tp.rows.static_c : W;
         for (int l = w; l < mine;) {
             chunk(l * G + rank);
-            l = tp.dynamic ? W + team_deal(&sh_deal[0], lane) : l + W;
+            l = !tp.dynamic ? l + W : (l + W < stat ? l + W : stat + team_deal(&sh_deal[0], lane));
         }
     };
     // ---- variable-node sweep  (:152-178).  Across XCDs a chunk is 16 consecutive bits, so that a 128-byte line of
@@ -486,13 +647,19 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
                 // table says about the four positions of a chunk is asked for at once (one scalar round trip per chunk)
                 constexpr int VT = team_vtab_words(DV);
                 auto single = [&](const TeamVRec<DV> &a) {
-                    if (a.bit >= 0) decide(a.bit, bit_update_exact_v<DV>(Mt, a.pos, r));
-                    else decide(a.bit & 0x7fffffff, bit_update_mixed<DV>(Mt, Lr, a.pos, a.lrow, r));
+                    if (a.bit >= 0) { decide(a.bit, bit_update_exact_v<DV, TF>(Mt, a.pos, r)); return; }
+                    if constexpr (RR > 0) {
+                        int lo = a.lrow[0];
+#pragma unroll
+                        for (int k = 1; k < DV; ++k) lo = min(lo, a.lrow[k]);
+                        if (lo <= -2) { decide(a.bit & 0x7fffffff, bit_update_onchip<DV, TF>(Mt, Lr, a.pos, a.lrow, r, rget, rput)); return; }
+                    }
+                    decide(a.bit & 0x7fffffff, bit_update_mixed<DV, TF>(Mt, Lr, a.pos, a.lrow, r));
                 };
                 auto two = [&](const TeamVRec<DV> &a, const TeamVRec<DV> &b) {
                     if ((a.bit | b.bit) >= 0 && tp.pairs) {   // neither has a row in LDS: both loaded together
                         double T0, T1;
-                        bit_update_pair_v<DV>(Mt, a.pos, b.pos, r, T0, T1);
+                        bit_update_pair_v<DV, TF>(Mt, a.pos, b.pos, r, T0, T1);
                         decide(a.bit, T0);
                         decide(b.bit, T1);
                     } else {
@@ -532,9 +699,10 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
             }
         };
         const int mine = (nch - rank + G - 1) / G;
+        const int stat = LROWS ? tp.rows.static_v : W;
         for (int l = w; l < mine;) {
             chunk(l * G + rank);
-            l = tp.dynamic ? W + team_deal(&sh_deal[1], lane) : l + W;
+            l = !tp.dynamic ? l + W : (l + W < stat ? l + W : stat + team_deal(&sh_deal[1], lane));
         }
     };
     // ---- convergence test (:180-184) of iteration it_t on the decision words em_t: lane = check, words = 64 syndromes;
@@ -632,6 +800,13 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
                 for (int q = w; q < tp.rows.R; q += W) {
                     const int e = le[q];
                     if (e >= 0) Mt[(size_t)e * kTile] = Lr[(size_t)q * kTile];
+                }
+                if constexpr (RR > 0) {   // ... and so do the rows this wave keeps in registers
+                    const int *const re = tp.rows.reg_edge + (size_t)(rank * W + w) * tp.rows.regs;
+                    for (int q = 0; q < tp.rows.regs; ++q) {
+                        const int e = __builtin_amdgcn_readfirstlane(re[q]);
+                        if (e >= 0) Mt[(size_t)e * kTile] = rget(q);
+                    }
                 }
             }
             if (rank == 0 && threadIdx.x == 0)

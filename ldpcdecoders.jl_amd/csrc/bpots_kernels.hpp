@@ -542,4 +542,196 @@ bpots_node_kernel(OtsNodeParams p, const int *__restrict__ row_ptr, const int *_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// BP-OTS without limits: graphs whose per-syndrome bytes do not fit a CU's LDS (n beyond ~30,000) or whose nodes are
+// wider than the register buckets above (check degree > 32, bit degree > 16) -- the reference's BPOTSDecoder takes any
+// H (bpots_decoder.jl:225-340).  The same geometry as bpots_node_kernel (one workgroup per syndrome, one thread per
+// node), but EVERYTHING of the syndrome lives in its private global slot: messages M[nnz], a second array T[nnz] for
+// what a node needs of its OLD values while it overwrites them (the "all other neighbours" folds of :161-167 and
+// :182-192 are O(deg^2) loads from it instead of register arrays), LLRs, oscillation counters, parities, syndrome codes
+// and the three decision vectors.  Only the per-thread candidates of the bias step are in LDS.  Statement for
+// statement the arithmetic of the two kernels above -- the same left folds in the same order, the same clamps, the same
+// tie-breaks --, so all three agree bit for bit wherever more than one applies (tests/test_gpu_bpots.py).
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t ots_big_slot_doubles(int s, int n, int nnz)
+{
+    // M[nnz] | T[nnz] | LLR[n] | OSC[n] (int) | par[s] (unsigned) | code[s] dec[n] prv[n] best[n] (bytes)
+    const size_t bytes = (size_t)nnz * 16 + (size_t)n * 8 + (size_t)n * 4 + (size_t)s * 4 + (size_t)s + 3 * (size_t)n;
+    return ((bytes + 7) / 8 + 63) & ~(size_t)63;
+}
+
+__global__ void __launch_bounds__(kOtsNodeThreads)
+bpots_big_kernel(OtsNodeParams p, const int *__restrict__ row_ptr, const int *__restrict__ csc_row,
+                 const int *__restrict__ col_ptr, const int *__restrict__ csc2csr)
+{
+    constexpr int THREADS = kOtsNodeThreads;
+    __shared__ double pk1[THREADS], pk2[THREADS];
+    __shared__ int po[THREADS], pi1[THREADS], pi2[THREADS];
+    __shared__ long long sh_b;
+    __shared__ int sh_cnt_m, sh_cnt_w, sh_best_m, sh_best_w, sh_bj1, sh_bj2, sh_flags;   // flags: 1 update best, 2 converged, 4 bias
+    const int s = p.s, n = p.n, nnz = p.nnz;
+    double *M = p.ws + (size_t)blockIdx.x * (size_t)p.slot_doubles;
+    double *Told = M + nnz;
+    double *LLR = Told + nnz;
+    int *OSC = (int *)(LLR + n);
+    unsigned int *par = (unsigned int *)(OSC + n);
+    unsigned char *code = (unsigned char *)(par + s);
+    unsigned char *dec = code + s, *prv = dec + n, *best = prv + n;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const double PI0 = p.prior, NEGC = -p.C;
+    const double MAX_TANH = 0.99999, MAX_MSG = 100.0;
+
+    for (;;) {
+        if (tid == 0) {
+            const long long q = (long long)atomicAdd(p.queue, 1u);
+            sh_b = q >= p.batch ? -1 : q;
+        }
+        __syncthreads();
+        const long long b = sh_b;
+        if (b < 0) break;                                   // every wave of every workgroup reaches this
+        // ---- reset! (:142-154) and the syndrome in
+        for (int i = tid; i < s; i += THREADS) {
+            const unsigned v = p.syn[(size_t)b * s + i];
+            code[i] = (unsigned char)(v > 1u ? 2u : v);
+        }
+        for (int e = tid; e < nnz; e += THREADS) M[e] = 0.0;
+        for (int j = tid; j < n; j += THREADS) { OSC[j] = 0; prv[j] = 0; best[j] = 0; }
+        if (tid == 0) { sh_best_m = s; sh_best_w = n; sh_bj1 = -1; sh_bj2 = -1; }          // :236-237
+        __syncthreads();
+
+        int it = 0, converged = 0;
+        while (it < p.max_iters) {
+            ++it;
+            const int bj1 = sh_bj1, bj2 = sh_bj2;
+            // ---- variable -> check (:241-245, :158-172): the old messages of the bit go to T, the new ones are folds over T
+            for (int j = tid; j < n; j += THREADS) {
+                const int c0 = col_ptr[j];
+                const int deg = col_ptr[j + 1] - c0;
+                const double om = (j == bj1 || j == bj2) ? NEGC : PI0;
+                for (int k = 0; k < deg; ++k) Told[c0 + k] = M[csc2csr[c0 + k]];
+                for (int k = 0; k < deg; ++k) {
+                    double sum = 0.0;
+                    for (int q = 0; q < deg; ++q)
+                        if (q != k) sum += Told[c0 + q];
+                    M[csc2csr[c0 + k]] = om + sum;
+                }
+            }
+            if (tid == 0) { sh_cnt_m = 0; sh_cnt_w = 0; sh_flags = 0; }
+            __syncthreads();
+            // ---- check -> variable (:247-251, :178-210): the clamped tanh of every edge goes to T first
+            for (int i = tid; i < s; i += THREADS) {
+                const int e0 = row_ptr[i];
+                const int deg = row_ptr[i + 1] - e0;
+                const bool flip = code[i] != 0;
+                par[i] = 0u;
+                for (int k = 0; k < deg; ++k) {
+                    double tv = pm_tanh(0.5 * M[e0 + k]);
+                    tv = tv > MAX_TANH ? MAX_TANH : (tv < -MAX_TANH ? -MAX_TANH : tv);
+                    Told[e0 + k] = tv;
+                }
+                for (int k = 0; k < deg; ++k) {
+                    double prod = 1.0;
+                    for (int q = 0; q < deg; ++q)
+                        if (q != k) prod *= Told[e0 + q];
+                    if (flip) prod = -prod;
+                    if (pm_fabs(prod) >= MAX_TANH) prod = prod > 0 ? MAX_TANH : -MAX_TANH;
+                    double msg = 2.0 * pm_atanh(prod);
+                    msg = msg > MAX_MSG ? MAX_MSG : (msg < -MAX_MSG ? -MAX_MSG : msg);
+                    M[e0 + k] = msg;
+                }
+            }
+            __syncthreads();
+            // ---- beliefs, decisions, oscillations, parities (:120-136, :257-263), weight (:281)
+            int wcount = 0;
+            for (int j = tid; j < n; j += THREADS) {
+                const int c0 = col_ptr[j];
+                const int deg = col_ptr[j + 1] - c0;
+                double llr = (j == bj1 || j == bj2) ? NEGC : PI0;
+                for (int k = 0; k < deg; ++k) llr += M[csc2csr[c0 + k]];
+                LLR[j] = llr;
+                const unsigned char d1 = llr < 0.0 ? 1 : 0;
+                if (it > 1 && d1 != prv[j]) OSC[j] += 1;
+                dec[j] = d1;
+                prv[j] = d1;
+                if (d1) {
+                    ++wcount;
+                    for (int k = 0; k < deg; ++k) atomicXor(&par[csc_row[c0 + k]], 1u);
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) wcount += __shfl_xor(wcount, off, 64);
+            if (lane == 0 && wcount) atomicAdd(&sh_cnt_w, wcount);
+            __syncthreads();
+            // ---- mismatch (:266-279)
+            int mcount = 0;
+            for (int i = tid; i < s; i += THREADS) mcount += (code[i] > 1 || (par[i] & 1u) != (unsigned)code[i]) ? 1 : 0;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mcount += __shfl_xor(mcount, off, 64);
+            if (lane == 0 && mcount) atomicAdd(&sh_cnt_m, mcount);
+            __syncthreads();
+            // ---- best solution so far (:284-292), converged?, bias due? (:295)
+            if (tid == 0) {
+                const int m = sh_cnt_m, wgt = sh_cnt_w;
+                int f = 0;
+                if (m < sh_best_m || (m == sh_best_m && wgt < sh_best_w)) {
+                    sh_best_m = m; sh_best_w = wgt;
+                    f |= 1;
+                    if (m == 0) f |= 2;
+                }
+                if (m > 0 && (it % p.T) == 0) f |= 4;
+                sh_flags = f;
+            }
+            __syncthreads();
+            const int flags = sh_flags;
+            if (flags & 1)
+                for (int j = tid; j < n; j += THREADS) best[j] = dec[j];
+            if (flags & 2) { converged = 1; __syncthreads(); break; }
+            if (flags & 4) {
+                // ---- bias step (:297-337): Omega .= Pi, then j1 (most oscillating, then least |llr|, then lowest
+                //      index) and j2 (least |llr| overall, lowest index)
+                int bo = -1, bi = -1, bi2 = -1;
+                double bk = 0.0, bk2 = 0.0;
+                for (int j = tid; j < n; j += THREADS) {
+                    const int o = OSC[j];
+                    const double a = pm_fabs(LLR[j]);
+                    if (bi < 0 || o > bo || (o == bo && a < bk)) { bo = o; bk = a; bi = j; }
+                    if (bi2 < 0 || a < bk2) { bk2 = a; bi2 = j; }
+                }
+                po[tid] = bo; pk1[tid] = bk; pi1[tid] = bi; pk2[tid] = bk2; pi2[tid] = bi2;
+                __syncthreads();
+                if (tid == 0) {
+                    bo = -1; bi = -1; bi2 = -1; bk = 0.0; bk2 = 0.0;
+                    for (int t = 0; t < THREADS; ++t) {
+                        const int i1 = pi1[t];
+                        if (i1 >= 0) {
+                            const int o = po[t];
+                            const double a = pk1[t];
+                            if (bi < 0 || o > bo || (o == bo && (a < bk || (a == bk && i1 < bi)))) { bo = o; bk = a; bi = i1; }
+                        }
+                        const int i2 = pi2[t];
+                        if (i2 >= 0) {
+                            const double a2 = pk2[t];
+                            if (bi2 < 0 || a2 < bk2 || (a2 == bk2 && i2 < bi2)) { bk2 = a2; bi2 = i2; }
+                        }
+                    }
+                    sh_bj1 = -1; sh_bj2 = -1;                 // Omega .= Pi (:297)
+                    if (bo > 0) {                             // maximum(oscillations) > 0 (:300)
+                        OSC[bi] = 0;                          // :320
+                        sh_bj1 = bi;                          // :323
+                        sh_bj2 = bi2;                         // :336
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // ---- results out: best_decisions (:340 / :291)
+        for (int j = tid; j < n; j += THREADS) p.err[(size_t)b * n + j] = best[j];
+        if (tid == 0) {
+            p.conv[b] = (unsigned char)converged;
+            if (p.iters) p.iters[b] = it;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace ldpc

@@ -50,6 +50,8 @@ struct ldpc_bpots_decoder {
     bool kernel_ready = false;  // dynamic-LDS limit set, occupancy known
     int per_cu = 1;
     bool node_mode = false;     // the graph is beyond the LDS kernel: bpots_node_kernel, messages in a global slot
+    bool big_mode = false;      // ... and beyond that one too (bytes of a syndrome past the LDS, or nodes wider than the
+                                // register buckets): bpots_big_kernel, everything in the global slot, any degree
     double *node_ws = nullptr;  // [grid][slot] of the node kernel
     size_t node_ws_cap = 0;
     ~ldpc_bpots_decoder()
@@ -133,13 +135,15 @@ ldpc_status ldpc_bpots_create(int64_t s, int64_t n, int64_t nnz, const int64_t *
         }
         col_ptr[(size_t)n] = (int)nnz;
     }
-    if (d->max_cdeg > 32 || d->max_bdeg > 16 || nnz >= ((int64_t)1 << 28) || s >= ((int64_t)1 << 28) || n >= ((int64_t)1 << 28)) {
+    if (nnz >= ((int64_t)1 << 28) || s >= ((int64_t)1 << 28) || n >= ((int64_t)1 << 28)) {
         delete d;
-        return set_error(LDPC_ERR_UNSUPPORTED, "BP-OTS kernels: check degree <= 32 and bit degree <= 16");
+        return set_error(LDPC_ERR_UNSUPPORTED, "BP-OTS kernels: graph too large for 32-bit edge indexing");
     }
     d->logS = -1;
-    const bool force_node = exp_env("LDPC_BPOTS_FORCE_NODE") != nullptr;   // tests (read at create): small graphs through the node kernel
-    if (!force_node && nnz < 65535 && s < 65535 && n < 65535)   // (uint16 graph copies in LDS)
+    // tests (experiments build, read at create): LDPC_BPOTS_FORCE_NODE = 1 sends small graphs through the node kernel, 2 through the unlimited one
+    const int force_node = exp_env("LDPC_BPOTS_FORCE_NODE") ? std::max(1, std::atoi(exp_env("LDPC_BPOTS_FORCE_NODE"))) : 0;
+    const bool wide = d->max_cdeg > 32 || d->max_bdeg > 16;   // beyond the register buckets of the two fast kernels
+    if (!force_node && !wide && nnz < 65535 && s < 65535 && n < 65535)   // (uint16 graph copies in LDS)
         for (int l = 0; l <= 6; ++l) {
             const size_t b = ots_lds_bytes((int)s, (int)n, (int)nnz, 1 << l) + 8192;
             if (b <= (size_t)76 * 1024 || (d->logS < 0 && b <= (size_t)156 * 1024)) d->logS = l;
@@ -147,12 +151,10 @@ ldpc_status ldpc_bpots_create(int64_t s, int64_t n, int64_t nnz, const int64_t *
         }
     if (d->logS < 0) {
         // beyond the LDS kernel: one workgroup per syndrome, messages in a global slot, bytes / parities in LDS
-        if (ots_node_lds_bytes((int)s, (int)n) + 1024 > (size_t)156 * 1024) {
-            delete d;
-            return set_error(LDPC_ERR_UNSUPPORTED, "BP-OTS kernels: s + 3n bytes of decisions and 4s bytes of parities must fit a CU's LDS "
-                                                   "(about n = 30,000 for a rate-1/2 code)");
-        }
         d->node_mode = true;
+        // ... and when even the bytes and parities of one syndrome do not fit the LDS, or nodes are wider than the register
+        // buckets: everything in the global slot, any degree (the reference's BPOTSDecoder has no limit either)
+        d->big_mode = wide || force_node >= 2 || ots_node_lds_bytes((int)s, (int)n) + 1024 > (size_t)156 * 1024;
     }
     auto up = [&](int *&dst, const std::vector<int> &v) -> bool {
         if (hipMalloc((void **)&dst, std::max<size_t>(v.size(), 1) * sizeof(int)) != hipSuccess) return false;
@@ -169,7 +171,7 @@ ldpc_status ldpc_bpots_create(int64_t s, int64_t n, int64_t nnz, const int64_t *
     return LDPC_OK;
 }
 
-int32_t ldpc_bpots_kernel(const ldpc_bpots_decoder *d) { return d ? (d->node_mode ? 3 : 2) : 0; }
+int32_t ldpc_bpots_kernel(const ldpc_bpots_decoder *d) { return d ? (d->big_mode ? 5 : d->node_mode ? 3 : 2) : 0; }
 
 ldpc_status ldpc_bpots_destroy(ldpc_bpots_decoder *d)
 {
@@ -204,14 +206,14 @@ static ldpc_status bpots_decode_impl(ldpc_bpots_decoder *d, int64_t batch, const
     }
     if (d->node_mode) {
         if (batch > (1ll << 30)) return set_error(LDPC_ERR_UNSUPPORTED, "batch too large for one call");
-        ots_node_kernel_t nk = pick_ots_node(d->max_cdeg, d->max_bdeg);
-        const size_t nlds = ots_node_lds_bytes((int)d->s, (int)d->n);
+        ots_node_kernel_t nk = d->big_mode ? (ots_node_kernel_t)bpots_big_kernel : pick_ots_node(d->max_cdeg, d->max_bdeg);
+        const size_t nlds = d->big_mode ? 0 : ots_node_lds_bytes((int)d->s, (int)d->n);
         if (!d->kernel_ready) {
-            OTS_TRY(hipFuncSetAttribute((const void *)nk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nlds));
+            if (nlds) OTS_TRY(hipFuncSetAttribute((const void *)nk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nlds));
             d->kernel_ready = true;
         }
         const int grid = (int)std::min<int64_t>(batch, d->num_cus);
-        const size_t slot = ots_node_slot_doubles((int)d->n, (int)d->nnz);
+        const size_t slot = d->big_mode ? ots_big_slot_doubles((int)d->s, (int)d->n, (int)d->nnz) : ots_node_slot_doubles((int)d->n, (int)d->nnz);
         if (d->node_ws_cap < (size_t)grid * slot * sizeof(double)) {
             if (d->node_ws) { OTS_TRY(hipStreamSynchronize(stream)); (void)hipFree(d->node_ws); }
             d->node_ws = nullptr; d->node_ws_cap = 0;

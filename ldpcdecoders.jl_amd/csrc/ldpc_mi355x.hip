@@ -363,7 +363,10 @@ struct ldpc_bp_decoder {
     bool team_rows_on = true;         // LDPC_TEAM_ROWS at create (0 = every row in the slot)
     int rows_dc = 0, rows_dv = 0;     // the graph's (check, bit) degree when it is regular and has a rows-in-LDS instantiation
     int rows_G = 0, rows_R = 0;       // what the tables below were built for: members per team, LDS rows per member
-    DevBuf rows_ctab, rows_vtab, rows_lds_edge;
+    int rows_regs = 0, rows_static_c = 0, rows_static_v = 0;   // ... register rows per wave, chunks per sweep that waves own by right
+    DevBuf rows_ctab, rows_vtab, rows_lds_edge, rows_reg_edge;
+    int team_regs = 0;                // LDPC_TEAM_REGS: rows a wave may keep in its top registers (0 = none: the default -- measured slower)
+    int team_static_quarters = 3;     // LDPC_TEAM_STATIC: quarters of a member's chunks per sweep that its waves own by right (0: only each wave's first)
     unsigned int *team_fault = nullptr, *team_fault_dev = nullptr;
     int team_max = 32;        // workgroups per tile at most (LDPC_TEAM_MAX; 1 = team kernel off)
     bool team_max_set = false;   // ... given by the environment: no automatic 64 for batches of <= 4 tiles
@@ -433,7 +436,7 @@ struct ldpc_bp_decoder {
     {
         DevBuf *all[] = {&row_ptr, &edge_bit, &col_ptr, &csc2csr, &msg, &ctrl, &synmask, &nevermask,
                          &errmask, &finmask, &llr_t, &st_all, &node_msg, &done_ctr, &team_ws, &team_ws_lvl[0], &team_ws_lvl[1], &cold,
-                         &rows_ctab, &rows_vtab, &rows_lds_edge};
+                         &rows_ctab, &rows_vtab, &rows_lds_edge, &rows_reg_edge};
         for (DevBuf *b : all) b->release();
         for (int l = 0; l < 2; ++l)
             for (DevBuf *b : {&lvl_state[l], &lvl_list[l], &lvl_it[l], &lvl_syn[l], &lvl_never[l], &lvl_err[l], &lvl_fin[l], &lvl_llr[l]}) b->release();
@@ -771,6 +774,8 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     if (const char *e = exp_env("LDPC_TEAM_XCDS")) d->team_xcds = std::max(1, std::min(8, std::atoi(e)));
     if (const char *e = exp_env("LDPC_TEAM_PAIRS")) d->team_pairs = std::atoi(e) != 0;
     if (const char *e = exp_env("LDPC_TEAM_AHEAD")) d->team_ahead = std::max(0, std::min(65, std::atoi(e)));
+    if (const char *e = exp_env("LDPC_TEAM_REGS")) d->team_regs = std::max(0, std::min(kTeamRegRows, std::atoi(e)));
+    if (const char *e = exp_env("LDPC_TEAM_STATIC")) d->team_static_quarters = std::max(0, std::min(4, std::atoi(e)));
     if (const char *e = exp_env("LDPC_TEAM_MAX")) { d->team_max = std::max(1, std::min(kTeamMaxMembers, std::atoi(e))); d->team_max_set = true; }
     {
         void *fp = nullptr, *fd = nullptr;
@@ -875,7 +880,7 @@ ldpc_status ldpc_bp_get_info(const ldpc_bp_decoder *d, ldpc_bp_info *info)
                            &d->lvl_state[0], &d->lvl_state[1], &d->lvl_list[0], &d->lvl_list[1], &d->lvl_it[0], &d->lvl_it[1],
                            &d->lvl_syn[0], &d->lvl_syn[1], &d->lvl_never[0], &d->lvl_never[1], &d->lvl_err[0], &d->lvl_err[1], &d->lvl_fin[0], &d->lvl_fin[1],
                            &d->lvl_llr[0], &d->lvl_llr[1], &d->team_ws, &d->team_ws_lvl[0], &d->team_ws_lvl[1],
-                           &d->rows_ctab, &d->rows_vtab, &d->rows_lds_edge};
+                           &d->rows_ctab, &d->rows_vtab, &d->rows_lds_edge, &d->rows_reg_edge};
     for (const DevBuf *b : all) info->workspace_bytes += (int64_t)b->cap;
     info->last_kernel = d->last_kernel;
     info->last_team_size = d->last_team;
@@ -990,21 +995,53 @@ static int team_rows_expected(const TeamPlanIn &in, int G)
 // have dc edges each and whose bits dv.  Checks are dealt as the kernel deals them -- chunk c of 2 checks to member
 // c % G -- and so are the POSITIONS of the bit order, in chunks of 4; the bits are put into positions by the graph: a
 // bit goes to the member, among the owners of its dv checks, that has most room left (any member once those are
-// full).  Every edge whose check and bit then share the owner is a candidate; up to kTeamRowsMax per member get a row
-// in its LDS, numbered in check order.  Record of position p in vtab (vt = team_vtab_words(dv) words): CSR rows of the
-// bit's dv edges, their LDS rows or -1, the bit (| 1 << 31 when one of its edges is in LDS), padding.
+// full).  Every edge whose check and bit then share the owner is a candidate for a row ON CHIP:
+//   * in the REGISTERS of one wave (TeamRegPlan; regs_per_wave > 0).  Inside a member the first `static_c` check
+//     chunks and the first `static_v` position chunks of every sweep belong to its waves by right (chunk l of the
+//     member's share to wave l % W; the rest is dealt from a counter as the waves finish).  A bit whose owning check
+//     sits in a static chunk of wave w is put into a static position of that same wave, as long as the wave has
+//     register rows and static positions left: that edge is then read and written by ONE wave in both sweeps of every
+//     iteration and lives in its registers, numbered per wave in check order;
+//   * else in the member's LDS: up to kTeamRowsMax per member, numbered in check order.
+// Tables: ctab [s][4] = per check {mask of its edges in LDS, LDS row of the first of them, mask of its edges in
+// registers, register row of the first of them} (a check's rows of either kind follow each other); vtab [n][vt]
+// (vt = team_vtab_words(dv)) = per position the CSR rows of the bit's dv edges, where each lives (>= 0: that LDS row,
+// -1: the slot, <= -2: register row -2 - x of the wave), the bit (| 1 << 31 when one of its edges is not in the
+// slot), padding; lds_edge [G][R], reg_edge [G][W][regs_per_wave] = the CSR rows held (-1: none), for the write-back
+// before a hand-off.
 // (pure host code: ldpc_debug_team_rows() hands the tables to a CPU test)
+struct TeamRegPlan {
+    int regs_per_wave = 0;        // 0 = no rows in registers
+    int static_c = 0, static_v = 0;   // chunks of a member's share of the check / variable sweep that belong to waves by right (multiples of W)
+    int W = LDPC_TEAM_THREADS / 64;
+};
 struct TeamRowTables {
     int R = 0;                    // LDS rows per member (the largest count; kTeamRowsMax at most)
     int vt = 0;                   // words per position record of vtab
-    size_t in_lds = 0;            // edges with a row in LDS
-    std::vector<int> vtab, ctab, lds_edge;
+    size_t in_lds = 0, in_regs = 0;   // edges with a row in LDS / in registers
+    std::vector<int> vtab, ctab, lds_edge, reg_edge;
 };
-static TeamRowTables team_rows_tables(int n, int s, int nnz, int dc, int dv, const std::vector<int> &c2r, int G)
+// the static part of a member's share under a plan: `frac_num / 4` of the smallest member's chunks, whole rounds of W
+static TeamRegPlan team_reg_plan(int n, int s, int G, int regs_per_wave, int quarters)
+{
+    TeamRegPlan rp;
+    const int W = rp.W;
+    const int nch_c = (s + kTeamCheckChunk - 1) / kTeamCheckChunk, nch_v = (n + 3) / 4;
+    const int min_c = nch_c / G, min_v = nch_v / G;           // the smallest member's share
+    rp.static_c = std::max(W, min_c * quarters / 4 / W * W);
+    rp.static_v = std::max(W, min_v * quarters / 4 / W * W);
+    if (min_c < 2 * W || min_v < 2 * W || quarters <= 0) { rp.static_c = W; rp.static_v = W; }   // (round 2's dealing: a wave's first chunk is its by right)
+    else rp.regs_per_wave = regs_per_wave;
+    return rp;
+}
+static TeamRowTables team_rows_tables(int n, int s, int nnz, int dc, int dv, const std::vector<int> &c2r, int G, const TeamRegPlan &rp)
 {
     TeamRowTables out;
-    const int vt = team_vtab_words(dv);
+    const int vt = team_vtab_words(dv), W = rp.W, RC = rp.regs_per_wave;
     auto check_owner = [&](int i) { return (i / kTeamCheckChunk) % G; };
+    // the wave that owns check i by right inside its member, or -1 (dealt dynamically)
+    auto check_wave = [&](int i) { const int l = (i / kTeamCheckChunk) / G; return (RC > 0 && l < rp.static_c) ? l % W : -1; };
+    auto pos_wave = [&](int p) { const int l = (p / 4) / G; return (RC > 0 && l < rp.static_v) ? l % W : -1; };
     std::vector<int> cap((size_t)G, 0), member_of_bit((size_t)n, -1);
     for (int p = 0; p < n; ++p) cap[(size_t)((p / 4) % G)]++;
     std::vector<int> room = cap;
@@ -1021,45 +1058,85 @@ static TeamRowTables team_rows_tables(int n, int s, int nnz, int dc, int dv, con
         while (room[(size_t)m] == 0) ++m;
         member_of_bit[(size_t)j] = m; room[(size_t)m]--;
     }
-    // positions: member m's bits, in ascending order, fill its positions in ascending order
-    std::vector<std::vector<int>> bits_of((size_t)G);
+    // positions of every member in ascending order, and which of them belong to a wave by right
+    std::vector<std::vector<int>> pos_of((size_t)G), bits_of((size_t)G);
+    for (int p = 0; p < n; ++p) pos_of[(size_t)((p / 4) % G)].push_back(p);
     for (int j = 0; j < n; ++j) bits_of[(size_t)member_of_bit[(size_t)j]].push_back(j);
-    std::vector<int> bit((size_t)n), taken((size_t)G, 0);
-    for (int p = 0; p < n; ++p) { const int m = (p / 4) % G; bit[(size_t)p] = bits_of[(size_t)m][(size_t)taken[(size_t)m]++]; }
-    // candidates per member, in check order; the first R of each get LDS rows
+    std::vector<int> bit((size_t)n, -1), reg_of((size_t)nnz, -1);
+    std::vector<std::vector<int>> reg_rows((size_t)G * W);       // per (member, wave): the CSR rows held in registers
+    for (int m = 0; m < G; ++m) {
+        std::vector<std::vector<int>> spos((size_t)W);           // static positions of each wave, ascending, not yet taken
+        for (int p : pos_of[(size_t)m]) { const int w = pos_wave(p); if (w >= 0) spos[(size_t)w].push_back(p); }
+        std::vector<size_t> snext((size_t)W, 0);
+        std::vector<char> placed(bits_of[(size_t)m].size(), 0);
+        if (RC > 0)
+            for (size_t b = 0; b < bits_of[(size_t)m].size(); ++b) {
+                const int j = bits_of[(size_t)m][b];
+                for (int k = 0; k < dv; ++k) {
+                    const int q = c2r[(size_t)dv * j + k], i = q / dc;
+                    if (check_owner(i) != m) continue;
+                    const int w = check_wave(i);
+                    if (w < 0 || (int)reg_rows[(size_t)m * W + w].size() >= RC || snext[(size_t)w] >= spos[(size_t)w].size()) continue;
+                    bit[(size_t)spos[(size_t)w][snext[(size_t)w]++]] = j;
+                    reg_rows[(size_t)m * W + w].push_back(q);
+                    placed[b] = 1;
+                    break;
+                }
+            }
+        // the other bits fill the positions that are left, both in ascending order
+        size_t b = 0;
+        for (int p : pos_of[(size_t)m]) {
+            if (bit[(size_t)p] >= 0) continue;
+            while (placed[b]) ++b;
+            bit[(size_t)p] = bits_of[(size_t)m][b++];
+        }
+    }
+    for (int mw = 0; mw < G * W; ++mw) {
+        std::sort(reg_rows[(size_t)mw].begin(), reg_rows[(size_t)mw].end());
+        for (int x = 0; x < (int)reg_rows[(size_t)mw].size(); ++x) reg_of[(size_t)reg_rows[(size_t)mw][(size_t)x]] = x;
+        out.in_regs += reg_rows[(size_t)mw].size();
+    }
+    // LDS candidates per member (check and bit share the owner, not in registers), in check order; the first R of each get rows
     std::vector<std::vector<int>> cand((size_t)G);
     for (int j = 0; j < n; ++j)
         for (int k = 0; k < dv; ++k) {
             const int q = c2r[(size_t)dv * j + k];
-            if (check_owner(q / dc) == member_of_bit[(size_t)j]) cand[(size_t)member_of_bit[(size_t)j]].push_back(q);
+            if (reg_of[(size_t)q] < 0 && check_owner(q / dc) == member_of_bit[(size_t)j]) cand[(size_t)member_of_bit[(size_t)j]].push_back(q);
         }
     int R = 0;
     for (auto &v : cand) { std::sort(v.begin(), v.end()); if ((int)v.size() > kTeamRowsMax) v.resize(kTeamRowsMax); R = std::max(R, (int)v.size()); }
     R = std::max(R, 1);
-    std::vector<int> lds_row_of((size_t)nnz, -1), cbase((size_t)s, 0);
-    std::vector<int> &lds_edge = out.lds_edge;
+    std::vector<int> lds_row_of((size_t)nnz, -1);
+    std::vector<int> &lds_edge = out.lds_edge, &reg_edge = out.reg_edge;
     lds_edge.assign((size_t)G * R, -1);
-    std::vector<unsigned> cmask((size_t)s, 0u);
+    reg_edge.assign((size_t)G * W * std::max(RC, 1), -1);
+    std::vector<int> &vtab = out.vtab, &ctab = out.ctab;
+    vtab.assign((size_t)n * vt, 0);
+    ctab.assign((size_t)s * 4, 0);
     for (int m = 0; m < G; ++m)
         for (int r = 0; r < (int)cand[(size_t)m].size(); ++r) {
             const int q = cand[(size_t)m][(size_t)r], i = q / dc;
             lds_row_of[(size_t)q] = r;
             lds_edge[(size_t)m * R + r] = q;
-            if (cmask[(size_t)i] == 0u) cbase[(size_t)i] = r;   // (ascending q: the check's LDS edges follow each other)
-            cmask[(size_t)i] |= 1u << (q - dc * i);
+            if (ctab[(size_t)4 * i] == 0) ctab[(size_t)4 * i + 1] = r;   // (ascending q: the check's LDS edges follow each other)
+            ctab[(size_t)4 * i] |= 1 << (q - dc * i);
         }
-    std::vector<int> &vtab = out.vtab, &ctab = out.ctab;
-    vtab.assign((size_t)n * vt, 0);
-    ctab.assign((size_t)s * 2, 0);
-    for (int i = 0; i < s; ++i) { ctab[(size_t)2 * i] = (int)cmask[(size_t)i]; ctab[(size_t)2 * i + 1] = cbase[(size_t)i]; }
+    for (int mw = 0; mw < G * W; ++mw)
+        for (int x = 0; x < (int)reg_rows[(size_t)mw].size(); ++x) {
+            const int q = reg_rows[(size_t)mw][(size_t)x], i = q / dc;
+            reg_edge[(size_t)mw * RC + x] = q;
+            if (ctab[(size_t)4 * i + 2] == 0) ctab[(size_t)4 * i + 3] = x;
+            ctab[(size_t)4 * i + 2] |= 1 << (q - dc * i);
+        }
     for (int p = 0; p < n; ++p) {
         const int j = bit[(size_t)p];
         bool any = false;
         for (int k = 0; k < dv; ++k) {
             const int q = c2r[(size_t)dv * j + k];
             vtab[(size_t)p * vt + k] = q;
-            vtab[(size_t)p * vt + dv + k] = lds_row_of[(size_t)q];
-            any = any || lds_row_of[(size_t)q] >= 0;
+            const int where = reg_of[(size_t)q] >= 0 ? -2 - reg_of[(size_t)q] : lds_row_of[(size_t)q];
+            vtab[(size_t)p * vt + dv + k] = where;
+            any = any || where != -1;
         }
         vtab[(size_t)p * vt + 2 * dv] = any ? (j | (int)0x80000000u) : j;
     }
@@ -1071,11 +1148,13 @@ static TeamRowTables team_rows_tables(int n, int s, int nnz, int dc, int dv, con
 
 // include/ldpc_mi355x_debug.h: the tables above for a CPU test
 extern "C" ldpc_status ldpc_debug_team_rows(int64_t s, int64_t n, const int64_t *colptr, const int64_t *rowval, int32_t members,
-                                            int32_t *degrees, int32_t *vt_words, int32_t *lds_rows, int32_t *vtab, int32_t *ctab,
-                                            int32_t *lds_edge)
+                                            int32_t regs_per_wave, int32_t static_quarters, int32_t *degrees, int32_t *shape,
+                                            int32_t *vtab, int32_t *ctab, int32_t *lds_edge, int32_t *reg_edge)
 {
-    if (!colptr || !rowval || !degrees || !vt_words || !lds_rows || !vtab || !ctab || !lds_edge) return fail(LDPC_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (s <= 0 || n <= 0 || members < 1 || members > kTeamMaxMembers) return fail(LDPC_ERR_INVALID_ARGUMENT, "bad dimension");
+    if (!colptr || !rowval || !degrees || !shape || !vtab || !ctab || !lds_edge || !reg_edge) return fail(LDPC_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (s <= 0 || n <= 0 || members < 1 || members > kTeamMaxMembers || regs_per_wave < 0 || regs_per_wave > kTeamRegRows ||
+        static_quarters < 0 || static_quarters > 4)
+        return fail(LDPC_ERR_INVALID_ARGUMENT, "bad dimension");
     const int64_t nnz = colptr[n];
     if (nnz <= 0 || nnz % s != 0 || nnz % n != 0 || nnz >= INT32_MAX) return fail(LDPC_ERR_UNSUPPORTED, "not a regular graph");
     const int dc = (int)(nnz / s), dv = (int)(nnz / n);
@@ -1089,36 +1168,40 @@ extern "C" ldpc_status ldpc_debug_team_rows(int64_t s, int64_t n, const int64_t 
             c2r[(size_t)k] = (int)(dc * i + fill[(size_t)i]++);   // bits ascending inside a check, as ldpc_bp_create lays the rows out
         }
     }
-    const TeamRowTables t = team_rows_tables((int)n, (int)s, (int)nnz, dc, dv, c2r, members);
+    const TeamRegPlan rp = team_reg_plan((int)n, (int)s, members, regs_per_wave, static_quarters);
+    const TeamRowTables t = team_rows_tables((int)n, (int)s, (int)nnz, dc, dv, c2r, members, rp);
     degrees[0] = dc; degrees[1] = dv;
-    *vt_words = t.vt;
-    *lds_rows = t.R;
+    shape[0] = t.vt; shape[1] = t.R; shape[2] = rp.static_c; shape[3] = rp.static_v; shape[4] = rp.regs_per_wave;
     std::memcpy(vtab, t.vtab.data(), t.vtab.size() * sizeof(int));
     std::memcpy(ctab, t.ctab.data(), t.ctab.size() * sizeof(int));
     std::memcpy(lds_edge, t.lds_edge.data(), t.lds_edge.size() * sizeof(int));
+    std::memcpy(reg_edge, t.reg_edge.data(), t.reg_edge.size() * sizeof(int));
     return LDPC_OK;
 }
 
 static ldpc_status team_rows_build(ldpc_bp_decoder *d, int G)
 {
     if (d->rows_G == G) return LDPC_OK;
-    const TeamRowTables t = team_rows_tables((int)d->n, (int)d->s, (int)d->nnz, d->rows_dc, d->rows_dv, d->h_csc2csr, G);
-    const std::vector<int> &vtab = t.vtab, &ctab = t.ctab, &lds_edge = t.lds_edge;
-    const int R = t.R;
-    auto up = [&](DevBuf &b, const void *src, size_t bytes) -> ldpc_status {
-        ldpc_status r = b.ensure(std::max<size_t>(bytes, 4));
+    // (three quarters of a member's share dealt statically measured 1 % faster than dealing all but the first chunk from
+    // the counter -- 873 against 883 ms on the full C3 batch --; rows in registers need it)
+    const TeamRegPlan rp = team_reg_plan((int)d->n, (int)d->s, G, kExperimentsBuild ? d->team_regs : 0, d->team_static_quarters);
+    const TeamRowTables t = team_rows_tables((int)d->n, (int)d->s, (int)d->nnz, d->rows_dc, d->rows_dv, d->h_csc2csr, G, rp);
+    auto up = [&](DevBuf &b, const std::vector<int> &v) -> ldpc_status {
+        ldpc_status r = b.ensure(std::max<size_t>(v.size() * 4, 4));
         if (r != LDPC_OK) return r;
-        if (hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return fail(LDPC_ERR_HIP, "hipMemcpy of the team row tables failed"); }
+        if (hipMemcpy(b.p, v.data(), v.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return fail(LDPC_ERR_HIP, "hipMemcpy of the team row tables failed"); }
         return LDPC_OK;
     };
     ldpc_status st;
     (void)hipDeviceSynchronize();   // (a launch that still reads the tables of another G)
-    if ((st = up(d->rows_ctab, ctab.data(), ctab.size() * 4)) != LDPC_OK || (st = up(d->rows_vtab, vtab.data(), vtab.size() * 4)) != LDPC_OK ||
-        (st = up(d->rows_lds_edge, lds_edge.data(), lds_edge.size() * 4)) != LDPC_OK)
+    if ((st = up(d->rows_ctab, t.ctab)) != LDPC_OK || (st = up(d->rows_vtab, t.vtab)) != LDPC_OK ||
+        (st = up(d->rows_lds_edge, t.lds_edge)) != LDPC_OK || (st = up(d->rows_reg_edge, t.reg_edge)) != LDPC_OK)
         return st;
-    d->rows_G = G; d->rows_R = R;
+    d->rows_G = G; d->rows_R = t.R;
+    d->rows_regs = rp.regs_per_wave; d->rows_static_c = rp.static_c; d->rows_static_v = rp.static_v;
     if (exp_env("LDPC_TEAM_DEBUG"))
-        std::fprintf(stderr, "[ldpc] team rows: %d members, %d LDS rows each at most, %zu of %d edges in LDS\n", G, R, t.in_lds, (int)d->nnz);
+        std::fprintf(stderr, "[ldpc] team rows: %d members, %d LDS rows each at most, %zu of %d edges in LDS, %zu in registers (%d per wave at most; static chunks %d / %d)\n",
+                     G, t.R, t.in_lds, (int)d->nnz, t.in_regs, rp.regs_per_wave, rp.static_c, rp.static_v);
     return LDPC_OK;
 }
 
@@ -1694,7 +1777,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         const int *t_col = a_col, *t_c2r = a_c2r;
         if (plan.rows && team_rows_build(d, team) == LDPC_OK) {   // (also with LDPC_TEAM_SCATTER: members over all XCDs, a test)
             // rows that only one member touches live in its LDS (TeamRows)
-            team_kernel_t tkr = pick_team_kernel_rows(d->rows_dc, d->rows_dv, want_llr);
+            team_kernel_t tkr = pick_team_kernel_rows(d->rows_dc, d->rows_dv, want_llr, kExperimentsBuild && d->rows_regs > 0);
             const size_t need = (size_t)d->rows_R * kTile * sizeof(double);
             int occ_rows = 0;
             if (tkr && d->prepare_kernel((const void *)tkr, LDPC_TEAM_THREADS, need, &occ_rows) == LDPC_OK && occ_rows >= 1) {
@@ -1702,6 +1785,9 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
                 d->last_lds_rows = d->rows_R;
                 tp.rows.lds_edge = (const int *)d->rows_lds_edge.p;
                 tp.rows.R = d->rows_R;
+                tp.rows.reg_edge = (const int *)d->rows_reg_edge.p;
+                tp.rows.regs = d->rows_regs;
+                tp.rows.static_c = d->rows_static_c; tp.rows.static_v = d->rows_static_v;
                 t_col = (const int *)d->rows_ctab.p;     // (this instantiation reads its tables through these two arguments)
                 t_c2r = (const int *)d->rows_vtab.p;
             }

@@ -33,18 +33,27 @@ team_kernel_t team_pick_dc(int dc, int dv)
 // tiles.  nullptr: no instantiation for this pair.
 namespace {
 template <int DC, int DV>
-team_kernel_t rows_pick(bool llr)
+team_kernel_t rows_pick(bool llr, bool regs)
 {
     static_assert(team_rows_degrees_ok(DC, DV), "keep team_rows_degrees_ok() and the instantiations in step");
+#ifdef LDPC_EXPERIMENTS   // rows in the waves' top registers measured slower than LDS alone: experiments build only
+    if (regs) {
+        if (llr) return bp_team_kernel<DC, DV, true, LDPC_TEAM_THREADS, false, true, kTeamRegRows>;
+        return bp_team_kernel<DC, DV, false, LDPC_TEAM_THREADS, false, true, kTeamRegRows>;
+    }
+#else
+    (void)regs;
+#endif
     if (llr) return bp_team_kernel<DC, DV, true, LDPC_TEAM_THREADS, false, true>;
     return bp_team_kernel<DC, DV, false, LDPC_TEAM_THREADS, false, true>;
 }
 }  // namespace
-team_kernel_t pick_team_kernel_rows(int dc, int dv, bool llr)
+// regs: the instantiation whose waves also keep rows in registers (TeamRows::regs > 0)
+team_kernel_t pick_team_kernel_rows(int dc, int dv, bool llr, bool regs)
 {
-    if (dc == 8 && dv == 4) return rows_pick<8, 4>(llr);
-    if (dc == 6 && dv == 3) return rows_pick<6, 3>(llr);
-    if (dc == 10 && dv == 5) return rows_pick<10, 5>(llr);
+    if (dc == 8 && dv == 4) return rows_pick<8, 4>(llr, regs);
+    if (dc == 6 && dv == 3) return rows_pick<6, 3>(llr, regs);
+    if (dc == 10 && dv == 5) return rows_pick<10, 5>(llr, regs);
     return nullptr;
 }
 #elif LDPC_TEAM_RESUMED

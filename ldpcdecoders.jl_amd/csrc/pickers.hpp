@@ -20,6 +20,6 @@ bp_kernel_t pick_kernel(int dc, int dv, bool llr, int threads, bool second = fal
 lds_kernel_t pick_lds_kernel(int dc, int dv, bool llr, int threads);                   // pick_lds.hip
 node_kernel_t pick_node_kernel(int dc, int dv, bool llr, int threads, int msg);   // pick_node.hip; msg: bp_node_kernels.hpp
 team_kernel_t pick_team_kernel(int dc, int dv, bool llr, bool resumed = false);        // pick_team.hip
-team_kernel_t pick_team_kernel_rows(int dc, int dv, bool llr);   // pick_team.hip: regular graphs of these exact degrees, rows in LDS (nullptr: none)
+team_kernel_t pick_team_kernel_rows(int dc, int dv, bool llr, bool regs);   // pick_team.hip: regular graphs of these exact degrees, rows in LDS (nullptr: none)
 
 }  // namespace ldpc

@@ -153,6 +153,41 @@ def test_c_host_multi_device_entries_equal_the_single_device_entry(tmp_path, gpu
     assert out.returncode == 0 and "multi ok" in out.stdout, (out.returncode, out.stdout, out.stderr)
 
 
+def _kernel_metadata(lib_path, tmp_path, tag):
+    """{kernel symbol: {vgpr_count, agpr_count, private_segment_fixed_size}} and the unbundled code objects of a library."""
+    import subprocess
+
+    llvm = "/opt/rocm/lib/llvm/bin"
+    fat = str(tmp_path / f"{tag}_fat.bin")
+    subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib_path, fat])
+    blob = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+    assert starts, "no offload bundle in .hip_fatbin"
+    notes, cos = "", []
+    for k, a in enumerate(starts):   # one bundle per translation unit (pick_*.hip, ...)
+        part, co = str(tmp_path / f"{tag}_bundle{k}.bin"), str(tmp_path / f"{tag}_dev{k}.co")
+        open(part, "wb").write(blob[a:starts[k + 1] if k + 1 < len(starts) else len(blob)])
+        subprocess.check_call([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o",
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={part}", f"--output={co}"])
+        notes += subprocess.run([f"{llvm}/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
+        cos.append(co)
+    # one record per kernel in amdhsa.kernels: a YAML list item ("  - .agpr_count: ...") whose keys come in alphabetical order
+    info, rec = {}, None
+    for line in notes.splitlines():
+        if re.match(r"  - \.", line):              # (the items of .args and the like sit deeper)
+            rec = {}
+        m = re.match(r"\s*(?:- )?\.(name|vgpr_count|agpr_count|private_segment_fixed_size):\s+(\S+)", line)
+        if not m or rec is None:
+            continue
+        if m.group(1) == "name":
+            if m.group(2).startswith("_Z"):
+                info[m.group(2)] = rec
+        else:
+            rec[m.group(1)] = int(m.group(2))
+    return info, cos
+
+
 def test_hot_kernels_keep_their_register_budget(tmp_path):
     """Three workgroups of 8 waves per CU need <= 80 VGPRs (512 / 6 waves per SIMD) and no scratch: the
     tile kernel's C3 instantiation and the LDS kernel's C2 instantiation sit right at that edge, and an
@@ -164,31 +199,42 @@ def test_hot_kernels_keep_their_register_budget(tmp_path):
     llvm = "/opt/rocm/lib/llvm/bin"
     if not (shutil.which("objcopy") and os.path.exists(f"{llvm}/clang-offload-bundler") and os.path.exists(f"{llvm}/llvm-readelf")):
         pytest.skip("no code-object tools")
-    fat = str(tmp_path / "fat.bin")
-    subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", ldpc._capi.LIB_PATH, fat])
-    blob = open(fat, "rb").read()
-    magic = b"__CLANG_OFFLOAD_BUNDLE__"
-    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
-    assert starts, "no offload bundle in .hip_fatbin"
-    notes = ""
-    for k, a in enumerate(starts):   # one bundle per translation unit (pick_*.hip, ...)
-        part, co = str(tmp_path / f"bundle{k}.bin"), str(tmp_path / f"dev{k}.co")
-        open(part, "wb").write(blob[a:starts[k + 1] if k + 1 < len(starts) else len(blob)])
-        subprocess.check_call([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o",
-                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={part}", f"--output={co}"])
-        notes += subprocess.run([f"{llvm}/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
-    info, name = {}, None
-    for line in notes.splitlines():
-        m = re.match(r"\s*\.(name|vgpr_count|private_segment_fixed_size):\s+(\S+)", line)
-        if not m:
-            continue
-        if m.group(1) == "name":
-            name = m.group(2)
-            info[name] = {}
-        elif name:
-            info[name][m.group(1)] = int(m.group(2))
+    info, _ = _kernel_metadata(ldpc._capi.LIB_PATH, tmp_path, "prod")
     hot = [k for k in info if k.startswith("_ZN4ldpc14bp_tile_kernelILi8ELi4ELb0ELi512ELb0EEE")
            or k.startswith("_ZN4ldpc13bp_lds_kernelILi8ELi4ELb0ELi512EEE")]
     assert len(hot) == 2, sorted(info)[:5]
     for k in hot:
         assert info[k]["vgpr_count"] <= 80 and info[k]["private_segment_fixed_size"] == 0, (k, info[k])
+    # every rows-on-chip instantiation of the team kernel -- (6,3), (8,4), (10,5), with and without LLRs --: one 8-wave
+    # workgroup per CU (156 KB of LDS), not a byte of scratch memory; the product holds none that keeps rows in registers
+    rows = [k for k in info if re.match(r"_ZN4ldpc14bp_team_kernelILi\d+ELi\d+ELb[01]ELi512ELb0ELb1ELi0EEE", k)]
+    assert len(rows) == 6, [k for k in info if "bp_team_kernel" in k][:8]
+    for k in rows:
+        assert info[k]["private_segment_fixed_size"] == 0 and info[k]["vgpr_count"] <= 256, (k, info[k])
+    assert not [k for k in info if re.match(r"_ZN4ldpc14bp_team_kernelILi\d+ELi\d+ELb[01]ELi512ELb0ELb1ELi32EEE", k)]
+    # the EXPERIMENTS build also has the instantiations that keep rows in the top 64 registers of every wave
+    # (bp_team_kernels.hpp "Rows in REGISTERS"): 256 registers a lane, no accumulator registers (the allocator would park
+    # values of its own in them), no scratch, and nothing but the two accessors (v_mov_b32 from / to v192 | v193 under
+    # s_set_gpr_idx_on) may touch v192 and up
+    xinfo, cos = _kernel_metadata(ldpc._capi.EXP_LIB_PATH, tmp_path, "exp")
+    regs = [k for k in xinfo if re.match(r"_ZN4ldpc14bp_team_kernelILi\d+ELi\d+ELb[01]ELi512ELb0ELb1ELi32EEE", k)]
+    assert len(regs) == 6
+    for k in regs:
+        assert xinfo[k]["private_segment_fixed_size"] == 0 and xinfo[k]["agpr_count"] == 0 and xinfo[k]["vgpr_count"] == 256, (k, xinfo[k])
+    top = re.compile(r"\bv(19[2-9]|2[0-4]\d|25[0-5])\b|\bv\[\d+:(19[2-9]|2[0-4]\d|25[0-5])\]")
+    ok_form = re.compile(r"^\s*v_mov_b32_e32 (v\d+, v19[23]|v19[23], v\d+)\b")
+    checked = 0
+    for co in cos:
+        dis = subprocess.run([f"{llvm}/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout
+        if "ELb0ELb1ELi32EEE" not in dis:
+            continue
+        cur = None
+        for line in dis.splitlines():
+            m = re.match(r"[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                cur = m.group(1)
+                continue
+            if cur in regs and top.search(line.split("//")[0]):
+                assert ok_form.match(line), (cur, line)
+                checked += 1
+    assert checked > 100, checked

@@ -113,20 +113,90 @@ def test_bb72_and_irregular_graphs(ldpc, gpu):
         assert_same_as_oracle(ldpc, H, 0.03, 30, 4, 1.5, syn)
 
 
-def test_max_iters_zero_and_unsupported(ldpc, gpu):
+def test_max_iters_zero(ldpc, gpu):
     H = cycle_matrix(8)
     err, conv, its = ldpc.BPOTSDecoder(H, 0.01, 0).decode_batch_host(np.zeros((3, 8), dtype=np.uint8))
     assert not err.any() and not conv.any() and not its.any()
-    # the size limit of the BP-OTS kernels: s + 3n bytes of decisions and 4s bytes of parities in one CU's LDS
-    # (the reference's BPOTSDecoder has no limit; README / INTEGRATION state ours)
+
+
+def test_no_size_or_degree_limit(ldpc, gpu):
+    """The reference's BPOTSDecoder takes any H (bpots_decoder.jl:225-340); round 2 returned LDPC_ERR_UNSUPPORTED
+    beyond n ~ 30,000 and for check degree > 32 / bit degree > 16.  Those graphs now take bpots_big_kernel (everything
+    of a syndrome in a global slot, nodes of any degree; ldpc_bpots_kernel = 5): a (4,8)-regular n = 65536 code, a
+    graph with a check of degree 40 and a bit of degree 20, and one with a few heavy nodes among light ones -- estimates,
+    flags and iteration counts equal the oracle's."""
     huge = ldpc.codes.parity_check_csc(65536, 8, 4)
-    with pytest.raises(ldpc.LdpcError) as ei:
-        ldpc.BPOTSDecoder(huge, 0.01, 10)
-    assert ei.value.status == 5 and "LDS" in ei.value.message
-    wide = sp.csc_matrix(np.ones((2, 40), dtype=np.uint8))          # check degree 40 > 32
-    with pytest.raises(ldpc.LdpcError) as ei:
-        ldpc.BPOTSDecoder(wide, 0.01, 10)
-    assert ei.value.status == 5
+    syn = ldpc.codes.syndromes_of(huge, ldpc.codes.random_errors(65536, 6, 0.02, seed=4))
+    err, conv, its = assert_same_as_oracle(ldpc, huge, 0.02, 12, 9, 2.0, syn, kernel=5)
+    assert conv.all()
+    rng = np.random.default_rng(21)
+    wide = np.zeros((24, 60), dtype=np.uint8)
+    wide[0, :40] = 1                                               # check degree 40 > 32
+    wide[:20, 59] = 1                                              # bit degree 20 > 16
+    wide |= (rng.random((24, 60)) < 0.08).astype(np.uint8)
+    S = rng.integers(0, 2, (200, 24)).astype(np.uint8)
+    S[5, 3] = 3
+    assert_same_as_oracle(ldpc, wide, 0.04, 40, 5, 2.0, S, kernel=5)
+    E = (rng.random((150, 60)) < 0.05).astype(np.uint8)
+    assert_same_as_oracle(ldpc, wide, 0.05, 30, 9, 1.5, (E.astype(int) @ wide.T.astype(int) % 2).astype(np.uint8), kernel=5)
+
+
+def test_unlimited_kernel_equals_the_other_two_on_small_graphs(ldpc, gpu, monkeypatch):
+    """LDPC_BPOTS_FORCE_NODE=2 sends everything through bpots_big_kernel: the graphs of the reference's BP-OTS tests and
+    the n = 8190 code against the oracle (and thereby against the LDS-resident and the node-parallel kernel)."""
+    monkeypatch.setenv("LDPC_BPOTS_FORCE_NODE", "2")
+    rng = np.random.default_rng(13)
+    for n in (4, 8, 16):
+        H = cycle_matrix(n)
+        S = (rng.integers(0, 2, (90, n)).astype(int) @ H.T.astype(int) % 2).astype(np.uint8)
+        assert_same_as_oracle(ldpc, H, 0.01, 100, 3, 1.0, S, kernel=5)
+    H = toric_x(3)
+    E = rng.integers(0, 2, (300, 18)).astype(np.uint8)
+    assert_same_as_oracle(ldpc, H, 0.05, 50, 9, 3.0, (E.astype(int) @ H.T.astype(int) % 2).astype(np.uint8), kernel=5)
+    HX, _ = ldpc.codes.bivariate_bicycle_72_12_6()
+    assert_same_as_oracle(ldpc, HX, 0.05, 40, 5, 2.0, ldpc.codes.syndromes_of(HX, ldpc.codes.random_errors(72, 500, 0.05, seed=2)), kernel=5)
+    H = ldpc.codes.parity_check_csc(8190, 6, 3)
+    syn = ldpc.codes.syndromes_of(H, ldpc.codes.random_errors(8190, 40, 0.07, seed=8))
+    assert_same_as_oracle(ldpc, H, 0.07, 30, 9, 2.0, syn, kernel=5)
+
+
+def test_gpu_against_the_independent_libm_oracle_stays_inside_the_band(ldpc, gpu):
+    """GPU == oracle above is by construction on tanh / atanh (kernel and oracle share portable_math.h).  The INDEPENDENT
+    witness is oracle/libbpots_oracle_libm.so (the host's libm; shares nothing with the product):
+    tests/test_bpots_oracle.py pins how often two libms that are each good to an ulp reach different -- equally valid --
+    estimates.  The GPU must live in the same band against it, and satisfy the reference's own assertions
+    (test/test_bpots.jl: the estimate reproduces the syndrome) as often as the libm build does."""
+    def band(H, per, iters, T, C, S):
+        M = sp.csc_matrix(H)
+        M.sort_indices()
+        dec = ldpc.BPOTSDecoder(M, per, iters, T=T, C=C)
+        ga, _, _ = dec.decode_batch_host(S)
+        dec.close()
+        ob, _, _ = BPOTSOracle((M.indptr, M.indices), M.shape, per, iters, T, C, libm=True).batchdecode(S)
+        Hd = np.asarray(M.todense()).astype(int)
+        ok = lambda e: float(np.all((e.astype(int) @ Hd.T % 2) == (S & 1), axis=1).mean())
+        return float((ga != ob).any(axis=1).mean()), ok(ga), ok(ob)
+
+    rng = np.random.default_rng(3)
+    for n, limit in ((4, 0.0), (8, 0.05), (16, 0.15)):
+        H = cycle_matrix(n)
+        for T, C in ((3, 1.0), (9, 3.0)):
+            S = (rng.integers(0, 2, (300, n)).astype(int) @ H.T.astype(int) % 2).astype(np.uint8)
+            d, oa, ob = band(H, 0.01, 100, T, C, S)
+            assert d <= limit and abs(oa - ob) <= 0.03, (n, T, C, d, oa, ob)
+    H = toric_x(3)
+    E = rng.integers(0, 2, (1000, 18)).astype(np.uint8)
+    S = (E.astype(int) @ H.T.astype(int) % 2).astype(np.uint8)
+    d, oa, ob = band(H, 0.05, 50, 9, 3.0, S)
+    assert d <= 0.30 and oa >= 0.85 and ob >= 0.85 and abs(oa - ob) <= 0.02, (d, oa, ob)
+    H = ldpc.codes.parity_check_csc(504, 6, 3)
+    S = ldpc.codes.syndromes_of(H, ldpc.codes.random_errors(504, 150, 0.09, seed=2))
+    d, oa, ob = band(H, 0.09, 60, 9, 2.0, S)
+    assert d <= 0.02 and abs(oa - ob) <= 0.02, (d, oa, ob)
+    HX, _ = ldpc.codes.bivariate_bicycle_72_12_6()
+    S = ldpc.codes.syndromes_of(HX, ldpc.codes.random_errors(72, 1500, 0.04, seed=3))
+    d, oa, ob = band(HX, 0.04, 50, 9, 2.0, S)
+    assert d <= 0.01 and oa >= 0.99 and ob >= 0.99, (d, oa, ob)
 
 
 def test_graphs_beyond_the_lds_take_the_node_kernel(ldpc, gpu):

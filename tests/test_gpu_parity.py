@@ -240,6 +240,7 @@ def test_team_kernel_is_bit_identical_to_the_tile_kernel(ldpc, gpu, B, per, scat
 def test_team_rows_in_lds_change_nothing(ldpc, gpu, per, monkeypatch):
     """(4,8)-regular graphs: the members of a persistent team keep the message rows that only they touch in LDS (a bit is
     dealt to a member that owns one of its checks; bp_team_kernels.hpp TeamRows).  With the rows in LDS (default), with
+    with rows in the waves' registers as well (up to 32 or 7 a wave; bp_team_kernels.hpp "Rows in REGISTERS") or not, with
     every row in the slot (LDPC_TEAM_ROWS=0) and through the tile kernel: the same bits, LLRs included -- at an error
     rate where tiles finish early, one where they hand stragglers on (the rows in LDS are written back for that) and
     one where nothing converges."""
@@ -249,8 +250,9 @@ def test_team_rows_in_lds_change_nothing(ldpc, gpu, per, monkeypatch):
     H = ldpc.codes.parity_check_csc(n, 8, 4)
     syn = torch.from_numpy(ldpc.codes.syndromes_of(H, ldpc.codes.random_errors(n, B, per, seed=77))).cuda()
     res = []
-    for variant, rows in ((4, "1"), (4, "0"), (1, "1")):
+    for variant, rows, regs in ((4, "1", "32"), (4, "1", "0"), (4, "1", "7"), (4, "0", "32"), (1, "1", "32")):
         monkeypatch.setenv("LDPC_TEAM_ROWS", rows)
+        monkeypatch.setenv("LDPC_TEAM_REGS", regs)          # rows in the waves' accumulator registers on top (0 = LDS only)
         dec = ldpc.BeliefPropagationDecoder(H, per, 30, kernel_variant=variant)
         err = torch.empty((B, n), dtype=torch.uint8, device="cuda")
         conv = torch.empty(B, dtype=torch.uint8, device="cuda")

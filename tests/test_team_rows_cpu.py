@@ -13,31 +13,40 @@ import ldpcdecoders_jl_amd as ldpc
 RMAX = 312
 
 
-def tables(n, members, wr=8, wc=4):
+W = 8            # waves per member
+RREGS = 32       # register rows a wave may hold (bp_team_kernels.hpp kTeamRegRows)
+
+
+def tables(n, members, wr=8, wc=4, regs=0, quarters=3):
     H = ldpc.codes.parity_check_csc(n, wr, wc)
     s = H.shape[0]
     colptr = np.ascontiguousarray(H.indptr, dtype=np.int64)
     rowval = np.ascontiguousarray(H.indices, dtype=np.int64)
-    R, vt = ctypes.c_int32(), ctypes.c_int32()
     deg = (ctypes.c_int32 * 2)()
+    shape = (ctypes.c_int32 * 5)()
     vtab = np.zeros((n, 16), dtype=np.int32)
-    ctab = np.zeros((s, 2), dtype=np.int32)
+    ctab = np.zeros((s, 4), dtype=np.int32)
     lds_edge = np.full(members * RMAX, -7, dtype=np.int32)
-    st = ldpc._capi.lib().ldpc_debug_team_rows(s, n, colptr.ctypes.data, rowval.ctypes.data, members, ctypes.byref(deg),
-                                               ctypes.byref(vt), ctypes.byref(R), vtab.ctypes.data, ctab.ctypes.data,
-                                               lds_edge.ctypes.data)
+    reg_edge = np.full(members * W * RREGS, -7, dtype=np.int32)
+    st = ldpc._capi.lib().ldpc_debug_team_rows(s, n, colptr.ctypes.data, rowval.ctypes.data, members, regs, quarters,
+                                               ctypes.byref(deg), ctypes.byref(shape), vtab.ctypes.data, ctab.ctypes.data,
+                                               lds_edge.ctypes.data, reg_edge.ctypes.data)
     ldpc._capi.check(st)
-    assert list(deg) == [wr, wc] and vt.value == (8 if 2 * wc + 1 <= 8 else 16)
-    vtab = vtab.reshape(-1)[: n * vt.value].reshape(n, vt.value)
-    return H, R.value, vtab, ctab, lds_edge[: members * R.value].reshape(members, R.value)
+    vt, R, static_c, static_v, regs_eff = list(shape)
+    assert list(deg) == [wr, wc] and vt == (8 if 2 * wc + 1 <= 8 else 16)
+    vtab = vtab.reshape(-1)[: n * vt].reshape(n, vt)
+    reg_edge = reg_edge[: members * W * max(regs_eff, 1)].reshape(members, W, max(regs_eff, 1))
+    return H, R, vtab, ctab, lds_edge[: members * R].reshape(members, R), reg_edge, (static_c, static_v, regs_eff)
 
 
-@pytest.mark.parametrize("n,members,wr,wc", [(4096, 8, 8, 4), (16384, 32, 8, 4), (16384, 28, 8, 4), (1024, 3, 8, 4), (32768, 32, 8, 4),
-                                             (16380, 32, 6, 3), (1008, 5, 6, 3), (16000, 32, 10, 5), (4000, 7, 10, 5)])
-def test_row_tables_describe_the_graph(n, members, wr, wc):
-    H, R, vtab, ctab, lds_edge = tables(n, members, wr, wc)
+@pytest.mark.parametrize("n,members,wr,wc,regs", [(4096, 8, 8, 4, 0), (16384, 32, 8, 4, 0), (16384, 32, 8, 4, 32), (16384, 28, 8, 4, 32), (1024, 3, 8, 4, 32),
+                                                  (32768, 32, 8, 4, 32), (16380, 32, 6, 3, 32), (1008, 5, 6, 3, 0), (16000, 32, 10, 5, 32),
+                                                  (4000, 7, 10, 5, 20)])
+def test_row_tables_describe_the_graph(n, members, wr, wc, regs):
+    H, R, vtab, ctab, lds_edge, reg_edge, (static_c, static_v, regs_eff) = tables(n, members, wr, wc, regs)
     s, nnz = H.shape[0], H.nnz
-    assert 1 <= R <= RMAX
+    assert 1 <= R <= RMAX and regs_eff in (0, regs)
+    assert static_c % W == 0 and static_v % W == 0 and W <= static_c <= (s // 2) // members and W <= static_v <= (n // 4) // members
     # CSR row of every CSC edge, as ldpc_bp_create lays the rows out: wr * check + place among the check's bits
     csr = H.tocsr()
     csr.sort_indices()
@@ -50,50 +59,74 @@ def test_row_tables_describe_the_graph(n, members, wr, wc):
     flagged = vtab[:, 2 * wc] < 0
     member_of_pos = (np.arange(n) // 4) % members                  # how the kernel deals positions: chunks of 4
     member_of_check = (np.arange(s) // 2) % members                # ... and checks: chunks of 2
-    seen_slots = set()
-    in_lds = 0
+
+    def wave_of(chunk, static):                                    # the wave that owns a chunk by right, or -1 (dealt from the counter)
+        l = chunk // members
+        return l % W if l < static else -1
+
+    seen_slots, seen_regs = set(), set()
+    in_lds = in_regs = 0
     for p in range(n):
         j = int(bits[p])
         rows = [place[(int(i), j)] for i in H.indices[H.indptr[j]:H.indptr[j + 1]]]
         assert list(vtab[p, 0:wc]) == rows, "a position must carry the message rows of its bit, checks ascending"
-        lrows = vtab[p, wc:2 * wc]
-        assert bool(flagged[p]) == bool((lrows >= 0).any())
-        for q, lr in zip(rows, lrows):
-            if lr < 0:
+        where = vtab[p, wc:2 * wc]
+        assert bool(flagged[p]) == bool((where != -1).any())
+        m = int(member_of_pos[p])
+        for q, lr in zip(rows, where):
+            if lr == -1:
                 continue
-            in_lds += 1
-            m = int(member_of_pos[p])
-            assert member_of_check[q // wr] == m, "a row in LDS must belong to ONE member in both sweeps"
-            assert 0 <= lr < R and (m, int(lr)) not in seen_slots
-            seen_slots.add((m, int(lr)))
-            assert lds_edge[m, lr] == q, "the member's write-back list must name the same row"
+            assert member_of_check[q // wr] == m, "a row on chip must belong to ONE member in both sweeps"
+            if lr >= 0:
+                in_lds += 1
+                assert lr < R and (m, int(lr)) not in seen_slots
+                seen_slots.add((m, int(lr)))
+                assert lds_edge[m, lr] == q, "the member's write-back list must name the same row"
+            else:
+                in_regs += 1
+                x = -2 - int(lr)
+                w = wave_of(p // 4, static_v)
+                assert regs_eff > 0 and 0 <= x < regs_eff and w >= 0, "a register row needs a position that a wave owns by right"
+                assert wave_of((q // wr) // 2, static_c) == w, "... and a check that the SAME wave owns by right"
+                assert (m, w, x) not in seen_regs
+                seen_regs.add((m, w, x))
+                assert reg_edge[m, w, x] == q, "the wave's write-back list must name the same row"
     assert in_lds == int((lds_edge >= 0).sum()) and np.all(lds_edge[lds_edge < 0] == -1)
-    # per check: mask = its edges in LDS, base = LDS row of the first, the others follow
+    assert in_regs == int((reg_edge >= 0).sum()) and np.all(reg_edge[reg_edge < 0] == -1)
+    # per check: masks = its edges in LDS / in registers, bases = the first row of either kind, the others follow
     for i in range(s):
-        mask, base = int(ctab[i, 0]) & 0xFFFFFFFF, int(ctab[i, 1])
+        mask, base, rmask, rbase = int(ctab[i, 0]) & 0xFFFFFFFF, int(ctab[i, 1]), int(ctab[i, 2]) & 0xFFFFFFFF, int(ctab[i, 3])
         m = int(member_of_check[i])
         want = [k for k in range(wr) if (lds_edge[m] == wr * i + k).any()]
         assert [k for k in range(32) if (mask >> k) & 1] == want
         for t, k in enumerate(want):
             assert lds_edge[m, base + t] == wr * i + k
-    # what it is for: one edge per bit (1 / wc of the edges) is a candidate, the LDS holds up to 312 rows per member
-    assert in_lds >= min(0.6 / wc * nnz, 0.9 * RMAX * members) * 0.9
+        w = wave_of(i // 2, static_c)
+        want_r = [k for k in range(wr) if w >= 0 and (reg_edge[m, w] == wr * i + k).any()]
+        assert [k for k in range(32) if (rmask >> k) & 1] == want_r and not (mask & rmask)
+        for t, k in enumerate(want_r):
+            assert reg_edge[m, w, rbase + t] == wr * i + k
+    # what it is for: one edge per bit (1 / wc of the edges) is a candidate, the LDS holds up to 312 rows per member,
+    # the registers of its eight waves up to 8 x 32 more
+    assert in_lds + in_regs >= min(0.6 / wc * nnz, 0.9 * (RMAX + W * regs_eff) * members) * 0.9
     per_member = (lds_edge >= 0).sum(axis=1)
-    assert per_member.max() == R and per_member.min() >= 0.8 * min(R, nnz // wc // members * 0.9)
+    assert per_member.max() == R
+    if regs_eff and nnz // wc // members >= 400:
+        assert in_regs >= 0.5 * regs_eff * W * members, "most register rows should be in use on a graph of this size"
 
 
 def test_only_regular_graphs_with_an_instantiation():
     buf = np.zeros(1 << 20, dtype=np.int32)
-    R, vt, deg = ctypes.c_int32(), ctypes.c_int32(), (ctypes.c_int32 * 2)()
+    shape, deg = (ctypes.c_int32 * 5)(), (ctypes.c_int32 * 2)()
 
     def status(H):
         H = H.tocsc()
         H.sort_indices()
         colptr = np.ascontiguousarray(H.indptr, dtype=np.int64)
         rowval = np.ascontiguousarray(H.indices, dtype=np.int64)
-        return ldpc._capi.lib().ldpc_debug_team_rows(H.shape[0], H.shape[1], colptr.ctypes.data, rowval.ctypes.data, 8,
-                                                     ctypes.byref(deg), ctypes.byref(vt), ctypes.byref(R), buf.ctypes.data,
-                                                     buf.ctypes.data, buf.ctypes.data)
+        return ldpc._capi.lib().ldpc_debug_team_rows(H.shape[0], H.shape[1], colptr.ctypes.data, rowval.ctypes.data, 8, 32, 3,
+                                                     ctypes.byref(deg), ctypes.byref(shape), buf.ctypes.data,
+                                                     buf.ctypes.data, buf.ctypes.data, buf.ctypes.data)
 
     assert status(ldpc.codes.parity_check_csc(1008, 6, 3)) == 0
     assert status(ldpc.codes.parity_check_csc(1000, 10, 9)) == 5      # LDPC_ERR_UNSUPPORTED: no (10,9) instantiation

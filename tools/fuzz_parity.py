@@ -20,11 +20,17 @@ rng = np.random.default_rng(seed)
 t0, cases, decoded = time.time(), 0, 0
 last_note = t0
 while time.time() - t0 < budget:
-    kind = rng.integers(0, 4)
+    kind = rng.integers(0, 5)
+    mid = False
     if kind == 0:      # Gallager regular
         wr, wc = int(rng.choice([4, 6, 8, 10])), int(rng.choice([2, 3, 4, 5]))
         n = wr * int(rng.integers(4, 60))
         H = ldpc.codes.parity_check_csc(n, wr, wc, seed=int(rng.integers(1 << 30)))
+    elif kind == 4:    # regular with a rows-on-chip instantiation, large enough for the waves of a small team to own chunks
+        wr, wc = [(6, 3), (8, 4), (10, 5)][int(rng.integers(0, 3))]
+        n = wr * int(rng.integers(150, 500))
+        H = ldpc.codes.parity_check_csc(n, wr, wc, seed=int(rng.integers(1 << 30)))
+        mid = True
     else:              # irregular random, with empty and heavy nodes now and then
         s, n = int(rng.integers(1, 80)), int(rng.integers(1, 160))
         A = (rng.random((s, n)) < rng.uniform(0.02, 0.25)).astype(np.uint8)
@@ -42,6 +48,9 @@ while time.time() - t0 < budget:
     per = float(rng.choice([1e-6, 0.005, 0.02, 0.05, 0.1, 0.3, 0.5, 0.9]))
     iters = int(rng.choice([1, 2, 3, 7, 20, 50]))
     B = int(rng.choice([1, 2, 63, 64, 65, 130, 400, 1500, 5000]))
+    if mid:
+        B = int(rng.choice([64, 130, 400, 700]))
+        iters = int(rng.choice([3, 7, 20]))
     if rng.random() < 0.5:
         E = (rng.random((B, n)) < min(per * rng.uniform(0.5, 3), 0.5)).astype(np.uint8)
         syn = ldpc.codes.syndromes_of(H, E)
@@ -66,8 +75,19 @@ while time.time() - t0 < budget:
         # hand-off levels (read at create): thresholds of fresh / level-1 tiles, tiny level capacities (levels fill
         # up and tiles must carry on), how many stragglers the node kernel finishes
         for k in ("LDPC_DEFER_T0", "LDPC_DEFER_T1", "LDPC_DEFER_CAP_TILES", "LDPC_NODE_TAKE_MAX", "LDPC_TEAM_CACHE_KIB",
-                  "LDPC_TEAM_DYNAMIC", "LDPC_TEAM_PAIRS", "LDPC_TEAM_ROWS"):
+                  "LDPC_TEAM_DYNAMIC", "LDPC_TEAM_PAIRS", "LDPC_TEAM_ROWS", "LDPC_TEAM_AHEAD", "LDPC_TEAM_REGS", "LDPC_TEAM_STATIC",
+                  "LDPC_TEAM_MAX"):
             os.environ.pop(k, None)
+        # running ahead (two team barriers an iteration on quiet tiles), rows in the waves' accumulator registers and how
+        # much of a member's share its waves own by right; few members on the mid-size graphs so that every wave owns chunks
+        if rng.random() < 0.7:
+            os.environ["LDPC_TEAM_AHEAD"] = str(int(rng.choice([0, 1, 20, 32, 64])))
+        if rng.random() < 0.5:
+            os.environ["LDPC_TEAM_REGS"] = str(int(rng.choice([0, 5, 32])))
+        if rng.random() < 0.5:
+            os.environ["LDPC_TEAM_STATIC"] = str(int(rng.choice([1, 2, 3, 4])))
+        if mid:
+            os.environ["LDPC_TEAM_MAX"] = str(int(rng.choice([3, 4, 6, 8])))
         # teams (read at create): a small cache budget makes them persistent on these small graphs (a team takes tile
         # after tile in its own slot); how a member's waves share its chunks; nodes loaded in pairs or singly
         if rng.random() < 0.6:
@@ -77,7 +97,7 @@ while time.time() - t0 < budget:
         if rng.random() < 0.5:
             os.environ["LDPC_TEAM_PAIRS"] = str(int(rng.integers(0, 2)))
         if rng.random() < 0.3:
-            os.environ["LDPC_TEAM_ROWS"] = "0"      # (8,4)-regular graphs: no rows in LDS
+            os.environ["LDPC_TEAM_ROWS"] = "0"      # regular graphs: no rows in LDS / registers
         if rng.random() < 0.7:
             os.environ["LDPC_DEFER_T0"] = str(int(rng.choice([4, 16, 32, 48])))
             os.environ["LDPC_DEFER_T1"] = str(int(rng.choice([0, 8, 16, 40])))
@@ -103,13 +123,13 @@ while time.time() - t0 < budget:
             sys.exit(1)
         dec.close()
         decoded += B
-    if kind == 1 and H.nnz > 0 and max(np.diff(H.indptr).max(), 0) <= 16 and np.diff(H.tocsr().indptr).max() <= 32:
+    if kind == 1 and H.nnz > 0:      # (any degree: nodes beyond 32 / 16 edges take the unlimited kernel)
         T, C = int(rng.choice([2, 3, 9])), float(rng.choice([1.0, 2.0, 3.0]))
         pp = max(per, 1e-3) if per < 0.9 else 0.3
         oe, ocv, oi = BPOTSOracle((H.indptr, H.indices), H.shape, pp, iters, T, C).batchdecode(syn)
         os.environ.pop("LDPC_BPOTS_FORCE_NODE", None)
-        if rng.random() < 0.5:
-            os.environ["LDPC_BPOTS_FORCE_NODE"] = "1"      # the node-parallel kernel (graphs beyond the LDS) on a small graph
+        if rng.random() < 0.6:      # the node-parallel kernel (graphs beyond the LDS) or the unlimited one on a small graph
+            os.environ["LDPC_BPOTS_FORCE_NODE"] = str(int(rng.integers(1, 3)))
         d2 = ldpc.BPOTSDecoder(H, pp, iters, T=T, C=C)
         e2, c2, i2 = d2.decode_batch_host(syn)
         if not (np.array_equal(e2, oe) and np.array_equal(c2, ocv) and np.array_equal(i2, oi)):
