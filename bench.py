@@ -52,8 +52,10 @@ WORKLOADS = {
     "ref_1000_10_9_hard": (1000, 10, 9, 65536, 0.06, 100),
     # a code whose messages fit a CU's LDS (128 KiB) but whose graph copy does not: node kernel, messages in LDS
     "mid_4096": (4096, 8, 4, 65536, 0.02, 50),
-    # a large code with wider nodes (row weight 10, column weight 5): the 16-wide register bucket
+    # a large code with wider nodes (row weight 10, column weight 5): the 16-wide register bucket; rows on chip <10,5>
     "wide_16000_10_5": (16000, 10, 5, 32768, 0.10, 50),
+    # a (3,6)-regular code of the C3 size (24 MiB a message slot: eight persistent teams; rows on chip <6,3>)
+    "reg36_16380": (16380, 6, 3, 65536, 0.10, 50),
     # BASELINE configs[4]: BB [[72,12,6]] H_X, BP on the GPU + OSD-0 on the host for what BP leaves
     "c5_bb72_bposd": (72, 6, 3, 1048576, 0.005, 50),
 }

@@ -200,11 +200,14 @@ struct TeamParams {
     // 909 -> 882 ms).  The variable sweep after it must not overwrite the decision words the test's verdict still
     // captures from, hence a second set of them (errmask_alt: odd iterations).  A sweep ahead is wasted when the
     // verdict stops every lane, and it delays a straggler hand-off by an iteration (the messages are half an iteration
-    // on); so a team only runs ahead while its tile is QUIET -- the previous verdict stopped no lane -- and at least
-    // ahead_min lanes are active: tiles whose lanes have begun to converge take the three-barrier iteration
-    // (per 0.02, ~3 iterations a tile: running ahead on lane count alone cost 13 %).
+    // on); so a team only runs ahead while its tile is QUIET -- the previous verdict stopped no lane --, at least
+    // ahead_min lanes are active, and the tile is at least two iterations short of where the team's PREVIOUS tile ended
+    // (handed its stragglers on, or finished): tiles whose lanes have begun to converge, or are about to, take the
+    // three-barrier iteration.  (Per 0.02, ~3 iterations a tile: running ahead on lane count alone cost 13 %, on
+    // quietness alone 7 % -- the first verdict that is not quiet is usually the one that hands off.)
     u64 *errmask_alt;           // [ntiles][n] or nullptr (no running ahead: passes over packed levels)
     int ahead_min;              // active lanes from which on a quiet tile's team runs ahead (0 = never)
+    int ahead_from;             // ... and the first iteration whose test may have company (2: a verdict must have been quiet first)
 };
 constexpr unsigned int kTeamRollcallFailed = 0x80000000u;
 
@@ -532,6 +535,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     constexpr bool resumed = RESUMED;                          // (the host sets p.resumed alike)
     const BPCold *const cd = p.cold;
     u64 tk_check = 0, tk_var = 0, tk_rest = 0;   // this wave's own sweep time / everything else (waiting included)
+    int horizon = p.max_iters;                   // the iteration at which this team's previous tile ended (running ahead: TeamParams)
     long long tot_iters = 0;                     // (rank 0, wave 0) iterations of the syndromes this team finished
 
     for (int tile = team; tile < ntiles;) {
@@ -780,7 +784,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
         const u64 t3 = wall_clock64();
         if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd, sh_deal)) return;
         run_test(it, em);
-        if (can_run_ahead && quiet && it < p.max_iters && (int)__popcll(active) >= tp.ahead_min) {
+        if (can_run_ahead && quiet && it >= tp.ahead_from && it + 2 <= horizon && it < p.max_iters && (int)__popcll(active) >= tp.ahead_min) {
             const u64 t3b = wall_clock64();
             check_sweep(false);                                // iteration it + 1; the barrier at the top of the loop closes both
             have_check = true;
@@ -829,6 +833,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
             }
         }
     }
+    horizon = it;
     if (rank == 0 && w == 0) {
         if (((valid & ~deferred) >> lane) & 1ull) {
             const long long ob = resumed ? (long long)cd->index[b0 + lane] : b0 + lane;

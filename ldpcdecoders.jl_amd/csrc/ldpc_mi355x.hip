@@ -375,6 +375,7 @@ struct ldpc_bp_decoder {
     int team_xcds = 0;        // LDPC_TEAM_XCDS: XCDs that host persistent teams, fixed (experiments; 0 = team_fit() chooses)
     int team_dynamic = 1;     // LDPC_TEAM_DYNAMIC: a member's waves take its chunks from a counter in LDS (0: every W-th)
     int team_pairs = 1;       // LDPC_TEAM_PAIRS: two nodes of the full degree are loaded together
+    int team_ahead_from = 2;  // LDPC_TEAM_AHEAD_FROM: first iteration whose test may ride with the next check sweep
     int team_ahead = 32;      // LDPC_TEAM_AHEAD: active lanes from which on a team starts the next check sweep with the convergence
                               // test still under way (two team barriers an iteration instead of three); 0 = never
     // latency mode of the host-pointer entry (tiny batches, a plain decode!): the kernel reads and writes a
@@ -774,6 +775,7 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     if (const char *e = exp_env("LDPC_TEAM_XCDS")) d->team_xcds = std::max(1, std::min(8, std::atoi(e)));
     if (const char *e = exp_env("LDPC_TEAM_PAIRS")) d->team_pairs = std::atoi(e) != 0;
     if (const char *e = exp_env("LDPC_TEAM_AHEAD")) d->team_ahead = std::max(0, std::min(65, std::atoi(e)));
+    if (const char *e = exp_env("LDPC_TEAM_AHEAD_FROM")) d->team_ahead_from = std::max(1, std::atoi(e));
     if (const char *e = exp_env("LDPC_TEAM_REGS")) d->team_regs = std::max(0, std::min(kTeamRegRows, std::atoi(e)));
     if (const char *e = exp_env("LDPC_TEAM_STATIC")) d->team_static_quarters = std::max(0, std::min(4, std::atoi(e)));
     if (const char *e = exp_env("LDPC_TEAM_MAX")) { d->team_max = std::max(1, std::min(kTeamMaxMembers, std::atoi(e))); d->team_max_set = true; }
@@ -1759,6 +1761,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         tp.rollcall_ticks = d->rollcall_ticks;
         tp.errmask_alt = nullptr;
         tp.ahead_min = 0;
+        tp.ahead_from = 2;
         return LDPC_OK;
     };
     bool team_ran = team > 1;
@@ -1772,6 +1775,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         tp.inject_fault = d->inject_fault;   // (tests; the kernel only looks at it in the experiments build)
         tp.errmask_alt = (u64 *)d->errmask.p + std::max<size_t>((size_t)ntiles * n, 1);
         tp.ahead_min = d->team_ahead;
+        tp.ahead_from = d->team_ahead_from;
         team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr);
         size_t team_lds = team_lds_bytes();
         const int *t_col = a_col, *t_c2r = a_c2r;
