@@ -5,5 +5,5 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_${WL} -- python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline > $OUT/prof_${TAG}_${WL}.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_${WL} -- python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --no-also > $OUT/prof_${TAG}_${WL}.log 2>&1
 head -12 $OUT/prof_${TAG}_${WL}/*/*_kernel_stats.csv | cut -c1-60,200-330
