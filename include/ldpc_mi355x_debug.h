@@ -16,7 +16,7 @@ extern "C" {
 /* How a batch of `batch` syndromes of a graph with nnz edges would be dealt to teams of workgroups on an MI355X
    (256 CUs, one team workgroup per CU, members of >= 2048 message rows) under a budget of cache_mib MiB of message
    slots in flight (the library's default: 240).  rows_dv: the bit degree when the graph is regular and has a
-   rows-in-LDS instantiation, else 0.  out = { members per team (1 = no teams: node-parallel or tile kernel),
+   rows-on-chip instantiation, else 0 (with it the plan counts on 312 rows in LDS and 8 x 32 in registers per member).  out = { members per team (1 = no teams: node-parallel or tile kernel),
    teams = message slots in flight, workgroups launched, XCDs that host teams, 1 if the members of a team are dealt
    over all XCDs (<= 4 tiles), 1 if members keep rows in LDS }. */
 ldpc_status ldpc_debug_team_plan(int64_t nnz, int64_t max_iters, int64_t batch, int32_t cache_mib, int32_t rows_dv,

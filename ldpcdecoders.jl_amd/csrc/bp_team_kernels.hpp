@@ -372,17 +372,21 @@ __device__ __forceinline__ double bit_update_mixed(double *Mt, double *L, const 
 
 // ... and with some rows in the wave's registers (rget(row) reads register row `row`, rput(on, row, v) writes it when
 // `on`; row numbers are wave-uniform): rmask = the check's edges that live there, from register row rbase on.  A
-// row that lives in registers is neither loaded from nor stored to memory.  Same arithmetic.
+// row that lives in registers is neither loaded from nor stored to its place in the slot: its pointer is bent to a
+// dummy row of the member's LDS (Ld), so that the loads and stores of the check's other rows need no branches around
+// them and are all in flight together -- with "if (in memory) load" per edge the compiler serialises them, and a
+// check with ONE row in registers (the usual case: a member's on-chip edges are spread over its checks) cost 5 us.
+// Same arithmetic.
 template <int D, bool FIRST, bool TF, class RGet, class RPut>
-__device__ __forceinline__ void check_update_onchip(double *M, double *L, unsigned int mask, unsigned int rmask, int rbase,
+__device__ __forceinline__ void check_update_onchip(double *M, double *L, double *Ld, unsigned int mask, unsigned int rmask, int rbase,
                                                     double sigma, double r, RGet &&rget, RPut &&rput)
 {
     double *ptr[D];
     int nl = 0;
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-        const bool in_lds = (mask >> k) & 1u;
-        ptr[k] = in_lds ? L + (size_t)nl * kTile : M + (size_t)k * kTile;
+        const bool in_lds = (mask >> k) & 1u, in_reg = (rmask >> k) & 1u;
+        ptr[k] = in_reg ? Ld : (in_lds ? L + (size_t)nl * kTile : M + (size_t)k * kTile);
         nl += in_lds ? 1 : 0;
     }
     double a[D], out[D];
@@ -393,10 +397,7 @@ __device__ __forceinline__ void check_update_onchip(double *M, double *L, unsign
     } else {
         double m[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) {                          // the rows in memory first: all their loads in flight
-            m[k] = 0.0;
-            if (!((rmask >> k) & 1u)) m[k] = *ptr[k];
-        }
+        for (int k = 0; k < D; ++k) m[k] = *ptr[k];
 #pragma unroll
         for (int k = 0; k < D; ++k)
             if ((rmask >> k) & 1u) m[k] = rget(rbase + __builtin_popcount(rmask & ((1u << k) - 1u)));
@@ -405,30 +406,25 @@ __device__ __forceinline__ void check_update_onchip(double *M, double *L, unsign
     }
     check_compute_exact<D, TF>(a, sigma, out);
 #pragma unroll
-    for (int k = D - 1; k >= 0; --k) {
-        const bool in_reg = (rmask >> k) & 1u;
-        if (!in_reg) *ptr[k] = out[k];
-        rput(in_reg, rbase + __builtin_popcount(rmask & ((1u << k) - 1u)), out[k]);
-    }
+    for (int k = D - 1; k >= 0; --k) *ptr[k] = out[k];
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) rput((rmask >> k) & 1u, rbase + __builtin_popcount(rmask & ((1u << k) - 1u)), out[k]);
 }
 
 // loc[k]: >= 0 that LDS row, -1 the slot (row pos[k]), <= -2 register row -2 - loc[k] of this wave
 template <int D, bool TF, class RGet, class RPut>
-__device__ __forceinline__ double bit_update_onchip(double *Mt, double *L, const int (&pos)[D], const int (&loc)[D], double r,
+__device__ __forceinline__ double bit_update_onchip(double *Mt, double *L, double *Ld, const int (&pos)[D], const int (&loc)[D], double r,
                                                     RGet &&rget, RPut &&rput)
 {
     double *ptr[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         const bool in_lds = loc[k] >= 0;
-        ptr[k] = (in_lds ? L : Mt) + (size_t)(in_lds ? loc[k] : pos[k]) * kTile;
+        ptr[k] = loc[k] <= -2 ? Ld : (in_lds ? L : Mt) + (size_t)(in_lds ? loc[k] : pos[k]) * kTile;
     }
     double c[D], out[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) {
-        c[k] = 0.0;
-        if (loc[k] > -2) c[k] = *ptr[k];
-    }
+    for (int k = 0; k < D; ++k) c[k] = *ptr[k];
 #pragma unroll
     for (int k = 0; k < D; ++k)
         if (loc[k] <= -2) c[k] = rget(-2 - loc[k]);
@@ -438,11 +434,9 @@ __device__ __forceinline__ double bit_update_onchip(double *Mt, double *L, const
     }
     const double F = bit_compute_exact<D>(c, r, out);
 #pragma unroll
-    for (int k = D - 1; k >= 0; --k) {
-        const bool in_reg = loc[k] <= -2;
-        if (!in_reg) *ptr[k] = out[k];
-        rput(in_reg, -2 - loc[k], out[k]);
-    }
+    for (int k = D - 1; k >= 0; --k) *ptr[k] = out[k];
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) rput(loc[k] <= -2, -2 - loc[k], out[k]);
     return F;
 }
 
@@ -484,6 +478,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     };
     extern __shared__ double lds_rows[];   // LROWS: [tp.rows.R][64]
     double *const Lr = lds_rows + (threadIdx.x & 63);
+    double *const Ldummy = Lr + (size_t)tp.rows.R * kTile;   // (RR > 0: one row past the member's LDS rows, see check_update_onchip)
     __shared__ int sh_ok;
     __shared__ unsigned int sh_deal[2];   // chunks of this member's share dealt so far beyond the waves' first: check sweep, variable sweep
     __shared__ u64 sh_mism[THREADS / 64];
@@ -574,8 +569,8 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
                 typedef int v8i __attribute__((ext_vector_type(8)));
                 auto one = [&](double *const M, const v4i ct, const double sg) {
                     if (RR > 0 && ct.z != 0) {
-                        if (first) check_update_onchip<DC, true, TF>(M, Lr + (size_t)ct.y * kTile, (unsigned int)ct.x, (unsigned int)ct.z, ct.w, sg, r, rget, rput);
-                        else check_update_onchip<DC, false, TF>(M, Lr + (size_t)ct.y * kTile, (unsigned int)ct.x, (unsigned int)ct.z, ct.w, sg, r, rget, rput);
+                        if (first) check_update_onchip<DC, true, TF>(M, Lr + (size_t)ct.y * kTile, Ldummy, (unsigned int)ct.x, (unsigned int)ct.z, ct.w, sg, r, rget, rput);
+                        else check_update_onchip<DC, false, TF>(M, Lr + (size_t)ct.y * kTile, Ldummy, (unsigned int)ct.x, (unsigned int)ct.z, ct.w, sg, r, rget, rput);
                     } else if (first) {
                         check_update_mixed<DC, true, TF>(M, Lr + (size_t)ct.y * kTile, (unsigned int)ct.x, sg, r);
                     } else if (ct.x == 0) {
@@ -656,7 +651,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
                         int lo = a.lrow[0];
 #pragma unroll
                         for (int k = 1; k < DV; ++k) lo = min(lo, a.lrow[k]);
-                        if (lo <= -2) { decide(a.bit & 0x7fffffff, bit_update_onchip<DV, TF>(Mt, Lr, a.pos, a.lrow, r, rget, rput)); return; }
+                        if (lo <= -2) { decide(a.bit & 0x7fffffff, bit_update_onchip<DV, TF>(Mt, Lr, Ldummy, a.pos, a.lrow, r, rget, rput)); return; }
                     }
                     decide(a.bit & 0x7fffffff, bit_update_mixed<DV, TF>(Mt, Lr, a.pos, a.lrow, r));
                 };

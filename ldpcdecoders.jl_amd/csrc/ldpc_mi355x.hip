@@ -365,7 +365,7 @@ struct ldpc_bp_decoder {
     int rows_G = 0, rows_R = 0;       // what the tables below were built for: members per team, LDS rows per member
     int rows_regs = 0, rows_static_c = 0, rows_static_v = 0;   // ... register rows per wave, chunks per sweep that waves own by right
     DevBuf rows_ctab, rows_vtab, rows_lds_edge, rows_reg_edge;
-    int team_regs = 0;                // LDPC_TEAM_REGS: rows a wave may keep in its top registers (0 = none: the default -- measured slower)
+    int team_regs = kTeamRegRows;     // LDPC_TEAM_REGS: rows a wave may keep in its top registers (0 = none)
     int team_static_quarters = 3;     // LDPC_TEAM_STATIC: quarters of a member's chunks per sweep that its waves own by right (0: only each wave's first)
     unsigned int *team_fault = nullptr, *team_fault_dev = nullptr;
     int team_max = 32;        // workgroups per tile at most (LDPC_TEAM_MAX; 1 = team kernel off)
@@ -983,14 +983,16 @@ struct TeamPlanIn {
     bool team_max_set = false; // LDPC_TEAM_MAX given: no teams over all XCDs for <= 4 tiles
     bool rows_possible = false;
     int rows_dv = 4;           // bit degree of the regular graph (one edge per bit is a candidate for a row in LDS)
+    int reg_rows = 0;          // rows a member's waves keep in registers on top of the LDS (W x regs per wave)
     int num_cus = 256;
     int per_xcd = 0, gcap = 0; // team_geometry(): team workgroups one XCD hosts, members per team at most
 };
 
-// What a member is expected to hold (a bit dealt to a member that owns one of its dv checks: 1 / dv of the edges).
+// What a member is expected to keep on chip (a bit dealt to a member that owns one of its dv checks: 1 / dv of the edges
+// are candidates; the LDS holds kTeamRowsMax of them, the waves' registers reg_rows more).
 static int team_rows_expected(const TeamPlanIn &in, int G)
 {
-    return in.rows_possible ? (int)std::min<int64_t>(kTeamRowsMax, in.nnz / std::max(in.rows_dv, 1) / std::max(G, 1)) : 0;
+    return in.rows_possible ? (int)std::min<int64_t>(kTeamRowsMax + in.reg_rows, in.nnz / std::max(in.rows_dv, 1) / std::max(G, 1)) : 0;
 }
 
 // The tables of TeamRows for teams of G members (kept until another G is asked for), for a regular graph whose checks
@@ -1016,6 +1018,7 @@ struct TeamRegPlan {
     int regs_per_wave = 0;        // 0 = no rows in registers
     int static_c = 0, static_v = 0;   // chunks of a member's share of the check / variable sweep that belong to waves by right (multiples of W)
     int W = LDPC_TEAM_THREADS / 64;
+    bool concentrate = false;      // bits go to the owner of their first check where there is room (team_rows_tables())
 };
 struct TeamRowTables {
     int R = 0;                    // LDS rows per member (the largest count; kTeamRowsMax at most)
@@ -1047,11 +1050,19 @@ static TeamRowTables team_rows_tables(int n, int s, int nnz, int dc, int dv, con
     std::vector<int> cap((size_t)G, 0), member_of_bit((size_t)n, -1);
     for (int p = 0; p < n; ++p) cap[(size_t)((p / 4) % G)]++;
     std::vector<int> room = cap;
+    // A bit goes to the owner of its FIRST check while that member has room, else to the owner of another of its checks
+    // (the one with most room).  First check first: in a Gallager code the first block's check i holds bits
+    // wr * i ... wr * i + wr - 1, so all of them land with that check's owner and the rows that end up on chip are
+    // whole checks' worth -- a quarter of the checks need no memory at all and the others none of the detours of a
+    // mixed update (two clean checks of a chunk load their rows together) -- instead of one or two rows in nearly
+    // every check (LDPC_TEAM_CONCENTRATE=0, experiments build: most room only, as in round 2).
     for (int j = 0; j < n; ++j) {
         int best = -1;
         for (int k = 0; k < dv; ++k) {
             const int m = check_owner(c2r[(size_t)dv * j + k] / dc);
-            if (room[(size_t)m] > 0 && (best < 0 || room[(size_t)m] > room[(size_t)best])) best = m;
+            if (room[(size_t)m] <= 0) continue;
+            if (k == 0 && rp.concentrate) { best = m; break; }
+            if (best < 0 || room[(size_t)m] > room[(size_t)best]) best = m;
         }
         if (best >= 0) { member_of_bit[(size_t)j] = best; room[(size_t)best]--; }
     }
@@ -1186,7 +1197,8 @@ static ldpc_status team_rows_build(ldpc_bp_decoder *d, int G)
     if (d->rows_G == G) return LDPC_OK;
     // (three quarters of a member's share dealt statically measured 1 % faster than dealing all but the first chunk from
     // the counter -- 873 against 883 ms on the full C3 batch --; rows in registers need it)
-    const TeamRegPlan rp = team_reg_plan((int)d->n, (int)d->s, G, kExperimentsBuild ? d->team_regs : 0, d->team_static_quarters);
+    TeamRegPlan rp = team_reg_plan((int)d->n, (int)d->s, G, d->team_regs, d->team_static_quarters);
+    if (const char *e = exp_env("LDPC_TEAM_CONCENTRATE")) rp.concentrate = std::atoi(e) != 0;
     const TeamRowTables t = team_rows_tables((int)d->n, (int)d->s, (int)d->nnz, d->rows_dc, d->rows_dv, d->h_csc2csr, G, rp);
     auto up = [&](DevBuf &b, const std::vector<int> &v) -> ldpc_status {
         ldpc_status r = b.ensure(std::max<size_t>(v.size() * 4, 4));
@@ -1218,8 +1230,12 @@ static bool team_fit(const TeamPlanIn &in, int64_t ntiles, bool rows, int *xcds,
     const size_t state = std::max<size_t>((size_t)in.nnz, 1) * kTile * sizeof(double);
     const size_t cache = in.cache;
     if (!cache) return false;
+    // the combination that gives most workgroups a tile -- but among combinations within 15 % of that, the one that
+    // uses most XCDs (their L2s and ports; fewer, larger teams per XCD): x runs downwards, so the first one that
+    // qualifies wins.  ((3,6) n = 16380: eight teams of 23 on eight XCDs measured 7.1 TB/s, sixteen of 16 6.3)
     int64_t best = 0;
     const int x_hi = in.xcds_forced ? in.xcds_forced : 8, x_lo = in.xcds_forced ? in.xcds_forced : 6;
+    for (int pass = 0; pass < 2; ++pass)
     for (int x = x_hi; x >= x_lo; --x)
         for (int t = 1; t <= per_xcd / 3; ++t) {
             if ((size_t)x * (size_t)t * (state - (rows ? state / (size_t)std::max(in.rows_dv, 1) : 0)) > cache) break;   // (1 / dv at most can be in LDS)
@@ -1229,7 +1245,8 @@ static bool team_fit(const TeamPlanIn &in, int64_t ntiles, bool rows, int *xcds,
             // rows that the members keep in LDS are not in the cache
             if ((size_t)x * (size_t)t * (state - (rows ? (size_t)g * team_rows_expected(in, g) * kTile * sizeof(double) : 0)) > cache) continue;
             const int64_t w = std::min<int64_t>((int64_t)x * t, ntiles) * g;   // workgroups with a tile
-            if (w > best) { best = w; *xcds = x; *tpx = t; *G = g; }
+            if (pass == 0) { if (w > best) best = w; }
+            else if (w * 100 >= best * 85) { *xcds = x; *tpx = t; *G = g; return true; }
         }
     if (best > 0) return true;
     // Slots up to 2.2 x the budget: one team per XCD still pays -- the slots are partly cached, and a team streams what is
@@ -1280,9 +1297,11 @@ static TeamPlan team_plan_pure(const TeamPlanIn &in, int64_t batch)
         const size_t state = std::max<size_t>((size_t)in.nnz, 1) * kTile * sizeof(double);
         int x = 8, t = (int)need, g = 0;
         const bool one_round = in.cache && !in.xcds_forced && (size_t)8 * (size_t)need * state <= in.cache + in.cache / 4;
-        // (the budget is applied to whole slots although members keep up to 15 % of the rows in LDS: eight teams of the
-        // C3 code -- 8 x 27 MiB with the rows in LDS -- measured 981 ms for the full batch, seven 957)
-        if (one_round || !team_fit(in, ntiles, false, &x, &t, &g)) {
+        // (With the rows in LDS alone -- 15 % of a tile -- the budget is applied to whole slots: eight teams of the C3 code,
+        // 8 x 27 MiB, measured 981 ms for the full batch, seven 957.  With rows in the waves' registers as well a quarter
+        // of a tile is on chip and the rows on chip are taken off the slots: 8 x 24 MiB fit, and eight teams measured
+        // 833 ms against 877 on seven -- round 3.)
+        if (one_round || !team_fit(in, ntiles, in.rows_possible && in.reg_rows > 0, &x, &t, &g)) {
             if (!one_round && ntiles > in.num_cus) return pl;
             x = 8; t = (int)need;
             g = (int)std::min<int64_t>(gcap, (int64_t)per_xcd / t);
@@ -1304,6 +1323,7 @@ static TeamPlanIn team_plan_in(const ldpc_bp_decoder *d, int per_xcd, int gcap)
     TeamPlanIn in;
     in.nnz = d->nnz; in.max_iters = d->max_iters; in.cache = d->team_cache; in.xcds_forced = d->team_xcds;
     in.team_max_set = d->team_max_set; in.rows_possible = team_rows_possible(d); in.rows_dv = std::max(d->rows_dv, 1); in.num_cus = d->num_cus;
+    in.reg_rows = in.rows_possible ? d->team_regs * (LDPC_TEAM_THREADS / 64) : 0;
     in.per_xcd = per_xcd; in.gcap = gcap;
     return in;
 }
@@ -1322,6 +1342,7 @@ extern "C" ldpc_status ldpc_debug_team_plan(int64_t nnz, int64_t max_iters, int6
     if (!out || nnz < 0 || batch < 0 || cache_mib < 0) return fail(LDPC_ERR_INVALID_ARGUMENT, "bad argument");
     TeamPlanIn in;
     in.nnz = nnz; in.max_iters = max_iters; in.cache = (size_t)cache_mib << 20; in.rows_possible = rows_dv > 0; in.rows_dv = std::max(rows_dv, 1);
+    in.reg_rows = rows_dv > 0 ? kTeamRegRows * (LDPC_TEAM_THREADS / 64) : 0;
     in.num_cus = 256; in.per_xcd = 32;
     in.gcap = (int)std::min<int64_t>(32, std::max<int64_t>(1, nnz / 2048));
     const TeamPlan pl = team_plan_pure(in, batch);
@@ -1781,8 +1802,8 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         const int *t_col = a_col, *t_c2r = a_c2r;
         if (plan.rows && team_rows_build(d, team) == LDPC_OK) {   // (also with LDPC_TEAM_SCATTER: members over all XCDs, a test)
             // rows that only one member touches live in its LDS (TeamRows)
-            team_kernel_t tkr = pick_team_kernel_rows(d->rows_dc, d->rows_dv, want_llr, kExperimentsBuild && d->rows_regs > 0);
-            const size_t need = (size_t)d->rows_R * kTile * sizeof(double);
+            team_kernel_t tkr = pick_team_kernel_rows(d->rows_dc, d->rows_dv, want_llr, d->rows_regs > 0);
+            const size_t need = (size_t)(d->rows_R + (d->rows_regs > 0 ? 1 : 0)) * kTile * sizeof(double);   // (+ the dummy row of the register rows)
             int occ_rows = 0;
             if (tkr && d->prepare_kernel((const void *)tkr, LDPC_TEAM_THREADS, need, &occ_rows) == LDPC_OK && occ_rows >= 1) {
                 tk = tkr; team_lds = need;

@@ -98,6 +98,17 @@ Rccl *rccl()
         if (r_ != ncclSuccess) return set_error(LDPC_ERR_HIP, std::string(#expr) + ": " + (R)->GetErrorString(r_)); \
     } while (0)
 
+// An RCCL group that has been opened is closed on every path out of the scope (an error between ncclGroupStart and
+// ncclGroupEnd must not leave the communicators inside a group).
+struct GroupGuard {
+    Rccl *R;
+    bool open = false;
+    explicit GroupGuard(Rccl *r) : R(r) {}
+    ncclResult_t start() { const ncclResult_t r = R->GroupStart(); open = r == ncclSuccess; return r; }
+    ncclResult_t end() { open = false; return R->GroupEnd(); }
+    ~GroupGuard() { if (open) (void)R->GroupEnd(); }
+};
+
 struct DeviceGuard {
     int prev = -1;
     DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; } }
@@ -336,7 +347,8 @@ ldpc_status ldpc_bp_decode_batch_multi_device(ldpc_bp_multi *m, int64_t batch, c
 
     // ---- scatter: syndromes of shard g -> device g
     if (use_rccl) {
-        NCCL_TRY(N, N->GroupStart());
+        GroupGuard grp(N);
+        NCCL_TRY(N, grp.start());
         for (int g = self ? 0 : 1; g < G; ++g) {
             int64_t lo, hi;
             shard_bounds(batch, G, g, &lo, &hi);
@@ -347,7 +359,7 @@ ldpc_status ldpc_bp_decode_batch_multi_device(ldpc_bp_multi *m, int64_t batch, c
             MHIP_TRY(hipSetDevice(m->dev[(size_t)g]));
             NCCL_TRY(N, N->Recv(m->shard[(size_t)g].syn.p, c * s, ncclUint8, 0, m->comm[(size_t)g], self ? R : m->st[(size_t)g]));
         }
-        NCCL_TRY(N, N->GroupEnd());
+        NCCL_TRY(N, grp.end());
     } else if (G > 1) {
         MHIP_TRY(hipSetDevice(m->dev[0]));
         MHIP_TRY(hipEventRecord(m->ev_in, R));
@@ -387,7 +399,8 @@ ldpc_status ldpc_bp_decode_batch_multi_device(ldpc_bp_multi *m, int64_t batch, c
 
     // ---- gather: hard decisions, flags (, iteration counts, LLRs) of shard g -> the caller's arrays on the root
     if (use_rccl) {
-        NCCL_TRY(N, N->GroupStart());
+        GroupGuard grp(N);
+        NCCL_TRY(N, grp.start());
         for (int g = self ? 0 : 1; g < G; ++g) {
             int64_t lo, hi;
             shard_bounds(batch, G, g, &lo, &hi);
@@ -410,7 +423,7 @@ ldpc_status ldpc_bp_decode_batch_multi_device(ldpc_bp_multi *m, int64_t batch, c
                 NCCL_TRY(N, N->Recv(q.dst, q.count, q.ty, g, m->comm[0], R));
             }
         }
-        NCCL_TRY(N, N->GroupEnd());
+        NCCL_TRY(N, grp.end());
     } else if (G > 1) {
         for (int g = 1; g < G; ++g) {
             int64_t lo, hi;

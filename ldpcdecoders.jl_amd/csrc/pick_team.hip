@@ -36,14 +36,10 @@ template <int DC, int DV>
 team_kernel_t rows_pick(bool llr, bool regs)
 {
     static_assert(team_rows_degrees_ok(DC, DV), "keep team_rows_degrees_ok() and the instantiations in step");
-#ifdef LDPC_EXPERIMENTS   // rows in the waves' top registers measured slower than LDS alone: experiments build only
     if (regs) {
         if (llr) return bp_team_kernel<DC, DV, true, LDPC_TEAM_THREADS, false, true, kTeamRegRows>;
         return bp_team_kernel<DC, DV, false, LDPC_TEAM_THREADS, false, true, kTeamRegRows>;
     }
-#else
-    (void)regs;
-#endif
     if (llr) return bp_team_kernel<DC, DV, true, LDPC_TEAM_THREADS, false, true>;
     return bp_team_kernel<DC, DV, false, LDPC_TEAM_THREADS, false, true>;
 }

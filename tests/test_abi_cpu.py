@@ -206,35 +206,35 @@ def test_hot_kernels_keep_their_register_budget(tmp_path):
     for k in hot:
         assert info[k]["vgpr_count"] <= 80 and info[k]["private_segment_fixed_size"] == 0, (k, info[k])
     # every rows-on-chip instantiation of the team kernel -- (6,3), (8,4), (10,5), with and without LLRs --: one 8-wave
-    # workgroup per CU (156 KB of LDS), not a byte of scratch memory; the product holds none that keeps rows in registers
+    # workgroup per CU (156 KB of LDS), not a byte of scratch memory
     rows = [k for k in info if re.match(r"_ZN4ldpc14bp_team_kernelILi\d+ELi\d+ELb[01]ELi512ELb0ELb1ELi0EEE", k)]
     assert len(rows) == 6, [k for k in info if "bp_team_kernel" in k][:8]
     for k in rows:
         assert info[k]["private_segment_fixed_size"] == 0 and info[k]["vgpr_count"] <= 256, (k, info[k])
-    assert not [k for k in info if re.match(r"_ZN4ldpc14bp_team_kernelILi\d+ELi\d+ELb[01]ELi512ELb0ELb1ELi32EEE", k)]
-    # the EXPERIMENTS build also has the instantiations that keep rows in the top 64 registers of every wave
-    # (bp_team_kernels.hpp "Rows in REGISTERS"): 256 registers a lane, no accumulator registers (the allocator would park
-    # values of its own in them), no scratch, and nothing but the two accessors (v_mov_b32 from / to v192 | v193 under
-    # s_set_gpr_idx_on) may touch v192 and up
-    xinfo, cos = _kernel_metadata(ldpc._capi.EXP_LIB_PATH, tmp_path, "exp")
-    regs = [k for k in xinfo if re.match(r"_ZN4ldpc14bp_team_kernelILi\d+ELi\d+ELb[01]ELi512ELb0ELb1ELi32EEE", k)]
-    assert len(regs) == 6
-    for k in regs:
-        assert xinfo[k]["private_segment_fixed_size"] == 0 and xinfo[k]["agpr_count"] == 0 and xinfo[k]["vgpr_count"] == 256, (k, xinfo[k])
-    top = re.compile(r"\bv(19[2-9]|2[0-4]\d|25[0-5])\b|\bv\[\d+:(19[2-9]|2[0-4]\d|25[0-5])\]")
-    ok_form = re.compile(r"^\s*v_mov_b32_e32 (v\d+, v19[23]|v19[23], v\d+)\b")
-    checked = 0
-    for co in cos:
-        dis = subprocess.run([f"{llvm}/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout
-        if "ELb0ELb1ELi32EEE" not in dis:
-            continue
-        cur = None
-        for line in dis.splitlines():
-            m = re.match(r"[0-9a-f]+ <(\S+)>:", line)
-            if m:
-                cur = m.group(1)
+    # ... and the ones that also keep rows in the top 64 registers of every wave (bp_team_kernels.hpp "Rows in
+    # REGISTERS"; the headline instantiation is one of them): 256 registers a lane, no accumulator registers (the
+    # allocator would park values of its own in them), no scratch, and nothing but the two accessors (v_mov_b32 from / to
+    # v192 | v193 under s_set_gpr_idx_on) may touch v192 and up
+    for tag, path in (("prod", ldpc._capi.LIB_PATH), ("exp", ldpc._capi.EXP_LIB_PATH)):
+        xinfo, cos = _kernel_metadata(path, tmp_path, tag + "2")
+        regs = [k for k in xinfo if re.match(r"_ZN4ldpc14bp_team_kernelILi\d+ELi\d+ELb[01]ELi512ELb0ELb1ELi32EEE", k)]
+        assert len(regs) == 6
+        for k in regs:
+            assert xinfo[k]["private_segment_fixed_size"] == 0 and xinfo[k]["agpr_count"] == 0 and xinfo[k]["vgpr_count"] == 256, (k, xinfo[k])
+        top = re.compile(r"\bv(19[2-9]|2[0-4]\d|25[0-5])\b|\bv\[\d+:(19[2-9]|2[0-4]\d|25[0-5])\]")
+        ok_form = re.compile(r"^\s*v_mov_b32_e32 (v\d+, v19[23]|v19[23], v\d+)\b")
+        checked = 0
+        for co in cos:
+            dis = subprocess.run([f"{llvm}/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout
+            if "ELb0ELb1ELi32EEE" not in dis:
                 continue
-            if cur in regs and top.search(line.split("//")[0]):
-                assert ok_form.match(line), (cur, line)
-                checked += 1
-    assert checked > 100, checked
+            cur = None
+            for line in dis.splitlines():
+                m = re.match(r"[0-9a-f]+ <(\S+)>:", line)
+                if m:
+                    cur = m.group(1)
+                    continue
+                if cur in regs and top.search(line.split("//")[0]):
+                    assert ok_form.match(line), (cur, line)
+                    checked += 1
+        assert checked > 100, checked

@@ -146,21 +146,29 @@ def test_team_plan_by_graph_and_batch():
     """The host's choice of teams (ldpc_mi355x.hip team_plan_pure / team_fit), for an MI355X's geometry.  Message slot of
     a graph: nnz x 512 B; budget of slots in flight: 240 MiB of the 256 MiB Infinity Cache."""
     c3 = 65536                                                   # n = 16384, (4,8)-regular: 32 MiB a slot
-    # the headline batch: SEVEN persistent teams of 32 (224 MiB; an eighth slot overfills the cache), rows in LDS;
-    # 8 x 32 workgroups are launched, the blocks of the eighth XCD leave at once
-    assert plan(c3, 65536) == dict(members=32, teams=7, grid=256, xcds=7, scatter=0, rows=1)
-    assert plan(c3, 65536, regular=0)["rows"] == 0
+    # the headline batch: EIGHT persistent teams of 32 -- with a quarter of a tile's rows on chip (312 in the LDS of every
+    # member, 8 x 32 in its waves' registers) eight slots are 8 x 24 MiB of the 240 MiB budget.  A graph without a
+    # rows-on-chip instantiation keeps whole slots: SEVEN teams (224 MiB; an eighth slot overfills the cache), 8 x 32
+    # workgroups are launched and the blocks of the eighth XCD leave at once
+    assert plan(c3, 65536) == dict(members=32, teams=8, grid=256, xcds=8, scatter=0, rows=1)
+    assert plan(c3, 65536, regular=0) == dict(members=32, teams=7, grid=256, xcds=7, scatter=0, rows=0)
     # exactly eight tiles: one round of eight teams rather than seven teams twice
     assert plan(c3, 512) == dict(members=32, teams=8, grid=256, xcds=8, scatter=0, rows=1)
-    assert plan(c3, 576)["teams"] == 7                           # nine tiles: persistent again
+    assert plan(c3, 576)["teams"] == 8 and plan(c3, 576, regular=0)["teams"] == 7    # nine tiles: persistent again
     # up to four tiles: one team per tile, members dealt over all XCDs, up to 64 of them, no rows in LDS
     assert plan(c3, 1) == dict(members=64, teams=1, grid=64, xcds=8, scatter=1, rows=0)
     assert plan(c3, 256) == dict(members=64, teams=4, grid=256, xcds=8, scatter=1, rows=0)
     # 28 MiB slots (n = 14336): eight fit the budget
     assert plan(57344, 65536)["teams"] == 8 and plan(57344, 65536)["members"] == 28
-    # 16 MiB slots (n = 8192): members of >= 2048 rows are 16 at most, so two teams per XCD on seven XCDs (224 MiB)
-    p = plan(32768, 65536)
+    # 16 MiB slots (n = 8192): members of >= 2048 rows are 16 at most, so two teams per XCD -- on seven XCDs with whole
+    # slots (224 MiB), on all eight with the rows on chip taken off
+    p = plan(32768, 65536, regular=0)
     assert p["members"] == 16 and p["teams"] == 14 and p["xcds"] == 7 and p["grid"] == 256
+    p = plan(32768, 65536)
+    assert p["members"] == 16 and p["teams"] == 16 and p["xcds"] == 8
+    # among combinations that give about as many workgroups a tile, the one on more XCDs: the (3,6) n = 16380 code
+    # (24 MiB slots, members of >= 2048 rows are 23 at most) takes eight teams of 23, not twelve of 16 on six XCDs
+    assert plan(49140, 65536, dv=3) == dict(members=23, teams=8, grid=184, xcds=8, scatter=0, rows=1)
     # 64 MiB slots (n = 32768): twice the cache -- the second tier, one persistent team per XCD
     assert plan(131072, 65536) == dict(members=32, teams=8, grid=256, xcds=8, scatter=0, rows=1)
     # 128 MiB slots (n = 65536): the tile kernel for more tiles than CUs, one team per tile below
