@@ -165,6 +165,9 @@ struct TeamRows {
     int regs;                   // register rows per wave (0 ... kTeamRegRows)
     int static_c, static_v;     // chunks of a member's share of the check / variable sweep that its waves own by right
                                 // (multiples of W, at least W, at most the smallest member's share)
+    int flip;                   // bit 0 / 1: the upper half of a member's waves walks its chunks by right of the check /
+                                // variable sweep from the last to the first (the chunks whose rows are all on chip come
+                                // first in the dealt order: so one wave of every SIMD computes while the other one loads)
 };
 
 struct TeamParams {
@@ -621,8 +624,9 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
         // l to wave l % W -- at least each wave's first), the rest they take from the counter in LDS
         const int mine = (nch - rank + G - 1) / G;
         const int stat = LROWS ? tp.rows.static_c : W;
+        const int mirror = (LROWS && (tp.rows.flip & 1) && w >= W / 2) ? 2 * w + stat - W : -1;
         for (int l = w; l < mine;) {
-            chunk(l * G + rank);
+            chunk(((mirror >= 0 && l < stat) ? mirror - l : l) * G + rank);
             l = !tp.dynamic ? l + W : (l + W < stat ? l + W : stat + team_deal(&sh_deal[0], lane));
         }
     };
@@ -699,8 +703,9 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
         };
         const int mine = (nch - rank + G - 1) / G;
         const int stat = LROWS ? tp.rows.static_v : W;
+        const int mirror = (LROWS && (tp.rows.flip & 2) && w >= W / 2) ? 2 * w + stat - W : -1;
         for (int l = w; l < mine;) {
-            chunk(l * G + rank);
+            chunk(((mirror >= 0 && l < stat) ? mirror - l : l) * G + rank);
             l = !tp.dynamic ? l + W : (l + W < stat ? l + W : stat + team_deal(&sh_deal[1], lane));
         }
     };

@@ -366,6 +366,7 @@ struct ldpc_bp_decoder {
     int rows_regs = 0, rows_static_c = 0, rows_static_v = 0;   // ... register rows per wave, chunks per sweep that waves own by right
     DevBuf rows_ctab, rows_vtab, rows_lds_edge, rows_reg_edge;
     int team_regs = kTeamRegRows;     // LDPC_TEAM_REGS: rows a wave may keep in its top registers (0 = none)
+    int team_flip = 3;                // LDPC_TEAM_FLIP: bit 0 / 1: upper half of the waves walks its check / position chunks by right backwards (TeamRows::flip)
     int team_static_quarters = 3;     // LDPC_TEAM_STATIC: quarters of a member's chunks per sweep that its waves own by right (0: only each wave's first)
     unsigned int *team_fault = nullptr, *team_fault_dev = nullptr;
     int team_max = 32;        // workgroups per tile at most (LDPC_TEAM_MAX; 1 = team kernel off)
@@ -777,6 +778,7 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     if (const char *e = exp_env("LDPC_TEAM_AHEAD")) d->team_ahead = std::max(0, std::min(65, std::atoi(e)));
     if (const char *e = exp_env("LDPC_TEAM_AHEAD_FROM")) d->team_ahead_from = std::max(1, std::atoi(e));
     if (const char *e = exp_env("LDPC_TEAM_REGS")) d->team_regs = std::max(0, std::min(kTeamRegRows, std::atoi(e)));
+    if (const char *e = exp_env("LDPC_TEAM_FLIP")) d->team_flip = std::atoi(e) & 3;
     if (const char *e = exp_env("LDPC_TEAM_STATIC")) d->team_static_quarters = std::max(0, std::min(4, std::atoi(e)));
     if (const char *e = exp_env("LDPC_TEAM_MAX")) { d->team_max = std::max(1, std::min(kTeamMaxMembers, std::atoi(e))); d->team_max_set = true; }
     {
@@ -1018,7 +1020,7 @@ struct TeamRegPlan {
     int regs_per_wave = 0;        // 0 = no rows in registers
     int static_c = 0, static_v = 0;   // chunks of a member's share of the check / variable sweep that belong to waves by right (multiples of W)
     int W = LDPC_TEAM_THREADS / 64;
-    bool concentrate = false;      // bits go to the owner of their first check where there is room (team_rows_tables())
+    bool concentrate = true;       // bits go to the owner of their first check where there is room (team_rows_tables())
 };
 struct TeamRowTables {
     int R = 0;                    // LDS rows per member (the largest count; kTeamRowsMax at most)
@@ -1812,7 +1814,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
                 tp.rows.R = d->rows_R;
                 tp.rows.reg_edge = (const int *)d->rows_reg_edge.p;
                 tp.rows.regs = d->rows_regs;
-                tp.rows.static_c = d->rows_static_c; tp.rows.static_v = d->rows_static_v;
+                tp.rows.static_c = d->rows_static_c; tp.rows.static_v = d->rows_static_v; tp.rows.flip = d->team_flip;
                 t_col = (const int *)d->rows_ctab.p;     // (this instantiation reads its tables through these two arguments)
                 t_c2r = (const int *)d->rows_vtab.p;
             }
