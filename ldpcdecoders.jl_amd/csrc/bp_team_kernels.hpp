@@ -443,6 +443,69 @@ __device__ __forceinline__ double bit_update_onchip(double *Mt, double *L, doubl
     return F;
 }
 
+// A check whose rows ALL live in this wave's registers (rows rbase ... rbase + D - 1): no memory at all.  This is
+// the usual kind when the host gathers the on-chip rows into whole checks (team_rows_tables(), "concentrate").
+template <int D, bool FIRST, bool TF, class RGet, class RPut>
+__device__ __forceinline__ void check_update_regs(int rbase, double sigma, double r, RGet &&rget, RPut &&rput)
+{
+    double a[D], out[D];
+    if (FIRST) {
+        const double a0 = 2.0 / (1.0 + r) - 1.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) a[k] = a0;
+    } else {
+        double m[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) m[k] = rget(rbase + k);
+#pragma unroll
+        for (int k = 0; k < D; ++k) a[k] = 2.0 / (1.0 + m[k]) - 1.0;
+    }
+    check_compute_exact<D, TF>(a, sigma, out);
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) rput(true, rbase + k, out[k]);
+}
+
+// Two bits whose edges 1 ... D-1 are rows of the slot and whose FIRST edge is anywhere (loc >= 0: that LDS row, -1:
+// the slot, <= -2: register row -2 - loc of this wave) -- what the variable sweep meets when the on-chip rows are whole
+// checks of the first block: every bit has exactly its first edge there.  All 2 (D - 1) slot rows are in flight
+// together (scalar row numbers: no pointer per edge as in bit_update_onchip); the first edges come by a wave-uniform
+// branch each.  Same arithmetic per bit.
+template <int D, bool TF, class RGet, class RPut>
+__device__ __forceinline__ void bit_update_pair_first(double *Mt, double *L, const int (&pos0)[D], const int loc0, const int (&pos1)[D],
+                                                      const int loc1, double r, RGet &&rget, RPut &&rput, double &T0, double &T1)
+{
+    double c0[D], c1[D], o0[D], o1[D];
+    size_t at0[D], at1[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) { at0[k] = (size_t)pos0[k] * kTile; at1[k] = (size_t)pos1[k] * kTile; }
+#pragma unroll
+    for (int k = 1; k < D; ++k) c0[k] = ldm(Mt + at0[k]);
+#pragma unroll
+    for (int k = 1; k < D; ++k) c1[k] = ldm(Mt + at1[k]);
+    if (loc0 == -1) c0[0] = ldm(Mt + at0[0]);
+    else if (loc0 >= 0) c0[0] = L[(size_t)loc0 * kTile];
+    else c0[0] = rget(-2 - loc0);
+    if (loc1 == -1) c1[0] = ldm(Mt + at1[0]);
+    else if (loc1 >= 0) c1[0] = L[(size_t)loc1 * kTile];
+    else c1[0] = rget(-2 - loc1);
+    if (TF) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) { c0[k] = (1.0 - c0[k]) / (1.0 + c0[k]); c1[k] = (1.0 - c1[k]) / (1.0 + c1[k]); }   // :147
+    }
+    T0 = bit_compute_exact<D>(c0, r, o0);
+#pragma unroll
+    for (int k = D - 1; k >= 1; --k) stm(Mt + at0[k], o0[k]);
+    if (loc0 == -1) stm(Mt + at0[0], o0[0]);
+    else if (loc0 >= 0) L[(size_t)loc0 * kTile] = o0[0];
+    else rput(true, -2 - loc0, o0[0]);
+    T1 = bit_compute_exact<D>(c1, r, o1);
+#pragma unroll
+    for (int k = D - 1; k >= 1; --k) stm(Mt + at1[k], o1[k]);
+    if (loc1 == -1) stm(Mt + at1[0], o1[0]);
+    else if (loc1 >= 0) L[(size_t)loc1 * kTile] = o1[0];
+    else rput(true, -2 - loc1, o1[0]);
+}
+
 // Register budget: teams run one or two workgroups per CU (team_geometry() on the host), so the narrow-degree
 // instantiation may have 128 VGPRs instead of the tile kernel's 80 (three workgroups per CU) -- under 80 it spilled.
 template <int DC, int DV, int THREADS, bool LROWS = false>
@@ -570,8 +633,15 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
                 // (Pairs of checks / bits with rows in LDS loaded together measured slower, not faster.)
                 typedef int v4i __attribute__((ext_vector_type(4)));
                 typedef int v8i __attribute__((ext_vector_type(8)));
+                constexpr int FULL = (1 << DC) - 1;
                 auto one = [&](double *const M, const v4i ct, const double sg) {
-                    if (RR > 0 && ct.z != 0) {
+                    if (RR > 0 && ct.z == FULL) {            // the whole check in this wave's registers
+                        if (first) check_update_regs<DC, true, TF>(ct.w, sg, r, rget, rput);
+                        else check_update_regs<DC, false, TF>(ct.w, sg, r, rget, rput);
+                    } else if (ct.x == FULL) {               // the whole check in LDS: consecutive rows from ct.y on
+                        if (first) check_update_exact<DC, true, TF>(Lr + (size_t)ct.y * kTile, sg, r);
+                        else check_update_exact<DC, false, TF>(Lr + (size_t)ct.y * kTile, sg, r);
+                    } else if (RR > 0 && ct.z != 0) {
                         if (first) check_update_onchip<DC, true, TF>(M, Lr + (size_t)ct.y * kTile, Ldummy, (unsigned int)ct.x, (unsigned int)ct.z, ct.w, sg, r, rget, rput);
                         else check_update_onchip<DC, false, TF>(M, Lr + (size_t)ct.y * kTile, Ldummy, (unsigned int)ct.x, (unsigned int)ct.z, ct.w, sg, r, rget, rput);
                     } else if (first) {
@@ -660,11 +730,19 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
                     decide(a.bit & 0x7fffffff, bit_update_mixed<DV, TF>(Mt, Lr, a.pos, a.lrow, r));
                 };
                 auto two = [&](const TeamVRec<DV> &a, const TeamVRec<DV> &b) {
-                    if ((a.bit | b.bit) >= 0 && tp.pairs) {   // neither has a row in LDS: both loaded together
+                    int rest = -1;                            // stays -1: the edges 1 ... DV-1 of both are rows of the slot
+#pragma unroll
+                    for (int k = 1; k < DV; ++k) rest &= a.lrow[k] & b.lrow[k];
+                    if ((a.bit | b.bit) >= 0 && tp.pairs) {   // neither has a row on chip: both loaded together
                         double T0, T1;
                         bit_update_pair_v<DV, TF>(Mt, a.pos, b.pos, r, T0, T1);
                         decide(a.bit, T0);
                         decide(b.bit, T1);
+                    } else if (rest == -1 && tp.pairs) {      // on chip at most the first edge of either (whole checks of the first block)
+                        double T0, T1;
+                        bit_update_pair_first<DV, TF>(Mt, Lr, a.pos, a.lrow[0], b.pos, b.lrow[0], r, rget, rput, T0, T1);
+                        decide(a.bit & 0x7fffffff, T0);
+                        decide(b.bit & 0x7fffffff, T1);
                     } else {
                         single(a);
                         single(b);

@@ -1021,6 +1021,7 @@ struct TeamRegPlan {
     int static_c = 0, static_v = 0;   // chunks of a member's share of the check / variable sweep that belong to waves by right (multiples of W)
     int W = LDPC_TEAM_THREADS / 64;
     bool concentrate = true;       // bits go to the owner of their first check where there is room (team_rows_tables())
+    bool whole_checks = false;     // ... and only checks with ALL their rows on chip keep them there
 };
 struct TeamRowTables {
     int R = 0;                    // LDS rows per member (the largest count; kTeamRowsMax at most)
@@ -1106,20 +1107,33 @@ static TeamRowTables team_rows_tables(int n, int s, int nnz, int dc, int dv, con
             bit[(size_t)p] = bits_of[(size_t)m][b++];
         }
     }
+    // LDS candidates per member (check and bit share the owner, not in registers), in check order; the first kTeamRowsMax of each get rows
+    std::vector<char> is_reg((size_t)nnz, 0);
+    for (auto &v : reg_rows) for (int q : v) is_reg[(size_t)q] = 1;
+    std::vector<std::vector<int>> cand((size_t)G);
+    for (int j = 0; j < n; ++j)
+        for (int k = 0; k < dv; ++k) {
+            const int q = c2r[(size_t)dv * j + k];
+            if (!is_reg[(size_t)q] && check_owner(q / dc) == member_of_bit[(size_t)j]) cand[(size_t)member_of_bit[(size_t)j]].push_back(q);
+        }
+    for (auto &v : cand) { std::sort(v.begin(), v.end()); if ((int)v.size() > kTeamRowsMax) v.resize(kTeamRowsMax); }
+    if (rp.whole_checks) {
+        // only whole checks stay on chip: a check with SOME rows on chip takes the general update (pointers per edge),
+        // which costs more than the few rows save -- in a Gallager code these are the stray edges beyond the first block
+        std::vector<int> on_chip((size_t)s, 0);
+        for (auto &v : reg_rows) for (int q : v) on_chip[(size_t)(q / dc)]++;
+        for (auto &v : cand) for (int q : v) on_chip[(size_t)(q / dc)]++;
+        auto partial = [&](int q) { return on_chip[(size_t)(q / dc)] < dc; };
+        for (auto &v : reg_rows) v.erase(std::remove_if(v.begin(), v.end(), partial), v.end());
+        for (auto &v : cand) v.erase(std::remove_if(v.begin(), v.end(), partial), v.end());
+    }
     for (int mw = 0; mw < G * W; ++mw) {
         std::sort(reg_rows[(size_t)mw].begin(), reg_rows[(size_t)mw].end());
         for (int x = 0; x < (int)reg_rows[(size_t)mw].size(); ++x) reg_of[(size_t)reg_rows[(size_t)mw][(size_t)x]] = x;
         out.in_regs += reg_rows[(size_t)mw].size();
     }
-    // LDS candidates per member (check and bit share the owner, not in registers), in check order; the first R of each get rows
-    std::vector<std::vector<int>> cand((size_t)G);
-    for (int j = 0; j < n; ++j)
-        for (int k = 0; k < dv; ++k) {
-            const int q = c2r[(size_t)dv * j + k];
-            if (reg_of[(size_t)q] < 0 && check_owner(q / dc) == member_of_bit[(size_t)j]) cand[(size_t)member_of_bit[(size_t)j]].push_back(q);
-        }
     int R = 0;
-    for (auto &v : cand) { std::sort(v.begin(), v.end()); if ((int)v.size() > kTeamRowsMax) v.resize(kTeamRowsMax); R = std::max(R, (int)v.size()); }
+    for (auto &v : cand) R = std::max(R, (int)v.size());
     R = std::max(R, 1);
     std::vector<int> lds_row_of((size_t)nnz, -1);
     std::vector<int> &lds_edge = out.lds_edge, &reg_edge = out.reg_edge;
@@ -1200,7 +1214,7 @@ static ldpc_status team_rows_build(ldpc_bp_decoder *d, int G)
     // (three quarters of a member's share dealt statically measured 1 % faster than dealing all but the first chunk from
     // the counter -- 873 against 883 ms on the full C3 batch --; rows in registers need it)
     TeamRegPlan rp = team_reg_plan((int)d->n, (int)d->s, G, d->team_regs, d->team_static_quarters);
-    if (const char *e = exp_env("LDPC_TEAM_CONCENTRATE")) rp.concentrate = std::atoi(e) != 0;
+    if (const char *e = exp_env("LDPC_TEAM_CONCENTRATE")) { rp.concentrate = std::atoi(e) != 0; rp.whole_checks = std::atoi(e) == 2; }
     const TeamRowTables t = team_rows_tables((int)d->n, (int)d->s, (int)d->nnz, d->rows_dc, d->rows_dv, d->h_csc2csr, G, rp);
     auto up = [&](DevBuf &b, const std::vector<int> &v) -> ldpc_status {
         ldpc_status r = b.ensure(std::max<size_t>(v.size() * 4, 4));
