@@ -506,6 +506,40 @@ __device__ __forceinline__ void bit_update_pair_first(double *Mt, double *L, con
     else rput(true, -2 - loc1, o1[0]);
 }
 
+// ... and NB bits at once (the four positions of a chunk): all NB (D - 1) slot rows in flight before anything is computed.
+// The variable sweep waits for scattered rows; a wave that asks for 6 of them at a time leaves the fabric idle.
+template <int D, int NB, bool TF, class RGet, class RPut>
+__device__ __forceinline__ void bit_update_multi_first(double *Mt, double *L, const int (&pos)[NB][D], const int (&loc)[NB], double r,
+                                                       RGet &&rget, RPut &&rput, double (&T)[NB])
+{
+    double c[NB][D];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+        for (int k = 1; k < D; ++k) c[b][k] = ldm(Mt + (size_t)pos[b][k] * kTile);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (loc[b] == -1) c[b][0] = ldm(Mt + (size_t)pos[b][0] * kTile);
+        else if (loc[b] >= 0) c[b][0] = L[(size_t)loc[b] * kTile];
+        else c[b][0] = rget(-2 - loc[b]);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (TF) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) c[b][k] = (1.0 - c[b][k]) / (1.0 + c[b][k]);   // :147
+        }
+        double o[D];
+        T[b] = bit_compute_exact<D>(c[b], r, o);
+#pragma unroll
+        for (int k = D - 1; k >= 1; --k) stm(Mt + (size_t)pos[b][k] * kTile, o[k]);
+        if (loc[b] == -1) stm(Mt + (size_t)pos[b][0] * kTile, o[0]);
+        else if (loc[b] >= 0) L[(size_t)loc[b] * kTile] = o[0];
+        else rput(true, -2 - loc[b], o[0]);
+    }
+}
+
 // Register budget: teams run one or two workgroups per CU (team_geometry() on the host), so the narrow-degree
 // instantiation may have 128 VGPRs instead of the tile kernel's 80 (three workgroups per CU) -- under 80 it spilled.
 template <int DC, int DV, int THREADS, bool LROWS = false>
@@ -753,6 +787,24 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
                     const int *const vt = csc2csr + (size_t)q * VT;
                     const TeamVRec<DV> A = team_vrec_load<DV>(vt), B = team_vrec_load<DV>(vt + VT), C = team_vrec_load<DV>(vt + 2 * VT),
                                        D = team_vrec_load<DV>(vt + 3 * VT);
+                    if (tp.pairs & 2) {
+                        int rest = -1;                        // stays -1: the edges 1 ... DV-1 of all four are rows of the slot
+#pragma unroll
+                        for (int k = 1; k < DV; ++k) rest &= A.lrow[k] & B.lrow[k] & C.lrow[k] & D.lrow[k];
+                        if (rest == -1) {
+                            int ps[4][DV];
+#pragma unroll
+                            for (int k = 0; k < DV; ++k) { ps[0][k] = A.pos[k]; ps[1][k] = B.pos[k]; ps[2][k] = C.pos[k]; ps[3][k] = D.pos[k]; }
+                            const int lc[4] = {A.lrow[0], B.lrow[0], C.lrow[0], D.lrow[0]};
+                            double T[4];
+                            bit_update_multi_first<DV, 4, TF>(Mt, Lr, ps, lc, r, rget, rput, T);
+                            decide(A.bit & 0x7fffffff, T[0]);
+                            decide(B.bit & 0x7fffffff, T[1]);
+                            decide(C.bit & 0x7fffffff, T[2]);
+                            decide(D.bit & 0x7fffffff, T[3]);
+                            return;
+                        }
+                    }
                     two(A, B);
                     two(C, D);
                     return;

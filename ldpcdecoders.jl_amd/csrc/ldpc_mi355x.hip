@@ -375,7 +375,7 @@ struct ldpc_bp_decoder {
     size_t team_cache = (size_t)240 << 20;   // LDPC_TEAM_CACHE_MIB: message slots in flight that persistent teams may hold (team_fit())
     int team_xcds = 0;        // LDPC_TEAM_XCDS: XCDs that host persistent teams, fixed (experiments; 0 = team_fit() chooses)
     int team_dynamic = 1;     // LDPC_TEAM_DYNAMIC: a member's waves take its chunks from a counter in LDS (0: every W-th)
-    int team_pairs = 1;       // LDPC_TEAM_PAIRS: two nodes of the full degree are loaded together
+    int team_pairs = 3;       // LDPC_TEAM_PAIRS: bit 0: two nodes of the full degree are loaded together; bit 1: the four bits of a position chunk (rows-on-chip kernels)
     int team_ahead_from = 2;  // LDPC_TEAM_AHEAD_FROM: first iteration whose test may ride with the next check sweep
     int team_ahead = 32;      // LDPC_TEAM_AHEAD: active lanes from which on a team starts the next check sweep with the convergence
                               // test still under way (two team barriers an iteration instead of three); 0 = never
@@ -774,7 +774,7 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     if (const char *e = exp_env("LDPC_TEAM_CACHE_KIB")) d->team_cache = (size_t)std::max(0, std::atoi(e)) << 10;   // (tests: persistent teams on small graphs)
     if (const char *e = exp_env("LDPC_TEAM_DYNAMIC")) d->team_dynamic = std::atoi(e) != 0;
     if (const char *e = exp_env("LDPC_TEAM_XCDS")) d->team_xcds = std::max(1, std::min(8, std::atoi(e)));
-    if (const char *e = exp_env("LDPC_TEAM_PAIRS")) d->team_pairs = std::atoi(e) != 0;
+    if (const char *e = exp_env("LDPC_TEAM_PAIRS")) d->team_pairs = std::atoi(e) & 3;   // (bit 1: four bits at once in the variable sweep)
     if (const char *e = exp_env("LDPC_TEAM_AHEAD")) d->team_ahead = std::max(0, std::min(65, std::atoi(e)));
     if (const char *e = exp_env("LDPC_TEAM_AHEAD_FROM")) d->team_ahead_from = std::max(1, std::atoi(e));
     if (const char *e = exp_env("LDPC_TEAM_REGS")) d->team_regs = std::max(0, std::min(kTeamRegRows, std::atoi(e)));
