@@ -47,6 +47,9 @@
 #ifndef LDPC_TEAM_TFORM   // 1 = the rows-on-chip instantiations make the division of :147 in the variable sweep (0: experiments)
 #define LDPC_TEAM_TFORM 0
 #endif
+#ifndef LDPC_TEAM_TEST_DIRECT   // 1: the waves of a member OR their share of the convergence test into the team's word directly
+#define LDPC_TEAM_TEST_DIRECT 1
+#endif
 #ifndef LDPC_TEAM_SLEEP   // s_sleep argument between two polls of the arrival counter (x64 cycles)
 #define LDPC_TEAM_SLEEP 16
 #endif
@@ -859,6 +862,11 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
             mism |= par ^ syn[i];
         }
         mism = wave_or(mism);
+#if LDPC_TEAM_TEST_DIRECT
+        // every wave tells the team by itself (an atomic nobody waits for; the next team barrier makes it visible):
+        // gathering the member's words in LDS first cost a workgroup barrier in the middle of every iteration
+        if (lane == 0 && mism) __hip_atomic_fetch_or(&mw[it_t - 1], mism, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
         if (lane == 0) sh_mism[w] = mism;
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -867,6 +875,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
             for (int q = 0; q < W; ++q) part |= sh_mism[q];
             if (part) __hip_atomic_fetch_or(&mw[it_t - 1], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+#endif
     };
     // ---- the verdict of that test (after a team barrier): who stopped, and with which decisions
     auto verdict = [&](const int it_t, const u64 *em_t) {
