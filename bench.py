@@ -169,7 +169,8 @@ def roofline_object(dec, args, kname, last_kernel, nnz, s_checks, n, batch, achi
     default_size = not args.batch and not args.per
     traffic, traffic_src = pmc_traffic(args.workload, kname) if default_size else (None, None)
     slots = int(info.resident_tiles // max(info.last_team_size, 1)) if last_kernel == 4 else 0
-    slot_bytes = slots * nnz * 512
+    rows_on_chip = int(getattr(info, "last_rows_on_chip", 0)) if last_kernel == 4 else 0   # rows of a tile in LDS / registers: not in the slot
+    slot_bytes = slots * (nnz - rows_on_chip) * 512
     in_cache = last_kernel == 4 and 0 < slot_bytes <= INFINITY_CACHE_BYTES
     on_chip = bool(last_kernel == 2 or (last_kernel == 3 and nnz * 8 <= 150 * 1024))
     ticks = dec.phase_ticks(0)
@@ -188,7 +189,8 @@ def roofline_object(dec, args, kname, last_kernel, nnz, s_checks, n, batch, achi
         # figure (profiles/*_traffic.json) of the same workload AND kernel, named in traffic_source
         "traffic": traffic,
         "traffic_source": traffic_src,
-        "message_slots_in_flight_bytes": slot_bytes if last_kernel == 4 else None,
+        "message_slots_in_flight_bytes": slot_bytes if last_kernel == 4 else None,   # what the teams keep in the Infinity Cache
+        "message_rows_on_chip_frac": (rows_on_chip / nnz) if last_kernel == 4 else None,   # ... and what never leaves the CUs
         "alg_bytes_per_launch": alg_bytes,
         "kernel_ms": sweep_ms,
         "pack_sweep_unpack_ms": total_ms,

@@ -63,7 +63,9 @@ typedef struct ldpc_bp_info {
     int32_t last_team_size;   /* workgroups per tile of that call (1 unless last_kernel == 4) */
     int32_t last_lds_rows;    /* team kernel: message rows each member kept in its LDS in that call (0 = every row in the
                                  team's slot; regular graphs with a rows-in-LDS instantiation keep up to 312) */
-    int32_t reserved_info[3];
+    int32_t last_rows_on_chip;/* team kernel: message rows of a tile (of its nnz) that lived in the members' LDS and in their
+                                 waves' registers in that call and never touched the team's slot */
+    int32_t reserved_info[2];
 } ldpc_bp_info;
 
 /* Optional knobs; pass NULL to ldpc_bp_create for defaults.  Zero = default. */

@@ -82,7 +82,7 @@ class BPInfo(ctypes.Structure):
         ("waves_per_tile", ctypes.c_int32), ("resident_tiles", ctypes.c_int32),
         ("workspace_bytes", ctypes.c_int64),
         ("last_kernel", ctypes.c_int32), ("last_team_size", ctypes.c_int32),
-        ("last_lds_rows", ctypes.c_int32), ("reserved_info", ctypes.c_int32 * 3),
+        ("last_lds_rows", ctypes.c_int32), ("last_rows_on_chip", ctypes.c_int32), ("reserved_info", ctypes.c_int32 * 2),
     ]
 
 

@@ -584,7 +584,9 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     double *const Ldummy = Lr + (size_t)tp.rows.R * kTile;   // (RR > 0: one row past the member's LDS rows, see check_update_onchip)
     __shared__ int sh_ok;
     __shared__ unsigned int sh_deal[2];   // chunks of this member's share dealt so far beyond the waves' first: check sweep, variable sweep
+#if !LDPC_TEAM_TEST_DIRECT
     __shared__ u64 sh_mism[THREADS / 64];
+#endif
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int W = THREADS / 64;

@@ -346,6 +346,8 @@ struct ldpc_bp_decoder {
     int last_threads = 512, last_grid = 0;   // geometry of the most recent streaming launch (info)
     int last_kernel = 0, last_team = 1;      // which kernel the most recent call ran (info)
     int last_lds_rows = 0;                   // ... and how many message rows each team member kept in LDS
+    int last_rows_on_chip = 0;               // ... and how many rows of a tile lived in LDS and registers in all
+    int rows_on_chip = 0;                    // (of the tables in hand: team_rows_build())
     size_t ws_budget = 0;     // bytes the message workspace may take
     int blocks_cache[2][17];  // [want_llr][waves per tile] -> resident workgroups per CU, -1 = not queried yet
     int variant = 0;          // 0 auto, 1 HBM-streaming tile kernel, 2 LDS-resident kernel, 3 node-parallel kernel
@@ -889,6 +891,7 @@ ldpc_status ldpc_bp_get_info(const ldpc_bp_decoder *d, ldpc_bp_info *info)
     info->last_kernel = d->last_kernel;
     info->last_team_size = d->last_team;
     info->last_lds_rows = d->last_lds_rows;
+    info->last_rows_on_chip = d->last_rows_on_chip;
     return LDPC_OK;
 }
 
@@ -1227,7 +1230,7 @@ static ldpc_status team_rows_build(ldpc_bp_decoder *d, int G)
     if ((st = up(d->rows_ctab, t.ctab)) != LDPC_OK || (st = up(d->rows_vtab, t.vtab)) != LDPC_OK ||
         (st = up(d->rows_lds_edge, t.lds_edge)) != LDPC_OK || (st = up(d->rows_reg_edge, t.reg_edge)) != LDPC_OK)
         return st;
-    d->rows_G = G; d->rows_R = t.R;
+    d->rows_G = G; d->rows_R = t.R; d->rows_on_chip = (int)(t.in_lds + t.in_regs);
     d->rows_regs = rp.regs_per_wave; d->rows_static_c = rp.static_c; d->rows_static_v = rp.static_v;
     if (exp_env("LDPC_TEAM_DEBUG"))
         std::fprintf(stderr, "[ldpc] team rows: %d members, %d LDS rows each at most, %zu of %d edges in LDS, %zu in registers (%d per wave at most; static chunks %d / %d)\n",
@@ -1473,7 +1476,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         const int logS = d->lds_logS[want_llr_early ? 1 : 0];
         const int64_t ngroups64 = (batch + (1ll << logS) - 1) >> logS;
         if (ngroups64 > (1ll << 30)) return fail(LDPC_ERR_UNSUPPORTED, "batch too large for one call");
-        d->last_kernel = 2; d->last_team = 1; d->last_lds_rows = 0;
+        d->last_kernel = 2; d->last_team = 1; d->last_lds_rows = 0; d->last_rows_on_chip = 0;
         LdsParams lp{};
         lp.s = (int)s; lp.n = (int)n; lp.nnz = (int)d->nnz; lp.max_iters = (int)d->max_iters;
         lp.logS = logS; lp.ngroups = (int)ngroups64; lp.batch = batch;
@@ -1541,7 +1544,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         const size_t stride = (std::max<size_t>((size_t)d->nnz, 1) + 63) & ~(size_t)63;   // 512-byte aligned slots
         ldpc_status nst = d->node_msg.ensure(mlds ? 64 : (size_t)ngrid * stride * sizeof(double));
         if (nst != LDPC_OK) return nst;
-        d->last_kernel = 3; d->last_team = 1; d->last_lds_rows = 0;
+        d->last_kernel = 3; d->last_team = 1; d->last_lds_rows = 0; d->last_rows_on_chip = 0;
         NodeParams np{};
         np.s = (int)s; np.n = (int)n; np.nnz = (int)d->nnz; np.max_iters = (int)d->max_iters;
         np.batch = batch; np.r = d->per / (1 - d->per);
@@ -1638,7 +1641,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     d->last_grid = team > 1 ? plan.nteams * team : grid;   // (teams: the workgroups that take part; on an XCD that hosts no team the blocks leave at once)
     d->last_kernel = team > 1 ? 4 : 1;
     d->last_team = team;
-    d->last_lds_rows = 0;
+    d->last_lds_rows = 0; d->last_rows_on_chip = 0;
     const size_t slot_stride_bytes = std::max<size_t>((size_t)d->nnz, 1) * kTile * sizeof(double) + slot_pad_bytes();
     if ((st = ensure_workspace(d, (size_t)grid * slot_stride_bytes, grid, slot_stride_bytes, stream)) != LDPC_OK)
         return st;
@@ -1823,7 +1826,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             int occ_rows = 0;
             if (tkr && d->prepare_kernel((const void *)tkr, LDPC_TEAM_THREADS, need, &occ_rows) == LDPC_OK && occ_rows >= 1) {
                 tk = tkr; team_lds = need;
-                d->last_lds_rows = d->rows_R;
+                d->last_lds_rows = d->rows_R; d->last_rows_on_chip = d->rows_on_chip;
                 tp.rows.lds_edge = (const int *)d->rows_lds_edge.p;
                 tp.rows.R = d->rows_R;
                 tp.rows.reg_edge = (const int *)d->rows_reg_edge.p;
@@ -1842,7 +1845,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             (void)hipGetLastError();
             d->team_max = 1;
             threads = tile_threads; grid = tile_grid;
-            d->last_kernel = 1; d->last_team = 1; d->last_lds_rows = 0; d->last_grid = grid; d->last_threads = threads;
+            d->last_kernel = 1; d->last_team = 1; d->last_lds_rows = 0; d->last_rows_on_chip = 0; d->last_grid = grid; d->last_threads = threads;
             if ((st = ensure_workspace(d, (size_t)grid * slot_stride_bytes, grid, slot_stride_bytes, stream)) != LDPC_OK) return st;
             p.msg = (double *)d->msg.p;
             kfn = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, threads);

@@ -158,6 +158,9 @@ def test_other_regular_codes_keep_rows_in_lds_full_batch(ldpc, gpu, n, wr, wc, b
     dec.last_status()
     info = dec.info()
     assert info.last_kernel == 4 and info.last_team_size >= 16 and info.last_lds_rows >= 200, (info.last_kernel, info.last_team_size, info.last_lds_rows)
+    # every bit's first edge (the whole checks of the first block) is on chip, in LDS or in registers, as far as the
+    # members' capacity (312 + 8 x 32 rows each) goes
+    assert info.last_rows_on_chip >= 0.9 * min(H.nnz // wc, info.last_team_size * 568), (info.last_rows_on_chip, H.nnz, info.last_team_size)
     dec.close()
     conv_b = conv.bool()
     for b0 in range(0, batch, 4096):
