@@ -241,6 +241,8 @@ def test_team_rows_in_lds_change_nothing(ldpc, gpu, per, monkeypatch):
     """(4,8)-regular graphs: the members of a persistent team keep the message rows that only they touch in LDS (a bit is
     dealt to a member that owns one of its checks; bp_team_kernels.hpp TeamRows).  With the rows in LDS (default), with
     with rows in the waves' registers as well (up to 32 or 7 a wave; bp_team_kernels.hpp "Rows in REGISTERS") or not, with
+    the on-chip rows gathered into whole checks (default), spread as in round 2, or whole checks only; the upper waves
+    walking forwards or backwards; nodes loaded singly, in pairs or four bits at a time; with
     every row in the slot (LDPC_TEAM_ROWS=0) and through the tile kernel: the same bits, LLRs included -- at an error
     rate where tiles finish early, one where they hand stragglers on (the rows in LDS are written back for that) and
     one where nothing converges."""
@@ -250,9 +252,17 @@ def test_team_rows_in_lds_change_nothing(ldpc, gpu, per, monkeypatch):
     H = ldpc.codes.parity_check_csc(n, 8, 4)
     syn = torch.from_numpy(ldpc.codes.syndromes_of(H, ldpc.codes.random_errors(n, B, per, seed=77))).cuda()
     res = []
-    for variant, rows, regs in ((4, "1", "32"), (4, "1", "0"), (4, "1", "7"), (4, "0", "32"), (1, "1", "32")):
+    # (kernel variant, rows on chip, register rows per wave, how bits are dealt: 1 = to the owner of their first check /
+    #  0 = most room / 2 = whole checks only, mirrored order of the upper waves, nodes loaded 2 (1) or 2 and 4 (3) at a time)
+    for variant, rows, regs, conc, flip, pairs in ((4, "1", "32", "1", "3", "3"), (4, "1", "0", "1", "3", "3"), (4, "1", "7", "1", "3", "3"),
+                                                   (4, "0", "32", "1", "3", "3"), (1, "1", "32", "1", "3", "3"),
+                                                   (4, "1", "32", "0", "0", "1"), (4, "1", "32", "2", "1", "3"), (4, "1", "0", "0", "2", "0"),
+                                                   (4, "1", "5", "2", "3", "1")):
         monkeypatch.setenv("LDPC_TEAM_ROWS", rows)
-        monkeypatch.setenv("LDPC_TEAM_REGS", regs)          # rows in the waves' accumulator registers on top (0 = LDS only)
+        monkeypatch.setenv("LDPC_TEAM_REGS", regs)          # rows in the waves' top registers on top (0 = LDS only)
+        monkeypatch.setenv("LDPC_TEAM_CONCENTRATE", conc)
+        monkeypatch.setenv("LDPC_TEAM_FLIP", flip)
+        monkeypatch.setenv("LDPC_TEAM_PAIRS", pairs)
         dec = ldpc.BeliefPropagationDecoder(H, per, 30, kernel_variant=variant)
         err = torch.empty((B, n), dtype=torch.uint8, device="cuda")
         conv = torch.empty(B, dtype=torch.uint8, device="cuda")

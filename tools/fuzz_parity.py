@@ -76,7 +76,7 @@ while time.time() - t0 < budget:
         # up and tiles must carry on), how many stragglers the node kernel finishes
         for k in ("LDPC_DEFER_T0", "LDPC_DEFER_T1", "LDPC_DEFER_CAP_TILES", "LDPC_NODE_TAKE_MAX", "LDPC_TEAM_CACHE_KIB",
                   "LDPC_TEAM_DYNAMIC", "LDPC_TEAM_PAIRS", "LDPC_TEAM_ROWS", "LDPC_TEAM_AHEAD", "LDPC_TEAM_REGS", "LDPC_TEAM_STATIC",
-                  "LDPC_TEAM_MAX"):
+                  "LDPC_TEAM_MAX", "LDPC_TEAM_CONCENTRATE", "LDPC_TEAM_FLIP"):
             os.environ.pop(k, None)
         # running ahead (two team barriers an iteration on quiet tiles), rows in the waves' accumulator registers and how
         # much of a member's share its waves own by right; few members on the mid-size graphs so that every wave owns chunks
@@ -95,7 +95,13 @@ while time.time() - t0 < budget:
         if rng.random() < 0.5:
             os.environ["LDPC_TEAM_DYNAMIC"] = str(int(rng.integers(0, 2)))
         if rng.random() < 0.5:
-            os.environ["LDPC_TEAM_PAIRS"] = str(int(rng.integers(0, 2)))
+            os.environ["LDPC_TEAM_PAIRS"] = str(int(rng.integers(0, 4)))   # bit 0: two nodes at a time, bit 1: four bits
+        # which rows end up on chip (0: most room, 1: whole checks of the first block, 2: only whole checks), and the
+        # order in which the upper waves walk their static chunks
+        if rng.random() < 0.5:
+            os.environ["LDPC_TEAM_CONCENTRATE"] = str(int(rng.integers(0, 3)))
+        if rng.random() < 0.5:
+            os.environ["LDPC_TEAM_FLIP"] = str(int(rng.integers(0, 4)))
         if rng.random() < 0.3:
             os.environ["LDPC_TEAM_ROWS"] = "0"      # regular graphs: no rows in LDS / registers
         if rng.random() < 0.7:
