@@ -23,11 +23,12 @@
 //
 // Teams are PERSISTENT: team t starts on tile t and then takes tiles from a queue until the batch is
 // done, always in ITS OWN message slot (iteration 1 reads nothing, so a slot needs no clearing between
-// tiles).  With one team per XCD the messages in flight are 7 or 8 slots: for the n = 16384 code 7 x 32 MiB, which
-// the 256 MiB Infinity Cache keeps (tools/mall_probe.hip: the in-place sweeps run at 8.8 TB/s on a working set of
-// <= 256 MiB against 5.1 ... 5.6 TB/s from HBM; the host plans the teams inside a budget of 240 MiB, team_fit() --
-// eight slots of 32 MiB fill the cache to the brim and every team is a fifth slower).  The tile kernel cannot do
-// that: one workgroup per tile means 768 tiles = 24 GiB in flight.
+// tiles).  With one team per XCD the messages in flight are 7 or 8 slots, which the 256 MiB Infinity Cache keeps
+// (tools/mall_probe.hip: the in-place sweeps run at 8.8 TB/s on a working set of <= 256 MiB against 5.1 ... 5.6 TB/s
+// from HBM; the host plans the teams inside a budget of 240 MiB, team_fit() -- eight WHOLE slots of the n = 16384
+// code, 8 x 32 MiB, fill the cache to the brim and every team is a fifth slower: seven teams then; with a quarter of
+// a tile's rows on chip, "Rows in REGISTERS" below, eight fit).  The tile kernel cannot do that: one workgroup per
+// tile means 768 tiles = 24 GiB in flight.
 //
 // Within a sweep a member has a share of the node chunks (every G-th chunk), and its waves take the chunks of
 // that share one after the other from a counter in LDS (a wave's first chunk is its by right): the 8 waves of
@@ -130,7 +131,12 @@ __device__ __forceinline__ TeamVRec<DV> team_vrec_load(const int *__restrict__ v
 //   * accumulator registers a0 ... a63 through the same index mode (gfx950 honours it for v_accvgpr_read / _write:
 //     tools/agpr_index_probe.hip): once a kernel has accumulator registers at all, the register allocator parks its
 //     own values in them between the asm statements -- 1,207 such moves, wrong results, the check sweep 20 us slower.
-// With them 25 % of the rows of a (4,8)-regular tile are on chip instead of 15 %.
+// With them 27 % of the rows of a (4,8)-regular tile are on chip instead of 15 %, eight slots fit the cache budget
+// instead of seven, and -- the host gathers the on-chip rows into WHOLE CHECKS (team_rows_tables(): a bit goes to
+// the owner of its first check) -- a quarter of the checks is updated without touching memory (check_update_regs, or
+// check_update_exact on the LDS rows) and every bit has exactly its first edge on chip (bit_update_pair_first /
+// bit_update_multi_first).  The general updates below (a pointer per edge; check_update_onchip, bit_update_onchip)
+// remain for graphs and knob settings that spread the on-chip rows.
 constexpr int kTeamRegRows = 32;
 #define LDPC_TEAM_TOP_VGPRS                                                                                                      \
     "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207",     \

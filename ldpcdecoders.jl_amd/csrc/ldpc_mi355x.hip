@@ -1240,9 +1240,11 @@ static ldpc_status team_rows_build(ldpc_bp_decoder *d, int G)
 
 // Persistent teams whose message slots in flight stay inside the cache budget (LDPC_TEAM_CACHE_MIB, default 240 of
 // the Infinity Cache's 256 MiB): how many XCDs host teams (8, 7 or 6), how many teams each, how many members a
-// team -- the combination that gives most workgroups a tile.  For the n = 16384 code (32 MiB a slot) that is SEVEN
-// teams of 32: with an eighth the slots fill the cache to the brim and every team is a fifth slower (full batch,
-// 50 iterations: 1111 ms on 8 XCDs, 1011 ms on 7, 1158 ms on 6).  false: nothing fits, not even the second tier below.
+// team -- the combination that gives most workgroups a tile.  For the n = 16384 code (32 MiB a slot) with every row in
+// the slot that is SEVEN teams of 32: with an eighth the slots fill the cache to the brim and every team is a fifth
+// slower (full batch, 50 iterations, round 2: 1111 ms on 8 XCDs, 1011 ms on 7, 1158 ms on 6); with the rows a member
+// keeps on chip counted off the slot (`rows`: 312 in LDS + 8 x 32 in registers) it is EIGHT (round 3: 712 ms).
+// false: nothing fits, not even the second tier below.
 static bool team_fit(const TeamPlanIn &in, int64_t ntiles, bool rows, int *xcds, int *tpx, int *G)
 {
     const int per_xcd = in.per_xcd, gcap = in.gcap;
