@@ -69,6 +69,20 @@ constexpr int min_waves_per_simd()
     return want;
 }
 
+// After the row loads of a node group (experiment, -DLDPC_LOADS_FIRST=1): keep the machine scheduler from sinking the
+// later loads below the first node's arithmetic.  It does sink them -- the second check's 8 loads of a pair come ~130
+// instructions after the first's -- and forcing all 16 to the front measured NOTHING on any workload
+// (profiles/r03_loads_first_ab.txt): a wave's memory parallelism is not what bounds the team kernel's sweeps.
+#ifndef LDPC_LOADS_FIRST
+#define LDPC_LOADS_FIRST 0
+#endif
+__device__ __forceinline__ void loads_first()
+{
+#if LDPC_LOADS_FIRST
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 __device__ __forceinline__ double ldm(const double *p)
 {
 #if LDPC_NT
@@ -224,6 +238,7 @@ __device__ __forceinline__ void check_update_pair(double *M0, double *M1, double
     for (int k = 0; k < D; ++k) m0[k] = ldm(M0 + (size_t)k * kTile);
 #pragma unroll
     for (int k = 0; k < D; ++k) m1[k] = ldm(M1 + (size_t)k * kTile);
+    loads_first();
     double a[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) a[k] = 2.0 / (1.0 + m0[k]) - 1.0;
@@ -353,6 +368,7 @@ __device__ __forceinline__ void bit_update_pair_v(double *Mt, const int (&pos0)[
     for (int k = 0; k < D; ++k) c0[k] = ldm(Mt + at0[k]);
 #pragma unroll
     for (int k = 0; k < D; ++k) c1[k] = ldm(Mt + at1[k]);
+    loads_first();
     if (TF) {
 #pragma unroll
         for (int k = 0; k < D; ++k) { c0[k] = (1.0 - c0[k]) / (1.0 + c0[k]); c1[k] = (1.0 - c1[k]) / (1.0 + c1[k]); }   // :147

@@ -497,6 +497,7 @@ __device__ __forceinline__ void bit_update_pair_first(double *Mt, double *L, con
     if (loc1 == -1) c1[0] = ldm(Mt + at1[0]);
     else if (loc1 >= 0) c1[0] = L[(size_t)loc1 * kTile];
     else c1[0] = rget(-2 - loc1);
+    loads_first();
     if (TF) {
 #pragma unroll
         for (int k = 0; k < D; ++k) { c0[k] = (1.0 - c0[k]) / (1.0 + c0[k]); c1[k] = (1.0 - c1[k]) / (1.0 + c1[k]); }   // :147
@@ -533,6 +534,7 @@ __device__ __forceinline__ void bit_update_multi_first(double *Mt, double *L, co
         else if (loc[b] >= 0) c[b][0] = L[(size_t)loc[b] * kTile];
         else c[b][0] = rget(-2 - loc[b]);
     }
+    loads_first();
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         if (TF) {
