@@ -1083,6 +1083,9 @@ static TeamRowTables team_rows_tables(int n, int s, int nnz, int dc, int dv, con
     for (int j = 0; j < n; ++j) bits_of[(size_t)member_of_bit[(size_t)j]].push_back(j);
     std::vector<int> bit((size_t)n, -1), reg_of((size_t)nnz, -1);
     std::vector<std::vector<int>> reg_rows((size_t)G * W);       // per (member, wave): the CSR rows held in registers
+    // (whole checks: a wave's registers take a multiple of dc rows, so that no check is split between registers and LDS --
+    //  a split check is all on chip and still pays the general update: 30 of 32 rows a wave for dc = 6 and 10)
+    const int RCw = rp.concentrate ? RC / dc * dc : RC;
     for (int m = 0; m < G; ++m) {
         std::vector<std::vector<int>> spos((size_t)W);           // static positions of each wave, ascending, not yet taken
         for (int p : pos_of[(size_t)m]) { const int w = pos_wave(p); if (w >= 0) spos[(size_t)w].push_back(p); }
@@ -1095,7 +1098,7 @@ static TeamRowTables team_rows_tables(int n, int s, int nnz, int dc, int dv, con
                     const int q = c2r[(size_t)dv * j + k], i = q / dc;
                     if (check_owner(i) != m) continue;
                     const int w = check_wave(i);
-                    if (w < 0 || (int)reg_rows[(size_t)m * W + w].size() >= RC || snext[(size_t)w] >= spos[(size_t)w].size()) continue;
+                    if (w < 0 || (int)reg_rows[(size_t)m * W + w].size() >= RCw || snext[(size_t)w] >= spos[(size_t)w].size()) continue;
                     bit[(size_t)spos[(size_t)w][snext[(size_t)w]++]] = j;
                     reg_rows[(size_t)m * W + w].push_back(q);
                     placed[b] = 1;

@@ -254,7 +254,7 @@ def test_team_rows_in_lds_change_nothing(ldpc, gpu, per, monkeypatch):
     res = []
     # (kernel variant, rows on chip, register rows per wave, how bits are dealt: 1 = to the owner of their first check /
     #  0 = most room / 2 = whole checks only, mirrored order of the upper waves, nodes loaded 2 (1) or 2 and 4 (3) at a time)
-    for variant, rows, regs, conc, flip, pairs in ((4, "1", "32", "1", "3", "3"), (4, "1", "0", "1", "3", "3"), (4, "1", "7", "1", "3", "3"),
+    for variant, rows, regs, conc, flip, pairs in ((4, "1", "32", "1", "3", "3"), (4, "1", "0", "1", "3", "3"), (4, "1", "7", "0", "3", "3"),
                                                    (4, "0", "32", "1", "3", "3"), (1, "1", "32", "1", "3", "3"),
                                                    (4, "1", "32", "0", "0", "1"), (4, "1", "32", "2", "1", "3"), (4, "1", "0", "0", "2", "0"),
                                                    (4, "1", "5", "2", "3", "1")):

@@ -115,6 +115,31 @@ def test_row_tables_describe_the_graph(n, members, wr, wc, regs):
         assert in_regs >= 0.5 * regs_eff * W * members, "most register rows should be in use on a graph of this size"
 
 
+@pytest.mark.parametrize("n,members,wr,wc", [(16384, 32, 8, 4), (16380, 23, 6, 3), (16000, 32, 10, 5)])
+def test_on_chip_rows_are_whole_checks_of_the_first_block(n, members, wr, wc):
+    """What the fast paths of the kernel live on (bp_team_kernels.hpp check_update_regs, bit_update_pair_first /
+    bit_update_multi_first; ldpc_mi355x.hip team_rows_tables(): a bit goes to the owner of its FIRST check): in a
+    Gallager code the rows a member keeps on chip are its first-block checks, complete, as far as its capacity (312 rows
+    in LDS, 8 x 32 in registers) goes -- a check with all its rows in one wave's registers or all in LDS needs no pointer
+    per edge, and every bit has at most its first edge on chip plus a stray one now and then."""
+    H, R, vtab, ctab, lds_edge, reg_edge, (static_c, static_v, regs_eff) = tables(n, members, wr, wc, regs=RREGS)
+    s = H.shape[0]
+    full = (1 << wr) - 1
+    whole_regs = int((ctab[:, 2] == full).sum())
+    whole_lds = int((ctab[:, 0] == full).sum())
+    first_block = s // wc                                         # checks of the first block: wr consecutive bits each
+    capacity = members * (RMAX + W * RREGS) // wr                  # whole checks the members can hold
+    assert whole_regs + whole_lds >= 0.9 * min(first_block, capacity), (whole_regs, whole_lds, first_block, capacity)
+    assert whole_regs >= 0.9 * min(first_block, members * W * (RREGS // wr)), whole_regs
+    # whole checks on chip are first-block checks (check index < s / wc)
+    assert int(np.flatnonzero((ctab[:, 0] | ctab[:, 2]) == full).max()) < first_block
+    # every bit: edges 1 ... wc-1 in the slot except for strays (< 15 % of the bits); the first edge on chip for most
+    loc = vtab[:, wc:2 * wc]
+    rest_on_chip = (loc[:, 1:] != -1).any(axis=1)
+    assert rest_on_chip.mean() < 0.15, rest_on_chip.mean()
+    assert (loc[:, 0] != -1).mean() >= 0.9 * min(1.0, capacity / first_block), (loc[:, 0] != -1).mean()
+
+
 def test_only_regular_graphs_with_an_instantiation():
     buf = np.zeros(1 << 20, dtype=np.int32)
     shape, deg = (ctypes.c_int32 * 5)(), (ctypes.c_int32 * 2)()
