@@ -953,12 +953,14 @@ static bool takes_lds_kernel(const ldpc_bp_decoder *d, bool want_llr)
 {
     return d->variant != 1 && d->variant != 3 && d->variant != 4 && d->lds_logS[want_llr ? 1 : 0] >= 0;
 }
+constexpr int64_t kTeamMinRowsOne = 1500;   // message rows per sweep a member of the ONLY team of an XCD must have (team_geometry())
+
 // Workgroups per tile the team kernel (bp_team_kernels.hpp) would use for this batch; 1 = it does not apply.
 // Teams are formed inside one XCD (1/8 of the CUs), two workgroups per CU so that every member is
 // resident with room to spare (the register budget admits three), and a member should have >= 2048
 // message rows per sweep to pay for the three team barriers of an iteration.
 // (per_xcd: team workgroups one XCD hosts; gcap: members per tile at most; false = no teams for this decoder)
-static bool team_geometry(ldpc_bp_decoder *d, bool want_llr, int *per_xcd, int *gcap)
+static bool team_geometry(ldpc_bp_decoder *d, bool want_llr, int *per_xcd, int *gcap, int *gcap_one = nullptr)
 {
     if (!(d->variant == 0 || d->variant == 4) || d->team_max < 2 || d->wpt_fixed || d->resident_fixed || d->nnz <= 0) return false;
     static const int per_cu_want = [] { const char *e = exp_env("LDPC_TEAM_PER_CU"); return e ? std::max(1, std::min(3, std::atoi(e))) : 2; }();
@@ -972,6 +974,12 @@ static bool team_geometry(ldpc_bp_decoder *d, bool want_llr, int *per_xcd, int *
     static const int64_t min_rows = [] { const char *e = exp_env("LDPC_TEAM_MIN_ROWS"); return e ? std::max<int64_t>(1, std::atoll(e)) : (int64_t)2048; }();
     *per_xcd = per_cu * (d->num_cus / 8);
     *gcap = (int)std::min<int64_t>(d->team_max, std::max<int64_t>(1, d->nnz / min_rows));   // (LDPC_TEAM_MIN_ROWS=1: tests put teams on tiny graphs)
+    // ONE persistent team per XCD may have more members than that -- all the CUs of its XCD -- down to 1500 rows a member
+    // (round 3, full batch of 50 iterations: (3,6) n = 16380 with 32 members of 1535 rows 528 ms, with 23 of 2136 rows
+    // 633 ms; (4,8) n = 12288: 139 against 155 ms for 16,384 syndromes; but n = 8192, 1024 rows a member: 96 ms against
+    // 90 ms for sixteen teams of 16 -- profiles/r03_minrows_ab.txt)
+    static const bool min_rows_set = exp_env("LDPC_TEAM_MIN_ROWS") != nullptr;
+    if (gcap_one) *gcap_one = min_rows_set ? *gcap : (int)std::min<int64_t>(d->team_max, std::max<int64_t>(*gcap, d->nnz / kTeamMinRowsOne));
     return *per_xcd >= 1;
 }
 
@@ -991,6 +999,7 @@ struct TeamPlanIn {
     int reg_rows = 0;          // rows a member's waves keep in registers on top of the LDS (W x regs per wave)
     int num_cus = 256;
     int per_xcd = 0, gcap = 0; // team_geometry(): team workgroups one XCD hosts, members per team at most
+    int gcap_one = 0;          // ... members at most of a persistent team that has an XCD to itself (>= gcap)
 };
 
 // What a member is expected to keep on chip (a bit dealt to a member that owns one of its dv checks: 1 / dv of the edges
@@ -1264,7 +1273,7 @@ static bool team_fit(const TeamPlanIn &in, int64_t ntiles, bool rows, int *xcds,
         for (int t = 1; t <= per_xcd / 3; ++t) {
             if ((size_t)x * (size_t)t * (state - (rows ? state / (size_t)std::max(in.rows_dv, 1) : 0)) > cache) break;   // (1 / dv at most can be in LDS)
             if (t > 1 && (int64_t)x * (t - 1) >= ntiles) break;            // no more teams than tiles
-            const int g = std::min(gcap, per_xcd / t);
+            const int g = std::min(t == 1 ? std::max(gcap, in.gcap_one) : gcap, per_xcd / t);
             if (g < 3) break;
             // rows that the members keep in LDS are not in the cache
             if ((size_t)x * (size_t)t * (state - (rows ? (size_t)g * team_rows_expected(in, g) * kTile * sizeof(double) : 0)) > cache) continue;
@@ -1342,21 +1351,21 @@ static TeamPlan team_plan_pure(const TeamPlanIn &in, int64_t batch)
     return pl;
 }
 
-static TeamPlanIn team_plan_in(const ldpc_bp_decoder *d, int per_xcd, int gcap)
+static TeamPlanIn team_plan_in(const ldpc_bp_decoder *d, int per_xcd, int gcap, int gcap_one = 0)
 {
     TeamPlanIn in;
     in.nnz = d->nnz; in.max_iters = d->max_iters; in.cache = d->team_cache; in.xcds_forced = d->team_xcds;
     in.team_max_set = d->team_max_set; in.rows_possible = team_rows_possible(d); in.rows_dv = std::max(d->rows_dv, 1); in.num_cus = d->num_cus;
     in.reg_rows = in.rows_possible ? d->team_regs * (LDPC_TEAM_THREADS / 64) : 0;
-    in.per_xcd = per_xcd; in.gcap = gcap;
+    in.per_xcd = per_xcd; in.gcap = gcap; in.gcap_one = std::max(gcap, gcap_one);
     return in;
 }
 
 static TeamPlan team_plan(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
 {
-    int per_xcd = 0, gcap = 0;
-    if (!team_geometry(d, want_llr, &per_xcd, &gcap)) return TeamPlan();
-    return team_plan_pure(team_plan_in(d, per_xcd, gcap), batch);
+    int per_xcd = 0, gcap = 0, gcap_one = 0;
+    if (!team_geometry(d, want_llr, &per_xcd, &gcap, &gcap_one)) return TeamPlan();
+    return team_plan_pure(team_plan_in(d, per_xcd, gcap, gcap_one), batch);
 }
 
 // include/ldpc_mi355x_debug.h: the plan for a CPU test (an MI355X's geometry: 256 CUs, one team workgroup per CU)
@@ -1369,6 +1378,7 @@ extern "C" ldpc_status ldpc_debug_team_plan(int64_t nnz, int64_t max_iters, int6
     in.reg_rows = rows_dv > 0 ? kTeamRegRows * (LDPC_TEAM_THREADS / 64) : 0;
     in.num_cus = 256; in.per_xcd = 32;
     in.gcap = (int)std::min<int64_t>(32, std::max<int64_t>(1, nnz / 2048));
+    in.gcap_one = (int)std::min<int64_t>(32, std::max<int64_t>(in.gcap, nnz / kTeamMinRowsOne));
     const TeamPlan pl = team_plan_pure(in, batch);
     out[0] = pl.G; out[1] = pl.nteams; out[2] = pl.grid; out[3] = pl.xcds; out[4] = pl.scatter ? 1 : 0; out[5] = pl.rows ? 1 : 0;
     return LDPC_OK;

@@ -183,17 +183,20 @@ def test_team_plan_by_graph_and_batch():
     # up to four tiles: one team per tile, members dealt over all XCDs, up to 64 of them, no rows in LDS
     assert plan(c3, 1) == dict(members=64, teams=1, grid=64, xcds=8, scatter=1, rows=0)
     assert plan(c3, 256) == dict(members=64, teams=4, grid=256, xcds=8, scatter=1, rows=0)
-    # 28 MiB slots (n = 14336): eight fit the budget
-    assert plan(57344, 65536)["teams"] == 8 and plan(57344, 65536)["members"] == 28
+    # 28 MiB slots (n = 14336): eight fit the budget; the one team of an XCD takes all its 32 CUs as long as a member
+    # keeps >= 1500 rows per sweep (1792 here), not only 28 of them (>= 2048 rows)
+    assert plan(57344, 65536)["teams"] == 8 and plan(57344, 65536)["members"] == 32
+    assert plan(49152, 65536) == dict(members=32, teams=8, grid=256, xcds=8, scatter=0, rows=1)      # n = 12288: 1536 rows
+    assert plan(40960, 65536)["members"] == 27 and plan(40960, 65536)["teams"] == 8                  # n = 10240: 1280 rows a member would be too few
     # 16 MiB slots (n = 8192): members of >= 2048 rows are 16 at most, so two teams per XCD -- on seven XCDs with whole
     # slots (224 MiB), on all eight with the rows on chip taken off
     p = plan(32768, 65536, regular=0)
     assert p["members"] == 16 and p["teams"] == 14 and p["xcds"] == 7 and p["grid"] == 256
     p = plan(32768, 65536)
     assert p["members"] == 16 and p["teams"] == 16 and p["xcds"] == 8
-    # among combinations that give about as many workgroups a tile, the one on more XCDs: the (3,6) n = 16380 code
-    # (24 MiB slots, members of >= 2048 rows are 23 at most) takes eight teams of 23, not twelve of 16 on six XCDs
-    assert plan(49140, 65536, dv=3) == dict(members=23, teams=8, grid=184, xcds=8, scatter=0, rows=1)
+    # the (3,6) n = 16380 code (24 MiB slots): eight teams of 32 (1535 rows a member; measured 528 ms for the full batch
+    # against 633 ms with eight teams of 23 -- members of >= 2048 rows --, and twelve teams of 16 on six XCDs before that)
+    assert plan(49140, 65536, dv=3) == dict(members=32, teams=8, grid=256, xcds=8, scatter=0, rows=1)
     # 64 MiB slots (n = 32768): twice the cache -- the second tier, one persistent team per XCD
     assert plan(131072, 65536) == dict(members=32, teams=8, grid=256, xcds=8, scatter=0, rows=1)
     # 128 MiB slots (n = 65536): the tile kernel for more tiles than CUs, one team per tile below
