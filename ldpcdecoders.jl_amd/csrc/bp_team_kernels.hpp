@@ -219,7 +219,7 @@ struct TeamParams {
     // quietness alone 7 % -- the first verdict that is not quiet is usually the one that hands off.)
     u64 *errmask_alt;           // [ntiles][n] or nullptr (no running ahead: passes over packed levels)
     int ahead_min;              // active lanes from which on a quiet tile's team runs ahead (0 = never)
-    int ahead_from;             // ... and the first iteration whose test may have company (2: a verdict must have been quiet first)
+    int ahead_from;             // ... and the first iteration whose test may have company (1; 2: a verdict must have been quiet first)
 };
 constexpr unsigned int kTeamRollcallFailed = 0x80000000u;
 

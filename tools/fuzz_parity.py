@@ -14,12 +14,20 @@ os.environ.setdefault("LDPC_TEAM_MIN_ROWS", "1")   # kernel_variant 4: teams of 
 import ldpcdecoders_jl_amd as ldpc  # noqa: E402
 from oracle import BPOracle, BPOTSOracle  # noqa: E402
 
+# FUZZ_DRY=1: draw the cases and print them (index, graph, knobs) without touching the GPU or the oracle -- the draws do not
+# depend on any result, so this lists what a run with the same seed decodes; FUZZ_FROM / FUZZ_TO: only decode the cases
+# with these indices (the others are drawn and skipped); FUZZ_VERBOSE=1: one line per case BEFORE it runs (a hang names itself)
+DRY = os.environ.get("FUZZ_DRY") == "1"
+FROM, TO = int(os.environ.get("FUZZ_FROM", "0")), int(os.environ.get("FUZZ_TO", str(1 << 60)))
+VERBOSE = os.environ.get("FUZZ_VERBOSE") == "1"
+MAXCASES = int(os.environ.get("FUZZ_CASES", str(1 << 60)))
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 t0, cases, decoded = time.time(), 0, 0
 last_note = t0
-while time.time() - t0 < budget:
+while time.time() - t0 < budget and cases < MAXCASES:
+    skip = DRY or not (FROM <= cases <= TO)
     kind = rng.integers(0, 5)
     mid = False
     if kind == 0:      # Gallager regular
@@ -58,8 +66,11 @@ while time.time() - t0 < budget:
         syn = rng.integers(0, 2, (B, s)).astype(np.uint8)
     if rng.random() < 0.1 and s > 0:
         syn[rng.integers(0, B), rng.integers(0, s)] = rng.integers(2, 5)
-    oc = BPOracle(csc=(H.indptr, H.indices), shape=H.shape, per=per, max_iters=iters)
-    oerr, oconv, ollr, oits = oc.batchdecode(syn)
+    if DRY or VERBOSE:
+        print(f"case {cases}: kind {int(kind)} shape {H.shape} nnz {H.nnz} per {per} iters {iters} B {B}", flush=True)
+    if not skip:
+        oc = BPOracle(csc=(H.indptr, H.indices), shape=H.shape, per=per, max_iters=iters)
+        oerr, oconv, ollr, oits = oc.batchdecode(syn)
     for variant in (0, 1, 3, 4):
         # node kernel: messages in LDS (default for these small graphs), split between LDS and the global slot
         # at a random point (hybrid), or all in the global slot
@@ -76,12 +87,14 @@ while time.time() - t0 < budget:
         # up and tiles must carry on), how many stragglers the node kernel finishes
         for k in ("LDPC_DEFER_T0", "LDPC_DEFER_T1", "LDPC_DEFER_CAP_TILES", "LDPC_NODE_TAKE_MAX", "LDPC_TEAM_CACHE_KIB",
                   "LDPC_TEAM_DYNAMIC", "LDPC_TEAM_PAIRS", "LDPC_TEAM_ROWS", "LDPC_TEAM_AHEAD", "LDPC_TEAM_REGS", "LDPC_TEAM_STATIC",
-                  "LDPC_TEAM_MAX", "LDPC_TEAM_CONCENTRATE", "LDPC_TEAM_FLIP"):
+                  "LDPC_TEAM_MAX", "LDPC_TEAM_CONCENTRATE", "LDPC_TEAM_FLIP", "LDPC_TEAM_AHEAD_FROM"):
             os.environ.pop(k, None)
         # running ahead (two team barriers an iteration on quiet tiles), rows in the waves' accumulator registers and how
         # much of a member's share its waves own by right; few members on the mid-size graphs so that every wave owns chunks
         if rng.random() < 0.7:
             os.environ["LDPC_TEAM_AHEAD"] = str(int(rng.choice([0, 1, 20, 32, 64])))
+        if rng.random() < 0.4:
+            os.environ["LDPC_TEAM_AHEAD_FROM"] = str(int(rng.integers(1, 4)))
         if rng.random() < 0.5:
             os.environ["LDPC_TEAM_REGS"] = str(int(rng.choice([0, 5, 32])))
         if rng.random() < 0.5:
@@ -115,8 +128,20 @@ while time.time() - t0 < budget:
                   defer_threshold=int(rng.choice([0, -1, 4, 40])))
         if variant != 4 and rng.random() < 0.3:
             kw["resident_tiles"] = int(rng.integers(1, 5))
-        dec = ldpc.BeliefPropagationDecoder(H, per, iters, **kw)
         want_llr = bool(rng.random() < 0.5)
+        knobs = {k[5:]: v for k, v in os.environ.items() if k.startswith("LDPC_") and not k.startswith("LDPC_MI355X")}
+        if DRY or VERBOSE:
+            print(f"   variant {variant} {kw} llr={want_llr} {knobs}", flush=True)
+        if not skip:   # what is about to run, where a run that stalls leaves it behind (gpurun merges gpurun_out/ back)
+            try:
+                with open("gpurun_out/fuzz_current.txt", "w") as fh:
+                    fh.write(f"seed {seed} case {cases} after {time.time() - t0:.0f} s: kind {int(kind)} shape {H.shape} nnz {H.nnz} per {per} "
+                             f"iters {iters} B {B}\n   variant {variant} {kw} llr={want_llr} {knobs}\n")
+            except OSError:
+                pass
+        if skip:
+            continue
+        dec = ldpc.BeliefPropagationDecoder(H, per, iters, **kw)
         err, conv, llr, its = dec.decode_batch_host(syn, want_llr=want_llr, want_iters=True)
         ok = np.array_equal(err, oerr) and np.array_equal(conv, oconv) and np.array_equal(its, oits)
         if ok and want_llr:
@@ -132,16 +157,25 @@ while time.time() - t0 < budget:
     if kind == 1 and H.nnz > 0:      # (any degree: nodes beyond 32 / 16 edges take the unlimited kernel)
         T, C = int(rng.choice([2, 3, 9])), float(rng.choice([1.0, 2.0, 3.0]))
         pp = max(per, 1e-3) if per < 0.9 else 0.3
-        oe, ocv, oi = BPOTSOracle((H.indptr, H.indices), H.shape, pp, iters, T, C).batchdecode(syn)
         os.environ.pop("LDPC_BPOTS_FORCE_NODE", None)
         if rng.random() < 0.6:      # the node-parallel kernel (graphs beyond the LDS) or the unlimited one on a small graph
             os.environ["LDPC_BPOTS_FORCE_NODE"] = str(int(rng.integers(1, 3)))
-        d2 = ldpc.BPOTSDecoder(H, pp, iters, T=T, C=C)
-        e2, c2, i2 = d2.decode_batch_host(syn)
-        if not (np.array_equal(e2, oe) and np.array_equal(c2, ocv) and np.array_equal(i2, oi)):
-            print(f"BP-OTS MISMATCH case {cases}: shape {H.shape} nnz {H.nnz} per {pp} iters {iters} B {B} T {T} C {C}")
-            sys.exit(1)
-        d2.close()
+        if DRY or VERBOSE:
+            print(f"   BP-OTS T {T} C {C} per {pp} force {os.environ.get('LDPC_BPOTS_FORCE_NODE')}", flush=True)
+        if not skip:
+            try:
+                with open("gpurun_out/fuzz_current.txt", "w") as fh:
+                    fh.write(f"seed {seed} case {cases} after {time.time() - t0:.0f} s: BP-OTS shape {H.shape} nnz {H.nnz} per {pp} iters {iters} B {B} "
+                             f"T {T} C {C} force {os.environ.get('LDPC_BPOTS_FORCE_NODE')}\n")
+            except OSError:
+                pass
+            oe, ocv, oi = BPOTSOracle((H.indptr, H.indices), H.shape, pp, iters, T, C).batchdecode(syn)
+            d2 = ldpc.BPOTSDecoder(H, pp, iters, T=T, C=C)
+            e2, c2, i2 = d2.decode_batch_host(syn)
+            if not (np.array_equal(e2, oe) and np.array_equal(c2, ocv) and np.array_equal(i2, oi)):
+                print(f"BP-OTS MISMATCH case {cases}: shape {H.shape} nnz {H.nnz} per {pp} iters {iters} B {B} T {T} C {C}")
+                sys.exit(1)
+            d2.close()
     cases += 1
     if time.time() - last_note > 60:   # a silent GPU job looks hung to the runner
         last_note = time.time()
