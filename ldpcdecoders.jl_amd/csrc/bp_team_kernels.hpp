@@ -233,7 +233,7 @@ constexpr unsigned int kTeamRollcallFailed = 0x80000000u;
 // one_xcd: every member of the team runs on the same XCD, so their stores meet in ONE L2 and the
 // release (a write-back of that L2) is not needed; the acquire (this CU's L1) always is.
 // Returns false when the team is broken (somebody timed out): the caller leaves the kernel.
-constexpr int kTeamMaxMembers = 96;
+constexpr int kTeamMaxMembers = 256;
 constexpr int kTeamCtlMember = 64;                                  // first member line
 constexpr int kTeamCtlWords = 64 + 32 * kTeamMaxMembers;            // per team
 constexpr int kTeamCheckChunk = 2;                                  // checks per chunk of the check sweep

@@ -379,6 +379,7 @@ struct ldpc_bp_decoder {
     int team_dynamic = 1;     // LDPC_TEAM_DYNAMIC: a member's waves take its chunks from a counter in LDS (0: every W-th)
     int team_pairs = 3;       // LDPC_TEAM_PAIRS: bit 0: two nodes of the full degree are loaded together; bit 1: the four bits of a position chunk (rows-on-chip kernels)
     int team_ahead_from = 1;  // LDPC_TEAM_AHEAD_FROM: first iteration whose test may ride with the next check sweep (1: realistic -1.6 %, waterfall -0.7 % against 2, profiles/r03_ahead_from1.txt)
+    bool team_ahead_set = false;   // LDPC_TEAM_AHEAD given (else: 1 for a single round of teams over all XCDs)
     int team_ahead = 32;      // LDPC_TEAM_AHEAD: active lanes from which on a team starts the next check sweep with the convergence
                               // test still under way (two team barriers an iteration instead of three); 0 = never
     // latency mode of the host-pointer entry (tiny batches, a plain decode!): the kernel reads and writes a
@@ -777,7 +778,7 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     if (const char *e = exp_env("LDPC_TEAM_DYNAMIC")) d->team_dynamic = std::atoi(e) != 0;
     if (const char *e = exp_env("LDPC_TEAM_XCDS")) d->team_xcds = std::max(1, std::min(8, std::atoi(e)));
     if (const char *e = exp_env("LDPC_TEAM_PAIRS")) d->team_pairs = std::atoi(e) & 3;   // (bit 1: four bits at once in the variable sweep)
-    if (const char *e = exp_env("LDPC_TEAM_AHEAD")) d->team_ahead = std::max(0, std::min(65, std::atoi(e)));
+    if (const char *e = exp_env("LDPC_TEAM_AHEAD")) { d->team_ahead = std::max(0, std::min(65, std::atoi(e))); d->team_ahead_set = true; }
     if (const char *e = exp_env("LDPC_TEAM_AHEAD_FROM")) d->team_ahead_from = std::max(1, std::atoi(e));
     if (const char *e = exp_env("LDPC_TEAM_REGS")) d->team_regs = std::max(0, std::min(kTeamRegRows, std::atoi(e)));
     if (const char *e = exp_env("LDPC_TEAM_FLIP")) d->team_flip = std::atoi(e) & 3;
@@ -1000,6 +1001,10 @@ struct TeamPlanIn {
     int num_cus = 256;
     int per_xcd = 0, gcap = 0; // team_geometry(): team workgroups one XCD hosts, members per team at most
     int gcap_one = 0;          // ... members at most of a persistent team that has an XCD to itself (>= gcap)
+    // <= 4 tiles, members over all XCDs: members at most, message rows a member at least.  (Round 3, one tile of the C3 code,
+    // a single decode! / 50 iterations: 64 members 0.294 / 3.44 ms, 96: 0.246 / 2.96, 128: 0.221 / 2.62, 192: 0.230 / 2.70,
+    // 256: 0.244 / 3.00; n = 32768, 50 iterations: 64: 5.64, 128: 3.83, 192: 3.57, 256: 3.72 ms -- profiles/r03_scatter_tune.txt)
+    int scatter_max = 192, scatter_rows = 512;
 };
 
 // What a member is expected to keep on chip (a bit dealt to a member that owns one of its dv checks: 1 / dv of the edges
@@ -1320,8 +1325,8 @@ static TeamPlan team_plan_pure(const TeamPlanIn &in, int64_t batch)
     int64_t team = 1, nteams = 0;
     if (ntiles <= 4 && !in.team_max_set) {
         // dealt over all 8 XCDs (scatter mode of the kernel): larger teams pay -- one tile of the C3 code, 50
-        // iterations: 32 members 5.4 ms, 48: 4.3 ms, 64: 3.4 ms (a member still has >= 1024 message rows per sweep)
-        const int64_t cap = std::min<int64_t>(64, std::max<int64_t>(gcap, in.nnz / 1024));
+        // iterations: 32 members 5.4 ms, 48: 4.3 ms, 64: 3.4 ms, 128: 2.6 ms (a member still has >= 512 message rows per sweep)
+        const int64_t cap = std::min<int64_t>(in.scatter_max, std::max<int64_t>(gcap, in.nnz / std::max(in.scatter_rows, 1)));
         team = std::min<int64_t>(cap, (int64_t)8 * per_xcd / ntiles);
         nteams = ntiles;
         pl.scatter = true;
@@ -1358,6 +1363,8 @@ static TeamPlanIn team_plan_in(const ldpc_bp_decoder *d, int per_xcd, int gcap, 
     in.team_max_set = d->team_max_set; in.rows_possible = team_rows_possible(d); in.rows_dv = std::max(d->rows_dv, 1); in.num_cus = d->num_cus;
     in.reg_rows = in.rows_possible ? d->team_regs * (LDPC_TEAM_THREADS / 64) : 0;
     in.per_xcd = per_xcd; in.gcap = gcap; in.gcap_one = std::max(gcap, gcap_one);
+    if (const char *e = exp_env("LDPC_TEAM_SCATTER_MAX")) in.scatter_max = std::max(3, std::min(kTeamMaxMembers, std::atoi(e)));
+    if (const char *e = exp_env("LDPC_TEAM_SCATTER_ROWS")) in.scatter_rows = std::max(1, std::atoi(e));
     return in;
 }
 
@@ -1831,6 +1838,10 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         tp.errmask_alt = (u64 *)d->errmask.p + std::max<size_t>((size_t)ntiles * n, 1);
         tp.ahead_min = d->team_ahead;
         tp.ahead_from = d->team_ahead_from;
+        // one round of teams over all XCDs (<= 4 tiles: a single decode!): no other tile waits for this team, so a sweep
+        // ahead that turns out to be for nothing costs one sweep at the end, and the barrier saved in every iteration
+        // is worth it whatever the number of active lanes (one syndrome, 50 iterations: 2.62 -> 2.31 ms)
+        if (plan.scatter && !d->team_ahead_set && tp.ahead_min > 0) tp.ahead_min = 1;
         team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr);
         size_t team_lds = team_lds_bytes();
         const int *t_col = a_col, *t_c2r = a_c2r;
