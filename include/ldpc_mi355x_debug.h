@@ -18,7 +18,7 @@ extern "C" {
    slots in flight (the library's default: 240).  rows_dv: the bit degree when the graph is regular and has a
    rows-on-chip instantiation, else 0 (with it the plan counts on 312 rows in LDS and 8 x 32 in registers per member).  out = { members per team (1 = no teams: node-parallel or tile kernel),
    teams = message slots in flight, workgroups launched, XCDs that host teams, 1 if the members of a team are dealt
-   over all XCDs (<= 4 tiles), 1 if members keep rows in LDS }. */
+   over all XCDs (<= 3 tiles), 1 if members keep rows in LDS }. */
 ldpc_status ldpc_debug_team_plan(int64_t nnz, int64_t max_iters, int64_t batch, int32_t cache_mib, int32_t rows_dv,
                                  int32_t out[6]);
 

@@ -372,7 +372,7 @@ struct ldpc_bp_decoder {
     int team_static_quarters = 3;     // LDPC_TEAM_STATIC: quarters of a member's chunks per sweep that its waves own by right (0: only each wave's first)
     unsigned int *team_fault = nullptr, *team_fault_dev = nullptr;
     int team_max = 32;        // workgroups per tile at most (LDPC_TEAM_MAX; 1 = team kernel off)
-    bool team_max_set = false;   // ... given by the environment: no automatic 64 for batches of <= 4 tiles
+    bool team_max_set = false;   // ... given by the environment: no automatic large teams for batches of <= 3 tiles
     // (read at create, so that a test or the fuzzer can vary them from decoder to decoder)
     size_t team_cache = (size_t)240 << 20;   // LDPC_TEAM_CACHE_MIB: message slots in flight that persistent teams may hold (team_fit())
     int team_xcds = 0;        // LDPC_TEAM_XCDS: XCDs that host persistent teams, fixed (experiments; 0 = team_fit() chooses)
@@ -994,17 +994,21 @@ struct TeamPlanIn {
     int64_t nnz = 0, max_iters = 0;
     size_t cache = 0;          // budget of message slots in flight (ldpc_bp_decoder::team_cache)
     int xcds_forced = 0;       // LDPC_TEAM_XCDS
-    bool team_max_set = false; // LDPC_TEAM_MAX given: no teams over all XCDs for <= 4 tiles
+    bool team_max_set = false; // LDPC_TEAM_MAX given: no teams over all XCDs for <= 3 tiles
     bool rows_possible = false;
     int rows_dv = 4;           // bit degree of the regular graph (one edge per bit is a candidate for a row in LDS)
     int reg_rows = 0;          // rows a member's waves keep in registers on top of the LDS (W x regs per wave)
     int num_cus = 256;
     int per_xcd = 0, gcap = 0; // team_geometry(): team workgroups one XCD hosts, members per team at most
     int gcap_one = 0;          // ... members at most of a persistent team that has an XCD to itself (>= gcap)
-    // <= 4 tiles, members over all XCDs: members at most, message rows a member at least.  (Round 3, one tile of the C3 code,
+    // <= 3 tiles, members over all XCDs: members at most, message rows a member at least.  (Round 3, one tile of the C3 code,
     // a single decode! / 50 iterations: 64 members 0.294 / 3.44 ms, 96: 0.246 / 2.96, 128: 0.221 / 2.62, 192: 0.230 / 2.70,
     // 256: 0.244 / 3.00; n = 32768, 50 iterations: 64: 5.64, 128: 3.83, 192: 3.57, 256: 3.72 ms -- profiles/r03_scatter_tune.txt)
     int scatter_max = 192, scatter_rows = 512;
+    // ... and up to how many tiles a batch is dealt that way (LDPC_TEAM_SCATTER_TILES).  (50 iterations, C3 code / n = 32768,
+    // all-XCD teams against one team per XCD: 1 tile 2.4 / 3.4 against 5.1 / 10.2 ms, 2 tiles 3.3 / 5.2, 3 tiles 4.3 / 7.1,
+    // 4 tiles 5.09 / 10.7 against 5.00 / 10.2, 5 tiles 6.1 / 13.9 against 5.1 / 12.1 -- profiles/r03_scatter_tiles.txt)
+    int scatter_tiles = 3;
 };
 
 // What a member is expected to keep on chip (a bit dealt to a member that owns one of its dv checks: 1 / dv of the edges
@@ -1299,7 +1303,7 @@ static bool team_fit(const TeamPlanIn &in, int64_t ntiles, bool rows, int *xcds,
 }
 
 // How a batch of fresh tiles is dealt to teams (bp_team_kernels.hpp).  G = 1: no teams for it.
-//   * up to 4 tiles: one team per tile, its members dealt over ALL XCDs (scatter), up to 64 of them;
+//   * up to 3 tiles: one team per tile, its members dealt over ALL XCDs (scatter), 128-192 of them;
 //   * as many tiles as fit one round of teams with the slots at most a quarter over the cache budget: one team per
 //     tile (8 tiles of the n = 16384 code: 8 teams once rather than 7 teams twice);
 //   * otherwise PERSISTENT teams inside the budget (team_fit()): a team takes tile after tile in its own slot;
@@ -1323,7 +1327,7 @@ static TeamPlan team_plan_pure(const TeamPlanIn &in, int64_t batch)
     if (ntiles < 1 || per_xcd < 1) return pl;
     if ((size_t)ntiles * ((size_t)in.max_iters + 32) * sizeof(u64) > ((size_t)64 << 20)) return pl;   // mismatch words per tile and iteration
     int64_t team = 1, nteams = 0;
-    if (ntiles <= 4 && !in.team_max_set) {
+    if (ntiles <= in.scatter_tiles && !in.team_max_set) {
         // dealt over all 8 XCDs (scatter mode of the kernel): larger teams pay -- one tile of the C3 code, 50
         // iterations: 32 members 5.4 ms, 48: 4.3 ms, 64: 3.4 ms, 128: 2.6 ms (a member still has >= 512 message rows per sweep)
         const int64_t cap = std::min<int64_t>(in.scatter_max, std::max<int64_t>(gcap, in.nnz / std::max(in.scatter_rows, 1)));
@@ -1365,6 +1369,7 @@ static TeamPlanIn team_plan_in(const ldpc_bp_decoder *d, int per_xcd, int gcap, 
     in.per_xcd = per_xcd; in.gcap = gcap; in.gcap_one = std::max(gcap, gcap_one);
     if (const char *e = exp_env("LDPC_TEAM_SCATTER_MAX")) in.scatter_max = std::max(3, std::min(kTeamMaxMembers, std::atoi(e)));
     if (const char *e = exp_env("LDPC_TEAM_SCATTER_ROWS")) in.scatter_rows = std::max(1, std::atoi(e));
+    if (const char *e = exp_env("LDPC_TEAM_SCATTER_TILES")) in.scatter_tiles = std::max(0, std::min(16, std::atoi(e)));
     return in;
 }
 
@@ -1399,7 +1404,7 @@ static int team_size(ldpc_bp_decoder *d, int64_t batch, bool want_llr) { return 
 //                time, three times that once the message slots in flight outgrow the L2s (32 MiB); 1.07 ns
 //                for the edges whose messages the hybrid placement keeps in LDS;
 //   team kernel: 41 ns per edge for a tile at one CU's pace, divided among the G members, + ~45 us for the
-//                three team barriers (~30 us for the small teams-over-all-XCDs geometry of <= 4 tiles).
+//                three team barriers (~30 us for the small teams-over-all-XCDs geometry of <= 3 tiles).
 // (A partial tile costs the team kernel as much as a full one, so below 64 syndromes this is a contest between
 // one syndrome per workgroup and up to 64 workgroups on one tile: n = 16384 and larger go to the team.)
 // Where the team kernel does not apply, the node kernel keeps the batches up to node_max_batch.
@@ -1418,7 +1423,7 @@ static bool takes_node_kernel(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
     const double g = d->node_split_check > 0 ? 1.0 - (double)d->node_split_edge / std::max(edges, 1.0) : 1.0;
     const double in_flight = (double)std::min<int64_t>(batch, 2 * (int64_t)d->num_cus) * edges * g * 8.0;
     const double est_node = rounds * (edges * (1.0 - g) * 1.07e-3 + edges * g * 1.9e-3 * (in_flight > 32.0 * 1048576.0 ? 3.0 : 1.0));
-    const double est_team = edges * 41e-3 / (double)G + (batch <= 4 * kTile ? 30.0 : 45.0);   // (<= 4 tiles: dealt over all XCDs)
+    const double est_team = edges * 41e-3 / (double)G + (batch <= 3 * kTile ? 30.0 : 45.0);   // (<= 3 tiles: dealt over all XCDs)
     return est_node < est_team;
 }
 
@@ -1838,7 +1843,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         tp.errmask_alt = (u64 *)d->errmask.p + std::max<size_t>((size_t)ntiles * n, 1);
         tp.ahead_min = d->team_ahead;
         tp.ahead_from = d->team_ahead_from;
-        // one round of teams over all XCDs (<= 4 tiles: a single decode!): no other tile waits for this team, so a sweep
+        // one round of teams over all XCDs (<= 3 tiles: a single decode!): no other tile waits for this team, so a sweep
         // ahead that turns out to be for nothing costs one sweep at the end, and the barrier saved in every iteration
         // is worth it whatever the number of active lanes (one syndrome, 50 iterations: 2.62 -> 2.31 ms)
         if (plan.scatter && !d->team_ahead_set && tp.ahead_min > 0) tp.ahead_min = 1;

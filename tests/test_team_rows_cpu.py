@@ -180,10 +180,11 @@ def test_team_plan_by_graph_and_batch():
     # exactly eight tiles: one round of eight teams rather than seven teams twice
     assert plan(c3, 512) == dict(members=32, teams=8, grid=256, xcds=8, scatter=0, rows=1)
     assert plan(c3, 576)["teams"] == 8 and plan(c3, 576, regular=0)["teams"] == 7    # nine tiles: persistent again
-    # up to four tiles: one team per tile, members dealt over all XCDs -- as many as leaves a member 512 message rows per
+    # up to three tiles: one team per tile, members dealt over all XCDs -- as many as leaves a member 512 message rows per
     # sweep, 192 at most (a single decode! of this code: 128 members 0.22 ms, 64 members 0.29 ms) --, no rows in LDS
     assert plan(c3, 1) == dict(members=128, teams=1, grid=128, xcds=8, scatter=1, rows=0)
-    assert plan(c3, 256) == dict(members=64, teams=4, grid=256, xcds=8, scatter=1, rows=0)      # (one workgroup per CU in this plan)
+    assert plan(c3, 192) == dict(members=85, teams=3, grid=255, xcds=8, scatter=1, rows=0)      # (one workgroup per CU in this plan)
+    assert plan(c3, 256) == dict(members=32, teams=8, grid=256, xcds=8, scatter=0, rows=1)      # four tiles: one round of teams, one per XCD
     assert plan(131072, 1)["members"] == 192 and plan(32768, 1)["members"] == 64
     # 28 MiB slots (n = 14336): eight fit the budget; the one team of an XCD takes all its 32 CUs as long as a member
     # keeps >= 1500 rows per sweep (1792 here), not only 28 of them (>= 2048 rows)
