@@ -68,9 +68,12 @@ while time.time() - t0 < budget and cases < MAXCASES:
         syn[rng.integers(0, B), rng.integers(0, s)] = rng.integers(2, 5)
     if DRY or VERBOSE:
         print(f"case {cases}: kind {int(kind)} shape {H.shape} nnz {H.nnz} per {per} iters {iters} B {B}", flush=True)
-    if not skip:
+    if not skip or os.environ.get("FUZZ_ORACLE_ONLY") == "1":
+        t_or = time.time()
         oc = BPOracle(csc=(H.indptr, H.indices), shape=H.shape, per=per, max_iters=iters)
         oerr, oconv, ollr, oits = oc.batchdecode(syn)
+        if time.time() - t_or > 3.0:
+            print(f"SLOW ORACLE {time.time() - t_or:.1f} s: seed {seed} case {cases} kind {int(kind)} shape {H.shape} nnz {H.nnz} per {per} iters {iters} B {B}", flush=True)
     for variant in (0, 1, 3, 4):
         # node kernel: messages in LDS (default for these small graphs), split between LDS and the global slot
         # at a random point (hybrid), or all in the global slot
@@ -141,6 +144,7 @@ while time.time() - t0 < budget and cases < MAXCASES:
                 pass
         if skip:
             continue
+        t_leg = time.time()
         dec = ldpc.BeliefPropagationDecoder(H, per, iters, **kw)
         err, conv, llr, its = dec.decode_batch_host(syn, want_llr=want_llr, want_iters=True)
         ok = np.array_equal(err, oerr) and np.array_equal(conv, oconv) and np.array_equal(its, oits)
@@ -153,15 +157,32 @@ while time.time() - t0 < budget and cases < MAXCASES:
             print(f"MISMATCH case {cases}: shape {H.shape} nnz {H.nnz} per {per} iters {iters} B {B} {kw} llr={want_llr}")
             sys.exit(1)
         dec.close()
+        if time.time() - t_leg > 3.0:   # a leg that took seconds on these small graphs: say which (timeouts inside the library?)
+            msg = (f"SLOW {time.time() - t_leg:.1f} s: seed {seed} case {cases} kind {int(kind)} shape {H.shape} nnz {H.nnz} per {per} iters {iters} B {B} "
+                   f"variant {variant} {kw} llr={want_llr} {knobs} last_kernel {getattr(dec, '_last_kernel_seen', '?')}")
+            print(msg, flush=True)
+            try:
+                with open("gpurun_out/fuzz_slow.txt", "a") as fh:
+                    fh.write(msg + "\n")
+            except OSError:
+                pass
         decoded += B
     if kind == 1 and H.nnz > 0:      # (any degree: nodes beyond 32 / 16 edges take the unlimited kernel)
         T, C = int(rng.choice([2, 3, 9])), float(rng.choice([1.0, 2.0, 3.0]))
+        # (the CPU oracle of BP-OTS re-runs with biases and takes minutes for 5,000 syndromes x 50 iterations -- what looked
+        #  like a stalled run in round 3 was this: the leg decodes the first 600 syndromes of the batch at most)
+        syn_ots = syn[:600]
         pp = max(per, 1e-3) if per < 0.9 else 0.3
         os.environ.pop("LDPC_BPOTS_FORCE_NODE", None)
         if rng.random() < 0.6:      # the node-parallel kernel (graphs beyond the LDS) or the unlimited one on a small graph
             os.environ["LDPC_BPOTS_FORCE_NODE"] = str(int(rng.integers(1, 3)))
         if DRY or VERBOSE:
             print(f"   BP-OTS T {T} C {C} per {pp} force {os.environ.get('LDPC_BPOTS_FORCE_NODE')}", flush=True)
+        if skip and os.environ.get("FUZZ_ORACLE_ONLY") == "1":
+            t_or = time.time()
+            BPOTSOracle((H.indptr, H.indices), H.shape, pp, iters, T, C).batchdecode(syn_ots)
+            if time.time() - t_or > 3.0:
+                print(f"SLOW BP-OTS ORACLE {time.time() - t_or:.1f} s: seed {seed} case {cases} shape {H.shape} nnz {H.nnz} per {pp} iters {iters} B {B} T {T} C {C}", flush=True)
         if not skip:
             try:
                 with open("gpurun_out/fuzz_current.txt", "w") as fh:
@@ -169,9 +190,12 @@ while time.time() - t0 < budget and cases < MAXCASES:
                              f"T {T} C {C} force {os.environ.get('LDPC_BPOTS_FORCE_NODE')}\n")
             except OSError:
                 pass
-            oe, ocv, oi = BPOTSOracle((H.indptr, H.indices), H.shape, pp, iters, T, C).batchdecode(syn)
+            t_or = time.time()
+            oe, ocv, oi = BPOTSOracle((H.indptr, H.indices), H.shape, pp, iters, T, C).batchdecode(syn_ots)
+            if time.time() - t_or > 3.0:
+                print(f"SLOW BP-OTS ORACLE {time.time() - t_or:.1f} s: seed {seed} case {cases} shape {H.shape} nnz {H.nnz} per {pp} iters {iters} B {B} T {T} C {C}", flush=True)
             d2 = ldpc.BPOTSDecoder(H, pp, iters, T=T, C=C)
-            e2, c2, i2 = d2.decode_batch_host(syn)
+            e2, c2, i2 = d2.decode_batch_host(syn_ots)
             if not (np.array_equal(e2, oe) and np.array_equal(c2, ocv) and np.array_equal(i2, oi)):
                 print(f"BP-OTS MISMATCH case {cases}: shape {H.shape} nnz {H.nnz} per {pp} iters {iters} B {B} T {T} C {C}")
                 sys.exit(1)
