@@ -1276,7 +1276,9 @@ static bool team_fit(const TeamPlanIn &in, int64_t ntiles, bool rows, int *xcds,
     // uses most XCDs (their L2s and ports; fewer, larger teams per XCD): x runs downwards, so the first one that
     // qualifies wins.  ((3,6) n = 16380: eight teams of 23 on eight XCDs measured 7.1 TB/s, sixteen of 16 6.3)
     int64_t best = 0;
-    const int x_hi = in.xcds_forced ? in.xcds_forced : 8, x_lo = in.xcds_forced ? in.xcds_forced : 6;
+    // (not fewer than seven XCDs: n = 24576, 48 MiB slots -- six cached teams 382 ms for 16,384 syndromes x 50 iterations,
+    //  eight partly cached ones 350 ms; n = 20480: seven cached 283 ms, eight 282 ms -- profiles/r03_midsize_plan.txt)
+    const int x_hi = in.xcds_forced ? in.xcds_forced : 8, x_lo = in.xcds_forced ? in.xcds_forced : 7;
     for (int pass = 0; pass < 2; ++pass)
     for (int x = x_hi; x >= x_lo; --x)
         for (int t = 1; t <= per_xcd / 3; ++t) {
@@ -1291,11 +1293,12 @@ static bool team_fit(const TeamPlanIn &in, int64_t ntiles, bool rows, int *xcds,
             else if (w * 100 >= best * 85) { *xcds = x; *tpx = t; *G = g; return true; }
         }
     if (best > 0) return true;
-    // Slots up to 2.2 x the budget: one team per XCD still pays -- the slots are partly cached, and a team streams what is
-    // not as well as three tile-kernel workgroups per CU do (n = 32768, 64 MiB a slot, 50 iterations: 16,384 syndromes
-    // 575 ms against 651 ms, 49,152 syndromes 1.76 s against 1.80 s -- with 8 slots instead of 768).  Beyond that
-    // (n = 65536) the two are equal and the tile kernel stays.
-    if (!in.xcds_forced && (size_t)8 * state <= cache / 5 * 11 && std::min(gcap, per_xcd) >= 3) {
+    // Slots up to 3.3 x the budget: one team per XCD still pays -- the slots are partly cached or not at all, and a team
+    // streams what is not as well as three tile-kernel workgroups per CU do, with 8 slots instead of 768 (round 3, 50
+    // iterations, teams against the tile kernel: n = 40960, 80 MiB a slot: 16,384 syndromes 693 against 874 ms, 65,536
+    // syndromes 2.76 against 2.94 s; n = 49152: 874 against 1071 ms, 3.51 against 3.70 s).  Beyond that (n = 65536,
+    // 128 MiB a slot: 4.96 against 4.85 s) the tile kernel stays.  (profiles/r03_midsize_plan.txt)
+    if (!in.xcds_forced && (size_t)8 * state <= cache / 10 * 33 && std::min(gcap, per_xcd) >= 3) {
         *xcds = 8; *tpx = 1; *G = std::min(gcap, per_xcd);
         return true;
     }
