@@ -954,7 +954,7 @@ static bool takes_lds_kernel(const ldpc_bp_decoder *d, bool want_llr)
 {
     return d->variant != 1 && d->variant != 3 && d->variant != 4 && d->lds_logS[want_llr ? 1 : 0] >= 0;
 }
-constexpr int64_t kTeamMinRowsOne = 1500;   // message rows per sweep a member of the ONLY team of an XCD must have (team_geometry())
+constexpr int64_t kTeamMinRowsOne = 1100;   // message rows per sweep a member of the ONLY team of an XCD must have (team_geometry())
 
 // Workgroups per tile the team kernel (bp_team_kernels.hpp) would use for this batch; 1 = it does not apply.
 // Teams are formed inside one XCD (1/8 of the CUs), two workgroups per CU so that every member is
@@ -975,12 +975,16 @@ static bool team_geometry(ldpc_bp_decoder *d, bool want_llr, int *per_xcd, int *
     static const int64_t min_rows = [] { const char *e = exp_env("LDPC_TEAM_MIN_ROWS"); return e ? std::max<int64_t>(1, std::atoll(e)) : (int64_t)2048; }();
     *per_xcd = per_cu * (d->num_cus / 8);
     *gcap = (int)std::min<int64_t>(d->team_max, std::max<int64_t>(1, d->nnz / min_rows));   // (LDPC_TEAM_MIN_ROWS=1: tests put teams on tiny graphs)
-    // ONE persistent team per XCD may have more members than that -- all the CUs of its XCD -- down to 1500 rows a member
-    // (round 3, full batch of 50 iterations: (3,6) n = 16380 with 32 members of 1535 rows 528 ms, with 23 of 2136 rows
-    // 633 ms; (4,8) n = 12288: 139 against 155 ms for 16,384 syndromes; but n = 8192, 1024 rows a member: 96 ms against
-    // 90 ms for sixteen teams of 16 -- profiles/r03_minrows_ab.txt)
+    // ONE persistent team per XCD may have more members than that -- ALL the CUs of its XCD, or it stays as it is --
+    // down to 1100 rows a member (round 3, 16,384 syndromes x 50 iterations: (3,6) n = 16380 with 32 members of 1535
+    // rows 132 ms, with 23 of 2136 rows 156 ms; (4,8) n = 12288 / 11264 / 10240 / 9216 with 32 members 139 / 126 / 117 /
+    // 105 ms against 155 / 149 / 152 / 110 ms under the 2048-row rule; (3,6) n = 12288 100 against 112 ms; but n = 8192,
+    // 1024 rows a member: 96 ms against 90 ms for sixteen teams of 16 -- profiles/r03_minrows_ab.txt, r03_minrows2.txt)
     static const bool min_rows_set = exp_env("LDPC_TEAM_MIN_ROWS") != nullptr;
-    if (gcap_one) *gcap_one = min_rows_set ? *gcap : (int)std::min<int64_t>(d->team_max, std::max<int64_t>(*gcap, d->nnz / kTeamMinRowsOne));
+    if (gcap_one) {
+        const int64_t full = std::min<int64_t>(d->team_max, d->num_cus / 8);
+        *gcap_one = (!min_rows_set && d->nnz / kTeamMinRowsOne >= full) ? (int)std::max<int64_t>(*gcap, full) : *gcap;
+    }
     return *per_xcd >= 1;
 }
 
@@ -1393,7 +1397,7 @@ extern "C" ldpc_status ldpc_debug_team_plan(int64_t nnz, int64_t max_iters, int6
     in.reg_rows = rows_dv > 0 ? kTeamRegRows * (LDPC_TEAM_THREADS / 64) : 0;
     in.num_cus = 256; in.per_xcd = 32;
     in.gcap = (int)std::min<int64_t>(32, std::max<int64_t>(1, nnz / 2048));
-    in.gcap_one = (int)std::min<int64_t>(32, std::max<int64_t>(in.gcap, nnz / kTeamMinRowsOne));
+    in.gcap_one = nnz / kTeamMinRowsOne >= 32 ? 32 : in.gcap;
     const TeamPlan pl = team_plan_pure(in, batch);
     out[0] = pl.G; out[1] = pl.nteams; out[2] = pl.grid; out[3] = pl.xcds; out[4] = pl.scatter ? 1 : 0; out[5] = pl.rows ? 1 : 0;
     return LDPC_OK;

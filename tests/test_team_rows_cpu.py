@@ -186,11 +186,12 @@ def test_team_plan_by_graph_and_batch():
     assert plan(c3, 192) == dict(members=85, teams=3, grid=255, xcds=8, scatter=1, rows=0)      # (one workgroup per CU in this plan)
     assert plan(c3, 256) == dict(members=32, teams=8, grid=256, xcds=8, scatter=0, rows=1)      # four tiles: one round of teams, one per XCD
     assert plan(131072, 1)["members"] == 192 and plan(32768, 1)["members"] == 64
-    # 28 MiB slots (n = 14336): eight fit the budget; the one team of an XCD takes all its 32 CUs as long as a member
-    # keeps >= 1500 rows per sweep (1792 here), not only 28 of them (>= 2048 rows)
+    # 28 MiB slots (n = 14336): eight fit the budget; the one team of an XCD takes ALL its 32 CUs as long as a member
+    # keeps >= 1100 rows per sweep (1792 here), not only 28 of them (>= 2048 rows) -- all of them or none
     assert plan(57344, 65536)["teams"] == 8 and plan(57344, 65536)["members"] == 32
     assert plan(49152, 65536) == dict(members=32, teams=8, grid=256, xcds=8, scatter=0, rows=1)      # n = 12288: 1536 rows
-    assert plan(40960, 65536)["members"] == 27 and plan(40960, 65536)["teams"] == 8                  # n = 10240: 1280 rows a member would be too few
+    assert plan(40960, 65536) == dict(members=32, teams=8, grid=256, xcds=8, scatter=0, rows=1)      # n = 10240: 1280 rows
+    assert plan(36864, 65536) == dict(members=32, teams=8, grid=256, xcds=8, scatter=0, rows=1)      # n = 9216: 1152 rows
     # 16 MiB slots (n = 8192): members of >= 2048 rows are 16 at most, so two teams per XCD -- on seven XCDs with whole
     # slots (224 MiB), on all eight with the rows on chip taken off
     p = plan(32768, 65536, regular=0)
