@@ -212,24 +212,42 @@ def roofline_object(dec, args, kname, last_kernel, nnz, s_checks, n, batch, achi
     return obj
 
 
-def also_workloads(ldpc, torch, H, Hcsr, n, nnz, device, local_rank, names=("c3_waterfall", "c3_realistic"), steps=3, sample=512):
+def llr_gate(H, per, max_iters, h_syn, h_llr, k=48):
+    """max |LLR difference| against the oracle on the first k syndromes (+-Inf must match exactly: -> inf if not)."""
+    from oracle import BPOracle
+
+    oc = BPOracle(csc=(H.indptr, H.indices), shape=H.shape, per=per, max_iters=max_iters)
+    _, _, ollr, _ = oc.batchdecode(h_syn[:k], want_llr=True)
+    g = h_llr[:k]
+    fin = np.isfinite(ollr)
+    if not np.array_equal(g[~fin], ollr[~fin]):
+        return float("inf")
+    return float(np.max(np.abs(g[fin] - ollr[fin]))) if fin.any() else 0.0
+
+
+def also_workloads(ldpc, torch, H, Hcsr, n, nnz, device, local_rank, names=("c3_waterfall", "c3_realistic", "c3_full50_llr", "c3_realistic_llr"), steps=3, sample=512):
     """The same code at other error rates, after the timed region (they are not the headline; they make the
     early-exit path -- straggler hand-off, packed levels -- observable in the driver's own run): `steps` calls each,
-    kernel time and iteration sum from the library's HIP events, and the same oracle gate on a sample."""
+    kernel time and iteration sum from the library's HIP events, and the same oracle gate on a sample.  The `_llr`
+    entries ask for the LLRs of every syndrome (the reference's decode! always fills scratch.log_probabs,
+    belief_propagation.jl:163; BP+OSD reads them): the instantiation of the sweep kernel that writes them, held to
+    <= 1e-5 against the oracle (+-Inf exact) on a sample."""
     res = {}
     cores = max(1, min(len(os.sched_getaffinity(0)), 16))
     for name in names:
-        _, _, _, batch, per, max_iters = WORKLOADS[name]
+        want_llr = name.endswith("_llr")
+        _, _, _, batch, per, max_iters = WORKLOADS[name[:-4] if want_llr else name]
         dec = ldpc.BeliefPropagationDecoder(H, per, max_iters, device=local_rank)
         syn = make_syndromes(torch, Hcsr, n, batch, per, seed=1234, device=device)
         err = torch.empty((batch, n), dtype=torch.uint8, device=device)
         conv = torch.empty(batch, dtype=torch.uint8, device=device)
         iters = torch.empty(batch, dtype=torch.int32, device=device)
-        dec.decode_batch_device(syn, err, conv, None, iters)      # warm-up (workspace, levels)
+        llr = torch.empty((batch, n), dtype=torch.float64, device=device) if want_llr else None
+        dec.decode_batch_device(syn, err, conv, llr, iters)      # warm-up (workspace, levels)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            dec.decode_batch_device(syn, err, conv, None, iters)
+            dec.decode_batch_device(syn, err, conv, llr, iters)
         dec.last_status()
         torch.cuda.synchronize()
         wall_ms = (time.perf_counter() - t0) / steps * 1e3
@@ -247,8 +265,13 @@ def also_workloads(ldpc, torch, H, Hcsr, n, nnz, device, local_rank, names=("c3_
                      "frac_is": "sum over syndromes of iterations executed x 32 nnz bytes / sweep-kernel time / HBM peak",
                      "kernel": {1: "bp_tile_kernel", 2: "bp_lds_kernel", 3: "bp_node_kernel", 4: "bp_team_kernel"}.get(int(dec.info().last_kernel), "?"),
                      "gpu_matches_oracle_on_sample": bool(ok), "oracle_sample": int(done)}
+        if want_llr:
+            kl = min(batch, 48)
+            res[name]["llr_max_abs_diff_vs_oracle"] = llr_gate(H, per, max_iters, h[0], llr[:kl].cpu().numpy(), kl)
+            res[name]["llr_sample"] = kl
+            res[name]["gpu_matches_oracle_on_sample"] = bool(ok and res[name]["llr_max_abs_diff_vs_oracle"] <= 1e-5)
         dec.close()
-        del syn, err, conv, iters
+        del syn, err, conv, iters, llr
     return res
 
 
@@ -274,6 +297,9 @@ def main():
     ap.add_argument("--kernel-variant", type=int, default=0, help="0 auto, 1 HBM-streaming, 2 LDS-resident, 3 node-parallel, 4 team")
     ap.add_argument("--defer-threshold", type=int, default=0, help="0 auto (16), -1 off (streaming kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--llr", action="store_true",
+                    help="the timed step asks for the LLRs of every syndrome as well (scratch.log_probabs, belief_propagation.jl:163; "
+                         "one GPU, decode straight into the result arrays)")
     ap.add_argument("--prealloc-gib", type=float, default=0.0,
                     help="experiment: hold this much HBM before anything else is allocated (shifts physical placement)")
     # rehearsal of the N>1 control flow on a box with fewer GPUs than ranks (never used by the driver):
@@ -320,7 +346,9 @@ def main():
     bposd_workload = args.workload == "c5_bb72_bposd"
     mode = args.mode
     if mode == "auto":
-        mode = "replicas" if bposd_workload else "scatter"
+        mode = "replicas" if (bposd_workload or args.llr) else "scatter"
+    if args.llr and (mode != "replicas" or bposd_workload):
+        raise SystemExit("--llr: --mode replicas (or auto) on a plain BP workload")
     if bposd_workload and mode == "scatter":
         raise SystemExit("the BP+OSD workload has a host step per rank: use --mode replicas")
     if bposd_workload:
@@ -360,6 +388,7 @@ def main():
         err = torch.empty((batch, n), dtype=torch.uint8, device=device)
         conv = torch.empty(batch, dtype=torch.uint8, device=device)
         iters = torch.empty(batch, dtype=torch.int32, device=device)
+    llr_out = torch.empty((batch, n), dtype=torch.float64, device=device) if args.llr else None
 
     osd_sent = [0]
     device_calls = [0]   # library calls made by the timed steps (1 per step unless noted)
@@ -393,7 +422,7 @@ def main():
             phases.append(tm)
     else:
         def step():
-            dec.decode_batch_device(syn, err, conv, None, iters)
+            dec.decode_batch_device(syn, err, conv, llr_out, iters)
 
     def fence():
         if cabi:
@@ -494,7 +523,7 @@ def main():
             "config": {
                 "workload": f"{args.workload}: Gallager ({wc},{wr})-regular LDPC n={n} m={s_checks} nnz={nnz}, "
                             f"batch={batch}/GPU, per={per}, max_iters={max_iters}, HBM-resident uint8 syndromes in, "
-                            f"uint8 hard decisions + converged + iteration counts out",
+                            f"uint8 hard decisions + converged + iteration counts out" + (" + f64 LLRs of every syndrome" if args.llr else ""),
                 "global_batch": batch * shards,
                 "mode": mode,
                 "parallelism": par,
@@ -522,6 +551,7 @@ def main():
                           f"structural non-zeros only), one decoder per thread on {cores} host threads; "
                           f"the Julia reference itself cannot run here (no Julia runtime)",
                 "gpu_matches_oracle_on_sample": bool(e_ok and d_ok),
+                **({"llr_max_abs_diff_vs_oracle": llr_gate(H, per, max_iters, h_syn, llr_out[:48].cpu().numpy(), min(batch, 48))} if args.llr else {}),
                 "reference_faithful_1_thread": {
                     "value": d_rate, "unit": "syndromes/s", "cores": 1,
                     "sample": f"first {d_done} syndromes, C oracle in reference-faithful dense mode (2 dense {s_checks}x{n} Float64 "

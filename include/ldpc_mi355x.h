@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LDPC_MI355X_ABI_VERSION 3
+#define LDPC_MI355X_ABI_VERSION 4
 
 typedef enum ldpc_status {
     LDPC_OK = 0,
@@ -79,9 +79,9 @@ typedef struct ldpc_bp_options {
                                  model picks between the node-parallel kernel and the team kernel (several
                                  workgroups per 64-syndrome tile) for small batches; the team kernel takes the larger
                                  ones with PERSISTENT teams (a team decodes tile after tile in its own message slot)
-                                 when a chip-wide set of slots fits the 256 MiB Infinity Cache or is at most about
-                                 twice its size (n <= ~32768 for (4,8)-regular codes), else with one team per tile
-                                 up to one tile per CU; the
+                                 when a chip-wide set of slots fits the 256 MiB Infinity Cache or is at most 3.3 x
+                                 the 240 MiB budget planned for it (n <= 49152 for (4,8)-regular codes), else with one
+                                 team per tile up to one tile per CU; the
                                  HBM-streaming tile kernel (one persistent workgroup per tile) takes the rest.
                                  1 = force streaming; 2 = force LDS-resident (error if it does not fit);
                                  3 = force node-parallel; 4 = team kernel wherever it applies, streaming otherwise
@@ -108,6 +108,16 @@ ldpc_status ldpc_trim_memory(void);
 
 /* Number of usable gfx950 devices (0 when there is none; never fails). */
 int32_t ldpc_device_count(void);
+
+/* Every wait of the HOST for the device inside this library (event / stream / device synchronisation, the flag spin of
+ * the single-decode latency path, the synchronisation in front of a free) is bounded: when the device has not got there
+ * after this many milliseconds the call returns LDPC_ERR_HIP, ldpc_last_error() names the wait, the device is taken to
+ * be stalled for the rest of the process (every later call on it fails at once with the same message, nothing it may
+ * still use is freed).  Per process; default 600000 (ten minutes: longer than any single call on the configurations of
+ * BASELINE.json by two orders of magnitude); 0 = wait for ever (the behaviour before ABI version 4).  The reference has no
+ * counterpart (pure host code).  Device-side waits have bounds of their own (team barrier 10 s, roll call 20 ms). */
+ldpc_status ldpc_set_wait_limit_ms(int64_t ms);
+int64_t ldpc_get_wait_limit_ms(void);
 
 /*
  * Replaces `BeliefPropagationDecoder(H, per::Float64, max_iters::Int)`

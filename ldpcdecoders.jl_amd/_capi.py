@@ -34,6 +34,8 @@ EXPORTED_SYMBOLS = (
     "ldpc_last_error",
     "ldpc_device_count",
     "ldpc_trim_memory",
+    "ldpc_set_wait_limit_ms",
+    "ldpc_get_wait_limit_ms",
     "ldpc_bp_create",
     "ldpc_bp_destroy",
     "ldpc_bp_get_info",
@@ -105,7 +107,7 @@ class BPOptions(ctypes.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("ldpc_mi355x.hip", "ldpc_multi.hip", "host_env.hpp", "pick_tile.hip", "pick_lds.hip", "pick_node.hip", "pick_team.hip", "pickers.hpp",
+    srcs = [os.path.join(CSRC, f) for f in ("ldpc_mi355x.hip", "ldpc_multi.hip", "host_env.hpp", "host_wait.hpp", "pick_tile.hip", "pick_lds.hip", "pick_node.hip", "pick_team.hip", "pickers.hpp",
                                              "ldpc_bpots.hip", "osd_host.cpp", "bp_kernels.hpp", "bp_lds_kernels.hpp", "bp_node_kernels.hpp", "bp_team_kernels.hpp", "latency_mode.hpp",
                                              "bpots_kernels.hpp", "portable_math.h", "Makefile")]
     srcs.append(os.path.join(_HERE, "..", "include", "ldpc_mi355x.h"))
@@ -153,6 +155,9 @@ def lib(experiments: bool = False) -> ctypes.CDLL:
     L.ldpc_last_error.restype = ctypes.c_char_p
     L.ldpc_device_count.restype = i32
     L.ldpc_trim_memory.restype = i32
+    L.ldpc_set_wait_limit_ms.restype = i32
+    L.ldpc_set_wait_limit_ms.argtypes = [i64]
+    L.ldpc_get_wait_limit_ms.restype = i64
     L.ldpc_debug_team_plan.restype = i32
     L.ldpc_debug_team_plan.argtypes = [i64, i64, i64, i32, i32, ctypes.POINTER(i32 * 6)]
     L.ldpc_debug_team_rows.restype = i32

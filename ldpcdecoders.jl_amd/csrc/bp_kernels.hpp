@@ -789,10 +789,11 @@ __global__ void __launch_bounds__(64) unpack_errors_kernel(const u64 *errmask, l
     }
 }
 
-// llr transpose: llr_t[tile][n][64] -> llr[batch][n]; 64x64 tile through LDS
+// llr transpose: llr_t[tile][n][64] -> llr[batch][n]; 64x64 tile through LDS.  raw: llr_t holds the posterior odds T
+// (the team kernel's fresh pass, TeamParams::llr_raw) and log(1 / T) (:163) is taken here, once per syndrome and bit
 __global__ void __launch_bounds__(256) unpack_llr_kernel(const double *llr_t, long long batch, int n,
                                                          double *llr, const int *index,
-                                                         const unsigned int *count_dev, unsigned int count_skip)
+                                                         const unsigned int *count_dev, unsigned int count_skip, int raw)
 {
     __shared__ double t[64][65];
     if (count_dev) { batch = (long long)*count_dev; if (batch <= (long long)count_skip) return; }   // uniform
@@ -808,7 +809,8 @@ __global__ void __launch_bounds__(256) unpack_llr_kernel(const double *llr_t, lo
     for (int rr = ty; rr < rows; rr += 4)
         if (j0 + tx < n) {
             const long long b = index ? (long long)index[b0 + rr] : b0 + rr;
-            llr[(size_t)b * n + j0 + tx] = t[tx][rr];
+            const double v = t[tx][rr];
+            llr[(size_t)b * n + j0 + tx] = raw ? log(1.0 / v) : v;
         }
 }
 

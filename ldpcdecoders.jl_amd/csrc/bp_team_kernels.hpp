@@ -145,16 +145,21 @@ constexpr int kTeamRegRows = 32;
         "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
 static_assert(192 + 2 * kTeamRegRows == 256, "the clobber list names the registers of kTeamRegRows rows");
 // (every lane of the wave is active wherever these are used; row is wave-uniform.  s_nop: one wait state between the
-// scalar write of M0 and a vector instruction that uses the index)
+// scalar write of M0 and a vector instruction that uses the index.  s_set_gpr_idx_on writes M0[7:0] and M0[15:12] --
+// LLVM lists Defs = [M0, MODE] for it.  M0 is a RESERVED register to hipcc: naming it as a clobber only earns the
+// warning that such clobbers "may not be preserved", so the accessors save M0 in a scalar register and put it back
+// themselves -- whatever the compiler keeps in M0 survives them.  tests/test_abi_cpu.py checks in the code object that
+// every s_set_gpr_idx_on is preceded by the save and every s_set_gpr_idx_off followed by the restore, with nothing
+// but the s_nop and the two v_mov_b32 in between)
 __device__ __forceinline__ double team_reg_get(const int row)
 {
 #ifdef LDPC_TEAM_FAKE_REGS   // (timing experiment: the code around the accessors without the accessors; results are wrong)
     return 0.5 + 1e-3 * row;
 #endif
-    unsigned int lo, hi;
+    unsigned int lo, hi, m0_keep;
     const int q = __builtin_amdgcn_readfirstlane(2 * row);
-    asm volatile("s_set_gpr_idx_on %2, 0x1\n\ts_nop 0\n\tv_mov_b32 %0, v192\n\tv_mov_b32 %1, v193\n\ts_set_gpr_idx_off"
-                 : "=v"(lo), "=v"(hi) : "s"(q) : LDPC_TEAM_TOP_VGPRS);
+    asm volatile("s_mov_b32 %2, m0\n\ts_set_gpr_idx_on %3, 0x1\n\ts_nop 0\n\tv_mov_b32 %0, v192\n\tv_mov_b32 %1, v193\n\ts_set_gpr_idx_off\n\ts_mov_b32 m0, %2"
+                 : "=v"(lo), "=v"(hi), "=&s"(m0_keep) : "s"(q) : LDPC_TEAM_TOP_VGPRS);
     return __hiloint2double((int)hi, (int)lo);
 }
 __device__ __forceinline__ void team_reg_put(const int row, const double v)
@@ -164,8 +169,9 @@ __device__ __forceinline__ void team_reg_put(const int row, const double v)
 #endif
     const unsigned int lo = (unsigned int)__double2loint(v), hi = (unsigned int)__double2hiint(v);
     const int q = __builtin_amdgcn_readfirstlane(2 * row);
-    asm volatile("s_set_gpr_idx_on %2, 0x8\n\ts_nop 0\n\tv_mov_b32 v192, %0\n\tv_mov_b32 v193, %1\n\ts_set_gpr_idx_off"
-                 : : "v"(lo), "v"(hi), "s"(q) : LDPC_TEAM_TOP_VGPRS);
+    unsigned int m0_keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_set_gpr_idx_on %3, 0x8\n\ts_nop 0\n\tv_mov_b32 v192, %1\n\tv_mov_b32 v193, %2\n\ts_set_gpr_idx_off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_keep) : "v"(lo), "v"(hi), "s"(q) : LDPC_TEAM_TOP_VGPRS);
 }
 struct TeamRows {
     const int *lds_edge;        // [G][R]  CSR rows held by each member, -1 beyond its count (write-back before a hand-off)
@@ -220,6 +226,11 @@ struct TeamParams {
     u64 *errmask_alt;           // [ntiles][n] or nullptr (no running ahead: passes over packed levels)
     int ahead_min;              // active lanes from which on a quiet tile's team runs ahead (0 = never)
     int ahead_from;             // ... and the first iteration whose test may have company (1; 2: a verdict must have been quiet first)
+    // LLRs (WANT_LLR instantiations, fresh tiles): what the variable sweep leaves in p.llr for every active lane and bit in
+    // every iteration -- 0: log(1 / T) (:163), as the other kernels do; 1: the posterior odds T themselves, the logarithm
+    // is taken once per syndrome and bit by unpack_llr_kernel (same OCML log on the same operand: the same bits) instead
+    // of once per iteration; 2: as 1 with non-temporal stores
+    int llr_raw;
 };
 constexpr unsigned int kTeamRollcallFailed = 0x80000000u;
 
@@ -755,7 +766,12 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
         auto decide = [&](int j, double T) {
             const u64 dec = __ballot(T >= 1.0);                                // :164-168
             if (WANT_LLR) {
-                if ((active >> lane) & 1ull) p.llr[((size_t)tile * n + j) * kTile + lane] = log(1.0 / T);  // :163
+                if ((active >> lane) & 1ull) {
+                    double *const dst = p.llr + ((size_t)tile * n + j) * kTile + lane;
+                    if (tp.llr_raw == 0) *dst = log(1.0 / T);  // :163
+                    else if (tp.llr_raw == 1) *dst = T;        // (the logarithm: unpack_llr_kernel)
+                    else __builtin_nontemporal_store(T, dst);
+                }
             }
             if (lane == 0) em[j] = dec;   // every lane; the stopped ones' decisions were captured when they stopped
         };

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <string>
@@ -19,9 +20,7 @@
 
 using namespace ldpc;
 
-namespace ldpc_detail {
-ldpc_status set_error(ldpc_status st, const std::string &msg);
-}
+#include "host_wait.hpp"   // set_error, and the bounded forms of every host-side wait
 using ldpc_detail::set_error;
 
 #define OTS_TRY(expr)                                                                        \
@@ -56,6 +55,7 @@ struct ldpc_bpots_decoder {
     size_t node_ws_cap = 0;
     ~ldpc_bpots_decoder()
     {
+        if (ldpc_detail::device_stalled(device)) return;   // (host_wait.hpp: nothing a stalled device may still use is freed)
         void *all[] = {row_ptr, csc_row, col_ptr, csc2csr, queue, stage, done_ctr, node_ws};
         for (void *q : all)
             if (q) (void)hipFree(q);
@@ -177,9 +177,9 @@ ldpc_status ldpc_bpots_destroy(ldpc_bpots_decoder *d)
 {
     if (!d) return LDPC_OK;
     (void)hipSetDevice(d->device);
-    (void)hipDeviceSynchronize();
+    const ldpc_status st = ldpc_detail::wait_device(d->device, "ldpc_bpots_destroy (device synchronise)");
     delete d;
-    return LDPC_OK;
+    return st;
 }
 
 }  // extern "C"
@@ -198,6 +198,7 @@ static ldpc_status bpots_decode_impl(ldpc_bpots_decoder *d, int64_t batch, const
     if ((d->s > 0 && !d_syn) || (d->n > 0 && !d_err) || !d_conv) return set_error(LDPC_ERR_INVALID_ARGUMENT, "NULL batch pointer");
     hipStream_t stream = (hipStream_t)stream_v;
     OTS_TRY(hipSetDevice(d->device));
+    if (ldpc_detail::device_stalled(d->device)) return ldpc_detail::stalled_error(d->device);
     if (d->max_iters == 0) {   // the loop at :239 never runs: best_decisions = 0, converged = false
         if (d->n > 0) OTS_TRY(hipMemsetAsync(d_err, 0, (size_t)batch * d->n, stream));
         OTS_TRY(hipMemsetAsync(d_conv, 0, (size_t)batch, stream));
@@ -215,7 +216,11 @@ static ldpc_status bpots_decode_impl(ldpc_bpots_decoder *d, int64_t batch, const
         const int grid = (int)std::min<int64_t>(batch, d->num_cus);
         const size_t slot = d->big_mode ? ots_big_slot_doubles((int)d->s, (int)d->n, (int)d->nnz) : ots_node_slot_doubles((int)d->n, (int)d->nnz);
         if (d->node_ws_cap < (size_t)grid * slot * sizeof(double)) {
-            if (d->node_ws) { OTS_TRY(hipStreamSynchronize(stream)); (void)hipFree(d->node_ws); }
+            if (d->node_ws) {
+                const ldpc_status ws = ldpc_detail::wait_device(d->device, "BP-OTS workspace regrow (device synchronise before the free)");
+                if (ws != LDPC_OK) return ws;
+                (void)hipFree(d->node_ws);
+            }
             d->node_ws = nullptr; d->node_ws_cap = 0;
             OTS_TRY(hipMalloc((void **)&d->node_ws, (size_t)grid * slot * sizeof(double)));
             d->node_ws_cap = (size_t)grid * slot * sizeof(double);
@@ -309,9 +314,13 @@ ldpc_status ldpc_bpots_decode_batch(ldpc_bpots_decoder *d, int64_t batch, const 
         ldpc_status lst = bpots_decode_impl(d, batch, (const uint8_t *)dp, (uint8_t *)(dp + o_err), (uint8_t *)(dp + o_conv),
                                             (int32_t *)(dp + o_it), nullptr, &lc);
         if (lst != LDPC_OK) return lst;
+        const auto lat_t0 = std::chrono::steady_clock::now();
         for (uint64_t spins = 1;; ++spins) {
             if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == lc.ticket) break;
-            if ((spins & 0xffff) == 0) {   // every ~65k polls: is the kernel still alive?
+            if ((spins & 0xffff) == 0) {   // every ~65k polls: is the kernel still alive?  (and the bound of host_wait.hpp)
+                const int64_t lim = ldpc_detail::wait_limit_ms();
+                if (lim > 0 && std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - lat_t0).count() > lim)
+                    return ldpc_detail::wait_stream(nullptr, d->device, "BP-OTS latency path (flag of the last workgroup)");   // (expires at once: names the wait, marks the device)
                 const hipError_t q = hipStreamQuery(nullptr);
                 if (q == hipSuccess) {
                     if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == lc.ticket) break;
@@ -330,7 +339,11 @@ ldpc_status ldpc_bpots_decode_batch(ldpc_bpots_decoder *d, int64_t batch, const 
         return LDPC_OK;
     }
     if (d->stage_cap < total) {
-        if (d->stage) (void)hipFree(d->stage);
+        if (d->stage) {
+            const ldpc_status ws = ldpc_detail::wait_device(d->device, "BP-OTS staging regrow (device synchronise before the free)");
+            if (ws != LDPC_OK) return ws;
+            (void)hipFree(d->stage);
+        }
         d->stage = nullptr; d->stage_cap = 0;
         OTS_TRY(hipMalloc(&d->stage, total));
         d->stage_cap = total;
@@ -343,8 +356,7 @@ ldpc_status ldpc_bpots_decode_batch(ldpc_bpots_decoder *d, int64_t batch, const 
     if (n > 0) OTS_TRY(hipMemcpyAsync(err, dp + o_err, B * n, hipMemcpyDeviceToHost, nullptr));
     OTS_TRY(hipMemcpyAsync(conv, dp + o_conv, B, hipMemcpyDeviceToHost, nullptr));
     if (iters) OTS_TRY(hipMemcpyAsync(iters, dp + o_it, B * 4, hipMemcpyDeviceToHost, nullptr));
-    OTS_TRY(hipStreamSynchronize(nullptr));
-    return LDPC_OK;
+    return ldpc_detail::wait_stream(nullptr, d->device, "ldpc_bpots_decode_batch (stream synchronise)");
 }
 
 }  // extern "C"

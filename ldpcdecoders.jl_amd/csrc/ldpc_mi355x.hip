@@ -18,12 +18,16 @@
 #include "bp_team_kernels.hpp"
 #include "pickers.hpp"
 #include "host_env.hpp"
+#include "host_wait.hpp"
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -48,6 +52,112 @@ ldpc_status fail(ldpc_status st, const std::string &msg)
 namespace ldpc_detail {
 // shared with osd_host.cpp: records the message ldpc_last_error() returns
 ldpc_status set_error(ldpc_status st, const std::string &msg) { return fail(st, msg); }
+
+// ---- bounded host-side waits (host_wait.hpp)
+namespace {
+std::atomic<int64_t> g_wait_limit_ms{600000};
+constexpr int kMaxDev = 64;
+std::atomic<bool> g_stalled[kMaxDev];
+std::mutex g_stall_mu;
+std::string g_stall_msg[kMaxDev];
+
+ldpc_status expired(int device, const char *what, int64_t limit_ms)
+{
+    const std::string msg = std::string(what) + ": the device did not get there within " + std::to_string(limit_ms / 1000) + "." +
+                            std::to_string(limit_ms % 1000 / 100) + " s (ldpc_set_wait_limit_ms); device " + std::to_string(device) +
+                            " is taken to be stalled: every later call on it fails with this message, and what it may still be "
+                            "using is not freed";
+    if (device >= 0 && device < kMaxDev) {
+        std::lock_guard<std::mutex> lk(g_stall_mu);
+        if (!g_stalled[device].load()) { g_stall_msg[device] = msg; g_stalled[device].store(true); }
+    }
+    return fail(LDPC_ERR_HIP, msg);
+}
+
+template <class Query>
+ldpc_status poll_until(Query &&query, int device, const char *what)
+{
+    if (device_stalled(device)) return stalled_error(device);
+    const int64_t limit = g_wait_limit_ms.load(std::memory_order_relaxed);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t q = query();
+        if (q == hipSuccess) return LDPC_OK;
+        if (q != hipErrorNotReady) {
+            (void)hipGetLastError();
+            return fail(LDPC_ERR_HIP, std::string(what) + ": " + hipGetErrorString(q));
+        }
+        if (spins < 64) { __builtin_ia32_pause(); continue; }   // (a query is ~1 us: the first polls back to back)
+        const int64_t us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (limit > 0 && us > limit * 1000) return expired(device, what, limit);
+        if (us < 300) __builtin_ia32_pause();                    // latency-bound calls (a small batch is ~100 us): keep polling
+        else if (us < 5000) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(us < 100000 ? 50 : 200));
+    }
+}
+}  // namespace
+
+int64_t wait_limit_ms() { return g_wait_limit_ms.load(std::memory_order_relaxed); }
+bool device_stalled(int device) { return device >= 0 && device < kMaxDev && g_stalled[device].load(std::memory_order_acquire); }
+ldpc_status stalled_error(int device)
+{
+    std::lock_guard<std::mutex> lk(g_stall_mu);
+    return fail(LDPC_ERR_HIP, (device >= 0 && device < kMaxDev) ? g_stall_msg[device] : std::string("device stalled"));
+}
+ldpc_status wait_event(hipEvent_t e, int device, const char *what)
+{
+    if (wait_limit_ms() == 0 && !device_stalled(device)) {       // unbounded, as before round 4
+        const hipError_t q = hipEventSynchronize(e);
+        if (q == hipSuccess) return LDPC_OK;
+        (void)hipGetLastError();
+        return fail(LDPC_ERR_HIP, std::string(what) + ": " + hipGetErrorString(q));
+    }
+    return poll_until([&] { return hipEventQuery(e); }, device, what);
+}
+ldpc_status wait_stream(hipStream_t s, int device, const char *what)
+{
+    if (wait_limit_ms() == 0 && !device_stalled(device)) {
+        const hipError_t q = hipStreamSynchronize(s);
+        if (q == hipSuccess) return LDPC_OK;
+        (void)hipGetLastError();
+        return fail(LDPC_ERR_HIP, std::string(what) + ": " + hipGetErrorString(q));
+    }
+    return poll_until([&] { return hipStreamQuery(s); }, device, what);
+}
+// hipDeviceSynchronize has no query form: it runs in a helper thread that the caller waits for with the deadline; a
+// thread that never comes back is left behind (detached) with the state it shares with nobody else.
+ldpc_status wait_device(int device, const char *what)
+{
+    if (device_stalled(device)) return stalled_error(device);
+    const int64_t limit = wait_limit_ms();
+    if (limit == 0) {
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        hipError_t q = hipSetDevice(device);
+        if (q == hipSuccess) q = hipDeviceSynchronize();
+        if (prev >= 0) (void)hipSetDevice(prev);
+        if (q == hipSuccess) return LDPC_OK;
+        (void)hipGetLastError();
+        return fail(LDPC_ERR_HIP, std::string(what) + ": " + hipGetErrorString(q));
+    }
+    struct Shared { std::mutex m; std::condition_variable cv; bool done = false; hipError_t e = hipSuccess; };
+    auto sh = std::make_shared<Shared>();
+    std::thread([sh, device] {
+        hipError_t q = hipSetDevice(device);
+        if (q == hipSuccess) q = hipDeviceSynchronize();
+        if (q != hipSuccess) (void)hipGetLastError();
+        std::lock_guard<std::mutex> lk(sh->m);
+        sh->e = q; sh->done = true;
+        sh->cv.notify_all();
+    }).detach();
+    std::unique_lock<std::mutex> lk(sh->m);
+    if (!sh->cv.wait_for(lk, std::chrono::milliseconds(limit), [&] { return sh->done; })) {
+        lk.unlock();
+        return expired(device, what, limit);
+    }
+    if (sh->e == hipSuccess) return LDPC_OK;
+    return fail(LDPC_ERR_HIP, std::string(what) + ": " + hipGetErrorString(sh->e));
+}
 }  // namespace ldpc_detail
 
 namespace {
@@ -118,13 +228,15 @@ struct ChunkGroup {
         if (!resv) return;
         DeviceGuard guard;
         (void)hipSetDevice(device);
-        (void)hipDeviceSynchronize();
-        if (vmm_log()) std::fprintf(stderr, "[ldpc-vmm] unmap %p .. %p\n", (void *)base, (void *)(base + bytes()));
-        for (size_t k = 0; k < mapped; ++k) (void)hipMemUnmap(base + k * chunk, chunk);   // one unmap per map
-        for (auto q : h) (void)hipMemRelease(q);
-        (void)hipDeviceSynchronize();
-        (void)hipMemAddressFree(resv, resv_size);   // never handed out again: the cursor only moves up
-        (void)hipGetLastError();
+        // (bounded, host_wait.hpp: a device that does not drain keeps its mappings -- leaked, never unmapped under a kernel)
+        if (ldpc_detail::device_idle_for_release(device, "chunk group release (device synchronise before the unmap)")) {
+            if (vmm_log()) std::fprintf(stderr, "[ldpc-vmm] unmap %p .. %p\n", (void *)base, (void *)(base + bytes()));
+            for (size_t k = 0; k < mapped; ++k) (void)hipMemUnmap(base + k * chunk, chunk);   // one unmap per map
+            for (auto q : h) (void)hipMemRelease(q);
+            if (ldpc_detail::device_idle_for_release(device, "chunk group release (device synchronise after the unmap)"))
+                (void)hipMemAddressFree(resv, resv_size);   // never handed out again: the cursor only moves up
+            (void)hipGetLastError();
+        }
         h.clear();
         resv = nullptr; base = nullptr;
         resv_size = chunk = mapped = 0;
@@ -194,11 +306,14 @@ uintptr_t vmm_next_address(size_t bytes, size_t align)
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    int device = -1;  // where p lives (set when it is allocated)
     ChunkGroup grp;   // set when the buffer is a chunk group (ensure_chunked), empty for hipMalloc
     ldpc_status ensure(size_t bytes)
     {
         if (bytes <= cap) return LDPC_OK;
         release();
+        if (hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); device = -1; }
+        if (ldpc_detail::device_stalled(device)) return ldpc_detail::stalled_error(device);
         hipError_t e = hipMalloc(&p, bytes);
         if (e == hipErrorOutOfMemory) {   // the pool may be what is in the way
             (void)hipGetLastError();
@@ -295,19 +410,23 @@ struct DevBuf {
     {
         std::swap(p, o.p);
         std::swap(cap, o.cap);
+        std::swap(device, o.device);
         std::swap(grp, o.grp);
     }
-    void release()
+    // device_idle: the caller has just waited for the device (ldpc_bp_destroy).  Every wait here is bounded
+    // (host_wait.hpp): memory of a device that does not drain is leaked, not freed under a kernel that may still run.
+    void release(bool device_idle = false)
     {
         if (!grp.empty()) {
             // hipFree waits for the device by itself; a group that goes to the pool still mapped must do so explicitly:
             // kernels of earlier asynchronous calls may still be using it when the next owner takes it over
-            DeviceGuard guard;
-            (void)hipSetDevice(grp.device);
-            (void)hipDeviceSynchronize();
-            (void)hipGetLastError();
-            pool_put(std::move(grp));
-        } else if (p) (void)hipFree(p);
+            if (device_idle || ldpc_detail::device_idle_for_release(grp.device, "workspace release (device synchronise before pooling)"))
+                pool_put(std::move(grp));
+            else { grp.h.clear(); grp.resv = nullptr; }   // (leaked)
+        } else if (p) {
+            if (device_idle || device < 0 || ldpc_detail::device_idle_for_release(device, "hipFree (device synchronise before the free)"))
+                (void)hipFree(p);
+        }
         grp = ChunkGroup();
         p = nullptr;
         cap = 0;
@@ -380,6 +499,8 @@ struct ldpc_bp_decoder {
     int team_pairs = 3;       // LDPC_TEAM_PAIRS: bit 0: two nodes of the full degree are loaded together; bit 1: the four bits of a position chunk (rows-on-chip kernels)
     int team_ahead_from = 1;  // LDPC_TEAM_AHEAD_FROM: first iteration whose test may ride with the next check sweep (1: realistic -1.6 %, waterfall -0.7 % against 2, profiles/r03_ahead_from1.txt)
     bool team_ahead_set = false;   // LDPC_TEAM_AHEAD given (else: 1 for a single round of teams over all XCDs)
+    int team_llr_raw = 1;     // LDPC_TEAM_LLR_RAW: what the team kernel's variable sweep stores per bit when LLRs are wanted (TeamParams::llr_raw)
+    bool team_llr_footprint = true;   // LDPC_TEAM_LLR_FOOTPRINT: the plan counts a tile's LLR rows (n x 512 B, rewritten in every iteration) as part of its slot
     int team_ahead = 32;      // LDPC_TEAM_AHEAD: active lanes from which on a team starts the next check sweep with the convergence
                               // test still under way (two team barriers an iteration instead of three); 0 = never
     // latency mode of the host-pointer entry (tiny batches, a plain decode!): the kernel reads and writes a
@@ -437,20 +558,24 @@ struct ldpc_bp_decoder {
     int inject_fault = 0;          // tests (experiments build, LDPC_TEAM_INJECT_FAULT at create): 1 = team kernels raise the fault word at once, 2 = a member misses the roll call
     unsigned rollcall_ticks = 2000000u;   // 20 ms of the 100 MHz clock: how long the members of a team wait for each other at launch (team_rollcall)
 
+    bool device_idle = false;      // ldpc_bp_destroy has waited for the device: frees need not wait again
     ~ldpc_bp_decoder()
     {
+        const bool stalled = ldpc_detail::device_stalled(device);   // (then nothing is freed: host_wait.hpp)
+        const bool idle = device_idle && !stalled;
         DevBuf *all[] = {&row_ptr, &edge_bit, &col_ptr, &csc2csr, &msg, &ctrl, &synmask, &nevermask,
                          &errmask, &finmask, &llr_t, &st_all, &node_msg, &done_ctr, &team_ws, &team_ws_lvl[0], &team_ws_lvl[1], &cold,
                          &rows_ctab, &rows_vtab, &rows_lds_edge, &rows_reg_edge};
-        for (DevBuf *b : all) b->release();
+        for (DevBuf *b : all) b->release(idle);
         for (int l = 0; l < 2; ++l)
-            for (DevBuf *b : {&lvl_state[l], &lvl_list[l], &lvl_it[l], &lvl_syn[l], &lvl_never[l], &lvl_err[l], &lvl_fin[l], &lvl_llr[l]}) b->release();
+            for (DevBuf *b : {&lvl_state[l], &lvl_list[l], &lvl_it[l], &lvl_syn[l], &lvl_never[l], &lvl_err[l], &lvl_fin[l], &lvl_llr[l]}) b->release(idle);
+        for (DevBuf &b : pipe_dev) b.release(idle);
+        if (stalled) return;   // pinned memory the device may still write, streams it may still run: left alone
         if (pin) (void)hipHostFree(pin);
         if (lat_pin) (void)hipHostFree(lat_pin);
         if (team_fault) (void)hipHostFree(team_fault);
         for (void *&q : pipe_pin)
             if (q) (void)hipHostFree(q);
-        for (DevBuf &b : pipe_dev) b.release();
         for (hipStream_t &q : pipe_stream)
             if (q) (void)hipStreamDestroy(q);
         for (auto &row : pipe_ev)
@@ -581,7 +706,7 @@ static ldpc_status ensure_workspace(ldpc_bp_decoder *d, size_t bytes, int grid, 
         if (hipEventRecord(ea, stream) != hipSuccess) return -1.f;
         hipLaunchKernelGGL(placement_probe_kernel, dim3((unsigned)grid), dim3(512), 0, stream, (double *)q, stride, (int)d->nnz);
         float ms = -1.f;
-        if (hipEventRecord(eb, stream) != hipSuccess || hipEventSynchronize(eb) != hipSuccess ||
+        if (hipEventRecord(eb, stream) != hipSuccess || ldpc_detail::wait_event(eb, d->device, "workspace placement probe") != LDPC_OK ||
             hipEventElapsedTime(&ms, ea, eb) != hipSuccess)
             return -1.f;
         return ms;
@@ -624,10 +749,11 @@ static ldpc_status ensure_workspace(ldpc_bp_decoder *d, size_t bytes, int grid, 
             if (tbs.back() > tbs[best]) best = held.size() - 1;
         }
     }
-    (void)hipStreamSynchronize(stream);
+    const ldpc_status wst = ldpc_detail::wait_stream(stream, d->device, "workspace placement probe (stream synchronise)");
     (void)hipGetLastError();
     (void)hipEventDestroy(ea);
     (void)hipEventDestroy(eb);
+    if (wst != LDPC_OK) return wst;   // (the groups held are leaked or pooled by their destructors' own bounded waits)
     d->msg.swap(held[best]);
     d->placement_ms = tbs[best] > 0 ? (float)(probe_bytes / ((double)tbs[best] * 1e12) * 1e3) : 0.f;
     d->placement_candidates = probed;
@@ -642,6 +768,14 @@ static ldpc_status ensure_workspace(ldpc_bp_decoder *d, size_t bytes, int grid, 
 extern "C" {
 
 int32_t ldpc_abi_version(void) { return LDPC_MI355X_ABI_VERSION; }
+
+ldpc_status ldpc_set_wait_limit_ms(int64_t ms)
+{
+    if (ms < 0) return fail(LDPC_ERR_INVALID_ARGUMENT, "negative wait limit");
+    ldpc_detail::g_wait_limit_ms.store(ms);
+    return LDPC_OK;
+}
+int64_t ldpc_get_wait_limit_ms(void) { return ldpc_detail::wait_limit_ms(); }
 
 ldpc_status ldpc_trim_memory(void)
 {
@@ -704,6 +838,7 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(LDPC_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    if (ldpc_detail::device_stalled(device)) return ldpc_detail::stalled_error(device);
 
     ldpc_bp_decoder *d = new (std::nothrow) ldpc_bp_decoder();
     if (!d) return fail(LDPC_ERR_OUT_OF_MEMORY, "host allocation failed");
@@ -780,6 +915,8 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     if (const char *e = exp_env("LDPC_TEAM_PAIRS")) d->team_pairs = std::atoi(e) & 3;   // (bit 1: four bits at once in the variable sweep)
     if (const char *e = exp_env("LDPC_TEAM_AHEAD")) { d->team_ahead = std::max(0, std::min(65, std::atoi(e))); d->team_ahead_set = true; }
     if (const char *e = exp_env("LDPC_TEAM_AHEAD_FROM")) d->team_ahead_from = std::max(1, std::atoi(e));
+    if (const char *e = exp_env("LDPC_TEAM_LLR_RAW")) d->team_llr_raw = std::max(0, std::min(2, std::atoi(e)));
+    if (const char *e = exp_env("LDPC_TEAM_LLR_FOOTPRINT")) d->team_llr_footprint = std::atoi(e) != 0;
     if (const char *e = exp_env("LDPC_TEAM_REGS")) d->team_regs = std::max(0, std::min(kTeamRegRows, std::atoi(e)));
     if (const char *e = exp_env("LDPC_TEAM_FLIP")) d->team_flip = std::atoi(e) & 3;
     if (const char *e = exp_env("LDPC_TEAM_STATIC")) d->team_static_quarters = std::max(0, std::min(4, std::atoi(e)));
@@ -868,10 +1005,12 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
 ldpc_status ldpc_bp_destroy(ldpc_bp_decoder *dec)
 {
     if (!dec) return LDPC_OK;
+    DeviceGuard guard;
     (void)hipSetDevice(dec->device);
-    (void)hipDeviceSynchronize();
-    delete dec;
-    return LDPC_OK;
+    const ldpc_status st = ldpc_detail::wait_device(dec->device, "ldpc_bp_destroy (device synchronise)");
+    dec->device_idle = st == LDPC_OK;
+    delete dec;          // (a stalled device: the handle goes, what the device may still use is leaked)
+    return st;
 }
 
 ldpc_status ldpc_bp_get_info(const ldpc_bp_decoder *d, ldpc_bp_info *info)
@@ -1013,6 +1152,9 @@ struct TeamPlanIn {
     // all-XCD teams against one team per XCD: 1 tile 2.4 / 3.4 against 5.1 / 10.2 ms, 2 tiles 3.3 / 5.2, 3 tiles 4.3 / 7.1,
     // 4 tiles 5.09 / 10.7 against 5.00 / 10.2, 5 tiles 6.1 / 13.9 against 5.1 / 12.1 -- profiles/r03_scatter_tiles.txt)
     int scatter_tiles = 3;
+    // bytes a team keeps rewriting besides its message slot: with LLRs wanted the posterior odds of every bit of the tile in
+    // hand, n x 512 B per iteration (they live in the cache with the slot, and count against the same budget)
+    size_t extra = 0;
 };
 
 // What a member is expected to keep on chip (a bit dealt to a member that owns one of its dv checks: 1 / dv of the edges
@@ -1096,7 +1238,8 @@ static TeamRowTables team_rows_tables(int n, int s, int nnz, int dc, int dv, con
     }
     for (int j = 0, m = 0; j < n; ++j) {
         if (member_of_bit[(size_t)j] >= 0) continue;
-        while (room[(size_t)m] == 0) ++m;
+        while (m < G && room[(size_t)m] == 0) ++m;
+        if (m >= G) std::abort();   // (cannot happen: the members' rooms add up to n positions and every bit takes one)
         member_of_bit[(size_t)j] = m; room[(size_t)m]--;
     }
     // positions of every member in ascending order, and which of them belong to a wave by right
@@ -1131,7 +1274,8 @@ static TeamRowTables team_rows_tables(int n, int s, int nnz, int dc, int dv, con
         size_t b = 0;
         for (int p : pos_of[(size_t)m]) {
             if (bit[(size_t)p] >= 0) continue;
-            while (placed[b]) ++b;
+            while (b < placed.size() && placed[b]) ++b;
+            if (b >= placed.size()) std::abort();   // (cannot happen: a member has as many bits as positions)
             bit[(size_t)p] = bits_of[(size_t)m][b++];
         }
     }
@@ -1251,7 +1395,7 @@ static ldpc_status team_rows_build(ldpc_bp_decoder *d, int G)
         return LDPC_OK;
     };
     ldpc_status st;
-    (void)hipDeviceSynchronize();   // (a launch that still reads the tables of another G)
+    if ((st = ldpc_detail::wait_device(d->device, "team row tables (device synchronise before the tables are replaced)")) != LDPC_OK) return st;   // (a launch that still reads the tables of another G)
     if ((st = up(d->rows_ctab, t.ctab)) != LDPC_OK || (st = up(d->rows_vtab, t.vtab)) != LDPC_OK ||
         (st = up(d->rows_lds_edge, t.lds_edge)) != LDPC_OK || (st = up(d->rows_reg_edge, t.reg_edge)) != LDPC_OK)
         return st;
@@ -1286,12 +1430,12 @@ static bool team_fit(const TeamPlanIn &in, int64_t ntiles, bool rows, int *xcds,
     for (int pass = 0; pass < 2; ++pass)
     for (int x = x_hi; x >= x_lo; --x)
         for (int t = 1; t <= per_xcd / 3; ++t) {
-            if ((size_t)x * (size_t)t * (state - (rows ? state / (size_t)std::max(in.rows_dv, 1) : 0)) > cache) break;   // (1 / dv at most can be in LDS)
+            if ((size_t)x * (size_t)t * (state + in.extra - (rows ? state / (size_t)std::max(in.rows_dv, 1) : 0)) > cache) break;   // (1 / dv at most can be in LDS)
             if (t > 1 && (int64_t)x * (t - 1) >= ntiles) break;            // no more teams than tiles
             const int g = std::min(t == 1 ? std::max(gcap, in.gcap_one) : gcap, per_xcd / t);
             if (g < 3) break;
             // rows that the members keep in LDS are not in the cache
-            if ((size_t)x * (size_t)t * (state - (rows ? (size_t)g * team_rows_expected(in, g) * kTile * sizeof(double) : 0)) > cache) continue;
+            if ((size_t)x * (size_t)t * (state + in.extra - (rows ? (size_t)g * team_rows_expected(in, g) * kTile * sizeof(double) : 0)) > cache) continue;
             const int64_t w = std::min<int64_t>((int64_t)x * t, ntiles) * g;   // workgroups with a tile
             if (pass == 0) { if (w > best) best = w; }
             else if (w * 100 >= best * 85) { *xcds = x; *tpx = t; *G = g; return true; }
@@ -1367,9 +1511,10 @@ static TeamPlan team_plan_pure(const TeamPlanIn &in, int64_t batch)
     return pl;
 }
 
-static TeamPlanIn team_plan_in(const ldpc_bp_decoder *d, int per_xcd, int gcap, int gcap_one = 0)
+static TeamPlanIn team_plan_in(const ldpc_bp_decoder *d, int per_xcd, int gcap, int gcap_one = 0, bool want_llr = false)
 {
     TeamPlanIn in;
+    in.extra = (want_llr && d->team_llr_footprint) ? (size_t)std::max<int64_t>(d->n, 0) * kTile * sizeof(double) : 0;
     in.nnz = d->nnz; in.max_iters = d->max_iters; in.cache = d->team_cache; in.xcds_forced = d->team_xcds;
     in.team_max_set = d->team_max_set; in.rows_possible = team_rows_possible(d); in.rows_dv = std::max(d->rows_dv, 1); in.num_cus = d->num_cus;
     in.reg_rows = in.rows_possible ? d->team_regs * (LDPC_TEAM_THREADS / 64) : 0;
@@ -1384,7 +1529,7 @@ static TeamPlan team_plan(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
 {
     int per_xcd = 0, gcap = 0, gcap_one = 0;
     if (!team_geometry(d, want_llr, &per_xcd, &gcap, &gcap_one)) return TeamPlan();
-    return team_plan_pure(team_plan_in(d, per_xcd, gcap, gcap_one), batch);
+    return team_plan_pure(team_plan_in(d, per_xcd, gcap, gcap_one, want_llr), batch);
 }
 
 // include/ldpc_mi355x_debug.h: the plan for a CPU test (an MI355X's geometry: 256 CUs, one team workgroup per CU)
@@ -1445,7 +1590,9 @@ static ldpc_status report_team_fault(ldpc_bp_decoder *d)
     if (ticket == 0u) return LDPC_OK;
     if (d->last_ev) {
         (void)hipSetDevice(d->device);
-        if (hipEventSynchronize(d->last_ev) != hipSuccess) (void)hipGetLastError();
+        // (no member may still be polling the word when it is cleared: a wait that expires leaves it set)
+        const ldpc_status wst = ldpc_detail::wait_event(d->last_ev, d->device, "team fault report (wait for the handle's last call)");
+        if (wst != LDPC_OK) return wst;
     }
     __atomic_store_n(d->team_fault, 0u, __ATOMIC_RELEASE);
     d->team_max = 1;
@@ -1471,6 +1618,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     if ((d->s > 0 && !d_syn) || (d->n > 0 && !d_err) || !d_conv)
         return fail(LDPC_ERR_INVALID_ARGUMENT, "syndromes/errors/converged pointer is NULL");
     HIP_TRY(hipSetDevice(d->device));
+    if (ldpc_detail::device_stalled(d->device)) return ldpc_detail::stalled_error(d->device);
     const int64_t s = d->s, n = d->n;
     {
         const ldpc_status fst = report_team_fault(d);   // a refused call is not counted and enqueues nothing
@@ -1836,9 +1984,11 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         tp.errmask_alt = nullptr;
         tp.ahead_min = 0;
         tp.ahead_from = 2;
+        tp.llr_raw = 0;
         return LDPC_OK;
     };
     bool team_ran = team > 1;
+    int llr_raw_out = 0;   // the fresh pass left posterior odds, not logarithms, in llr_t (TeamParams::llr_raw)
     HIP_TRY(hipEventRecord(ev[1], stream));
     if (team > 1) {
         TeamParams tp{};
@@ -1850,6 +2000,8 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         tp.errmask_alt = (u64 *)d->errmask.p + std::max<size_t>((size_t)ntiles * n, 1);
         tp.ahead_min = d->team_ahead;
         tp.ahead_from = d->team_ahead_from;
+        tp.llr_raw = want_llr ? d->team_llr_raw : 0;
+        llr_raw_out = tp.llr_raw != 0;
         // one round of teams over all XCDs (<= 3 tiles: a single decode!): no other tile waits for this team, so a sweep
         // ahead that turns out to be for nothing costs one sweep at the end, and the barrier saved in every iteration
         // is worth it whatever the number of active lanes (one syndrome, 50 iterations: 2.62 -> 2.31 ms)
@@ -1888,11 +2040,12 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             p.msg = (double *)d->msg.p;
             kfn = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, threads);
             team_ran = false;
+            llr_raw_out = 0;
         }
         if (team_ran && exp_env("LDPC_TEAM_DEBUG")) {   // diagnostics: which XCDs did the teams land on?
             const int nt = std::min(plan.nteams, ntiles);
             std::vector<unsigned> xm((size_t)nt);
-            (void)hipStreamSynchronize(stream);
+            (void)ldpc_detail::wait_stream(stream, d->device, "LDPC_TEAM_DEBUG (stream synchronise)");
             for (int t = 0; t < nt; ++t)
                 (void)hipMemcpy(&xm[(size_t)t], tp.ctl + (size_t)t * kTeamCtlWords + 32, sizeof(unsigned), hipMemcpyDeviceToHost);
             int single = 0;
@@ -1975,7 +2128,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         HIP_TRY(hipGetLastError());
         if (want_llr) {
             hipLaunchKernelGGL(unpack_llr_kernel, g, dim3(256), 0, stream, (const double *)d->llr_t.p,
-                               (long long)batch, (int)n, d_llr, (const int *)nullptr, (const unsigned int *)nullptr, 0u);
+                               (long long)batch, (int)n, d_llr, (const int *)nullptr, (const unsigned int *)nullptr, 0u, llr_raw_out);
             HIP_TRY(hipGetLastError());
         }
         for (int l = 1; l <= nlevels; ++l) {
@@ -1987,7 +2140,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             if (want_llr) {
                 hipLaunchKernelGGL(unpack_llr_kernel, g2, dim3(256), 0, stream, (const double *)d->lvl_llr[l - 1].p,
                                    (long long)0, (int)n, d_llr, (const int *)d->lvl_list[l - 1].p,
-                                   (const unsigned int *)lv[l].count, lv[l].node_take);
+                                   (const unsigned int *)lv[l].count, lv[l].node_take, 0);
                 HIP_TRY(hipGetLastError());
             }
         }
@@ -2097,9 +2250,13 @@ static ldpc_status decode_batch_host_impl(ldpc_bp_decoder *d, int64_t batch, con
             st = decode_device_impl(d, batch, (const uint8_t *)dp, (uint8_t *)(dp + o_err), (uint8_t *)(dp + o_conv),
                                     llr ? (double *)(dp + o_llr) : nullptr, (int32_t *)(dp + o_it), stream, &lc);
             if (st != LDPC_OK) return st;
+            const auto lat_t0 = std::chrono::steady_clock::now();
             for (uint64_t spins = 1;; ++spins) {
                 if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == lc.ticket) break;
-                if ((spins & 0xffff) == 0) {   // every ~65k polls: is the kernel still alive?
+                if ((spins & 0xffff) == 0) {   // every ~65k polls: is the kernel still alive?  (and the bound of host_wait.hpp)
+                    const int64_t lim = ldpc_detail::wait_limit_ms();
+                    if (lim > 0 && std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - lat_t0).count() > lim)
+                        return ldpc_detail::wait_stream(stream, d->device, "latency path (flag of the last workgroup)");   // (expires at once: names the wait, marks the device)
                     const hipError_t q = hipStreamQuery(stream);
                     if (q == hipSuccess) {
                         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == lc.ticket) break;
@@ -2133,7 +2290,7 @@ static ldpc_status decode_batch_host_impl(ldpc_bp_decoder *d, int64_t batch, con
                                              llr ? (double *)(dp + o_llr) : nullptr, (int32_t *)(dp + o_it), stream);
             if (st != LDPC_OK) return st;
             HIP_TRY(hipMemcpyAsync(hp + o_err, dp + o_err, total - o_err, hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipStreamSynchronize(stream));
+            if ((st = ldpc_detail::wait_stream(stream, d->device, "ldpc_bp_decode_batch (small batch: stream synchronise)")) != LDPC_OK) return st;
             std::memcpy(err, hp + o_err, B * n);
             std::memcpy(conv, hp + o_conv, B);
             if (iters) std::memcpy(iters, hp + o_it, B * sizeof(int32_t));
@@ -2181,7 +2338,10 @@ static ldpc_status decode_batch_host_impl(ldpc_bp_decoder *d, int64_t batch, con
         auto drain = [&](size_t j) -> ldpc_status {
             const int slot = (int)(j % (size_t)R);
             const size_t b0 = j * cb, nb = std::min(cb, B - b0);
-            HIP_TRY(hipEventSynchronize(d->pipe_ev[slot][2]));
+            {
+                const ldpc_status wst = ldpc_detail::wait_event(d->pipe_ev[slot][2], d->device, "ldpc_bp_decode_batch (host pipeline: results of a chunk)");
+                if (wst != LDPC_OK) return wst;
+            }
             const char *hp = (const char *)d->pipe_pin[slot];
             parallel_memcpy(err + b0 * n, hp + o_err, nb * n);
             std::memcpy(conv + b0, hp + o_conv, nb);
@@ -2215,7 +2375,7 @@ static ldpc_status decode_batch_host_impl(ldpc_bp_decoder *d, int64_t batch, con
             for (size_t j = nchunks > (size_t)R ? nchunks - R : 0; j < nchunks && pst == LDPC_OK; ++j) pst = drain(j);
         if (pst != LDPC_OK) {
             const std::string keep = g_err;
-            (void)hipDeviceSynchronize();   // nothing of this call may still be in flight when we return
+            (void)ldpc_detail::wait_device(d->device, "ldpc_bp_decode_batch (host pipeline: drain after an error)");   // nothing of this call may still be in flight when we return
             g_err = keep;
         }
         return pst;
@@ -2226,7 +2386,10 @@ ldpc_status ldpc_bp_last_status(ldpc_bp_decoder *d)
 {
     if (!d) return fail(LDPC_ERR_INVALID_ARGUMENT, "decoder is NULL");
     HIP_TRY(hipSetDevice(d->device));
-    if (d->last_ev) HIP_TRY(hipEventSynchronize(d->last_ev));
+    if (d->last_ev) {
+        const ldpc_status wst = ldpc_detail::wait_event(d->last_ev, d->device, "ldpc_bp_last_status (wait for the handle's last call)");
+        if (wst != LDPC_OK) return wst;
+    }
     return report_team_fault(d);
 }
 
@@ -2243,7 +2406,10 @@ ldpc_status ldpc_bp_call_timing(ldpc_bp_decoder *d, int32_t calls_back, double *
     if (!d->timed[slot]) return LDPC_OK;
     HIP_TRY(hipSetDevice(d->device));
     const int e0 = d->two_events[slot] ? 1 : 0, e3 = d->two_events[slot] ? 2 : 3;
-    HIP_TRY(hipEventSynchronize(d->ev[slot][e3]));
+    {
+        const ldpc_status wst = ldpc_detail::wait_event(d->ev[slot][e3], d->device, "ldpc_bp_call_timing (wait for that call)");
+        if (wst != LDPC_OK) return wst;
+    }
     float a = 0.f, b = 0.f;
     HIP_TRY(hipEventElapsedTime(&a, d->ev[slot][1], d->ev[slot][2]));
     HIP_TRY(hipEventElapsedTime(&b, d->ev[slot][e0], d->ev[slot][e3]));
@@ -2266,7 +2432,10 @@ ldpc_status ldpc_bp_call_phase_ticks(ldpc_bp_decoder *d, int32_t calls_back, uin
     const int slot = (int)((d->ncalls - 1 - (uint64_t)calls_back) % ldpc_bp_decoder::kRing);
     if (!d->timed[slot]) return LDPC_OK;
     HIP_TRY(hipSetDevice(d->device));
-    HIP_TRY(hipEventSynchronize(d->ev[slot][d->two_events[slot] ? 2 : 3]));
+    {
+        const ldpc_status wst = ldpc_detail::wait_event(d->ev[slot][d->two_events[slot] ? 2 : 3], d->device, "ldpc_bp_call_phase_ticks (wait for that call)");
+        if (wst != LDPC_OK) return wst;
+    }
     HIP_TRY(hipMemcpy(ticks, (char *)d->ctrl.p + 64 * slot + 16, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return LDPC_OK;
 }

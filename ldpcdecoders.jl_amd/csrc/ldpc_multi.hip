@@ -22,6 +22,7 @@
 // There is no CPU path here either: everything decodes through ldpc_bp_decode_batch[_device].
 #include "../../include/ldpc_mi355x.h"
 #include "host_env.hpp"
+#include "host_wait.hpp"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -36,10 +37,7 @@
 #include <thread>
 #include <vector>
 
-namespace ldpc_detail {
-ldpc_status set_error(ldpc_status st, const std::string &msg);   // ldpc_mi355x.hip
-}
-using ldpc_detail::set_error;
+using ldpc_detail::set_error;   // (ldpc_mi355x.hip, declared in host_wait.hpp)
 
 namespace {
 
@@ -58,6 +56,7 @@ struct Rccl {
     void *lib = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -83,6 +82,7 @@ Rccl *rccl()
         };
         r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
         r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.CommAbort = (decltype(r.CommAbort))sym("ncclCommAbort");
         r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
         r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
         r.Send = (decltype(r.Send))sym("ncclSend");
@@ -98,8 +98,12 @@ Rccl *rccl()
         if (r_ != ncclSuccess) return set_error(LDPC_ERR_HIP, std::string(#expr) + ": " + (R)->GetErrorString(r_)); \
     } while (0)
 
-// An RCCL group that has been opened is closed on every path out of the scope (an error between ncclGroupStart and
-// ncclGroupEnd must not leave the communicators inside a group).
+// An RCCL group that has been opened is closed on every path out of the scope (the calling thread must not stay inside
+// a group).  Between ncclGroupStart and ncclGroupEnd ONLY RCCL's own calls can fail here -- buffers, streams and device
+// ordinals are all settled before the group opens --, and a group in which an RCCL call has failed is discarded by
+// ncclGroupEnd, not launched (NCCL 2.27 group.cc: the thread's group error makes ncclGroupEnd clean the queued tasks up
+// and return that error), so closing it cannot send the caller's stream waiting for a peer that never comes.  After
+// such a failure the communicators are aborted (exchange_failed()): the next root-device call builds new ones.
 struct GroupGuard {
     Rccl *R;
     bool open = false;
@@ -128,7 +132,7 @@ struct Buf {
         else { (void)hipGetLastError(); p = nullptr; }
         return e;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }   // (destroy_multi: after the device has been waited for)
 };
 
 }  // namespace
@@ -172,6 +176,7 @@ void destroy_multi(ldpc_bp_multi *m)
             if (R && c) (void)R->CommDestroy(c);
     }
     for (int g = 0; g < (int)m->dev.size(); ++g) {
+        if (ldpc_detail::device_stalled(m->dev[(size_t)g])) continue;   // (host_wait.hpp: nothing of a stalled device is freed)
         (void)hipSetDevice(m->dev[(size_t)g]);
         if (g < (int)m->shard.size()) {
             ldpc_bp_multi::Shard &sh = m->shard[(size_t)g];
@@ -185,6 +190,38 @@ void destroy_multi(ldpc_bp_multi *m)
     for (hipEvent_t &e : m->ev_t)
         if (e) (void)hipEventDestroy(e);
     delete m;
+}
+
+// Everything enqueued by a root-device call that is being given up -- on the peers' streams and on the root's -- has
+// finished (or the bounded wait has named what did not) before the call returns: the caller may free or reuse its
+// arrays, and the next call finds the shard buffers idle.
+void drain_streams(ldpc_bp_multi *m, hipStream_t root)
+{
+    const std::string keep = ldpc_last_error();
+    for (int g = 1; g < m->ndev; ++g)
+        if (m->st[(size_t)g] && hipSetDevice(m->dev[(size_t)g]) == hipSuccess)
+            (void)ldpc_detail::wait_stream(m->st[(size_t)g], m->dev[(size_t)g], "multi-device call given up: drain of a peer's stream");
+    if (hipSetDevice(m->dev[0]) == hipSuccess)
+        (void)ldpc_detail::wait_stream(root, m->dev[0], "multi-device call given up: drain of the root's stream");
+    (void)hipGetLastError();
+    (void)set_error(LDPC_ERR_HIP, keep);   // (the message of the failure itself, not of the drain)
+}
+
+// An RCCL call failed inside a group (the group has been closed and discarded by then, see GroupGuard): the
+// communicators are in an unknown state -- abort them; the next root-device call creates new ones.
+void exchange_failed(ldpc_bp_multi *m, hipStream_t root)
+{
+    drain_streams(m, root);
+    const std::string keep = ldpc_last_error();
+    if (m->comm_ready) {
+        Rccl *R = rccl();
+        for (ncclComm_t &c : m->comm) {
+            if (R && c) (void)(R->CommAbort ? R->CommAbort(c) : R->CommDestroy(c));
+            c = nullptr;
+        }
+        m->comm_ready = false;
+    }
+    (void)set_error(LDPC_ERR_HIP, keep);
 }
 
 ldpc_status ensure_comms(ldpc_bp_multi *m)
@@ -347,19 +384,36 @@ ldpc_status ldpc_bp_decode_batch_multi_device(ldpc_bp_multi *m, int64_t batch, c
 
     // ---- scatter: syndromes of shard g -> device g
     if (use_rccl) {
-        GroupGuard grp(N);
-        NCCL_TRY(N, grp.start());
-        for (int g = self ? 0 : 1; g < G; ++g) {
-            int64_t lo, hi;
-            shard_bounds(batch, G, g, &lo, &hi);
-            const size_t c = (size_t)(hi - lo);
-            if (!c || !s) continue;
-            MHIP_TRY(hipSetDevice(m->dev[0]));
-            NCCL_TRY(N, N->Send(d_syn + (size_t)lo * s, c * s, ncclUint8, g, m->comm[0], R));
-            MHIP_TRY(hipSetDevice(m->dev[(size_t)g]));
-            NCCL_TRY(N, N->Recv(m->shard[(size_t)g].syn.p, c * s, ncclUint8, 0, m->comm[(size_t)g], self ? R : m->st[(size_t)g]));
+        // (nothing but RCCL's own calls can fail inside the group: the device ordinals were checked at create, the shard
+        //  buffers are allocated above)
+        ncclResult_t nr = ncclSuccess;
+        const char *what = "ncclGroupStart (scatter)";
+        {
+            GroupGuard grp(N);
+            nr = grp.start();
+            for (int g = self ? 0 : 1; g < G && nr == ncclSuccess; ++g) {
+                int64_t lo, hi;
+                shard_bounds(batch, G, g, &lo, &hi);
+                const size_t c = (size_t)(hi - lo);
+                if (!c || !s) continue;
+                (void)hipSetDevice(m->dev[0]);
+                what = "ncclSend (scatter)";
+                nr = N->Send(d_syn + (size_t)lo * s, c * s, ncclUint8, g, m->comm[0], R);
+                if (nr != ncclSuccess) break;
+                (void)hipSetDevice(m->dev[(size_t)g]);
+                what = "ncclRecv (scatter)";
+                nr = N->Recv(m->shard[(size_t)g].syn.p, c * s, ncclUint8, 0, m->comm[(size_t)g], self ? R : m->st[(size_t)g]);
+            }
+            if (grp.open) {
+                const ncclResult_t er = grp.end();   // (after a failed call: discards the group and returns that error)
+                if (nr == ncclSuccess && er != ncclSuccess) { nr = er; what = "ncclGroupEnd (scatter)"; }
+            }
         }
-        NCCL_TRY(N, grp.end());
+        if (nr != ncclSuccess) {
+            (void)set_error(LDPC_ERR_HIP, std::string(what) + ": " + N->GetErrorString(nr));
+            exchange_failed(m, R);
+            return LDPC_ERR_HIP;
+        }
     } else if (G > 1) {
         MHIP_TRY(hipSetDevice(m->dev[0]));
         MHIP_TRY(hipEventRecord(m->ev_in, R));
@@ -392,38 +446,57 @@ ldpc_status ldpc_bp_decode_batch_multi_device(ldpc_bp_multi *m, int64_t batch, c
                                              d_llr ? (double *)sh.llr.p : nullptr, d_iters ? (int32_t *)sh.iters.p : nullptr,
                                              self ? R : m->st[(size_t)g]);
         }
-        if (ds != LDPC_OK) return ds;
+        if (ds != LDPC_OK) {
+            // shards 0 ... g - 1 and the scatter are enqueued, nothing will gather them: wait for them, so that the caller
+            // gets its arrays back idle and the shard buffers are free for the next call
+            drain_streams(m, R);
+            return ds;
+        }
     }
     MHIP_TRY(hipSetDevice(m->dev[0]));
     MHIP_TRY(hipEventRecord(m->ev_t[2], R));
 
     // ---- gather: hard decisions, flags (, iteration counts, LLRs) of shard g -> the caller's arrays on the root
     if (use_rccl) {
-        GroupGuard grp(N);
-        NCCL_TRY(N, grp.start());
-        for (int g = self ? 0 : 1; g < G; ++g) {
-            int64_t lo, hi;
-            shard_bounds(batch, G, g, &lo, &hi);
-            const size_t c = (size_t)(hi - lo);
-            if (!c) continue;
-            ldpc_bp_multi::Shard &sh = m->shard[(size_t)g];
-            hipStream_t P = self ? R : m->st[(size_t)g];
-            struct Piece { const void *src; void *dst; size_t count; ncclDataType_t ty; };
-            const Piece pieces[4] = {
-                {sh.err.p, d_err + (size_t)lo * n, c * n, ncclUint8},
-                {sh.conv.p, d_conv + lo, c, ncclUint8},
-                {d_iters ? sh.iters.p : nullptr, d_iters ? d_iters + lo : nullptr, c, ncclInt32},
-                {d_llr ? sh.llr.p : nullptr, d_llr ? d_llr + (size_t)lo * n : nullptr, c * n, ncclFloat64},
-            };
-            for (const Piece &q : pieces) {
-                if (!q.src || !q.count) continue;
-                MHIP_TRY(hipSetDevice(m->dev[(size_t)g]));
-                NCCL_TRY(N, N->Send(q.src, q.count, q.ty, 0, m->comm[(size_t)g], P));
-                MHIP_TRY(hipSetDevice(m->dev[0]));
-                NCCL_TRY(N, N->Recv(q.dst, q.count, q.ty, g, m->comm[0], R));
+        ncclResult_t nr = ncclSuccess;
+        const char *what = "ncclGroupStart (gather)";
+        {
+            GroupGuard grp(N);
+            nr = grp.start();
+            for (int g = self ? 0 : 1; g < G && nr == ncclSuccess; ++g) {
+                int64_t lo, hi;
+                shard_bounds(batch, G, g, &lo, &hi);
+                const size_t c = (size_t)(hi - lo);
+                if (!c) continue;
+                ldpc_bp_multi::Shard &sh = m->shard[(size_t)g];
+                hipStream_t P = self ? R : m->st[(size_t)g];
+                struct Piece { const void *src; void *dst; size_t count; ncclDataType_t ty; };
+                const Piece pieces[4] = {
+                    {sh.err.p, d_err + (size_t)lo * n, c * n, ncclUint8},
+                    {sh.conv.p, d_conv + lo, c, ncclUint8},
+                    {d_iters ? sh.iters.p : nullptr, d_iters ? d_iters + lo : nullptr, c, ncclInt32},
+                    {d_llr ? sh.llr.p : nullptr, d_llr ? d_llr + (size_t)lo * n : nullptr, c * n, ncclFloat64},
+                };
+                for (const Piece &q : pieces) {
+                    if (!q.src || !q.count) continue;
+                    (void)hipSetDevice(m->dev[(size_t)g]);
+                    what = "ncclSend (gather)";
+                    if ((nr = N->Send(q.src, q.count, q.ty, 0, m->comm[(size_t)g], P)) != ncclSuccess) break;
+                    (void)hipSetDevice(m->dev[0]);
+                    what = "ncclRecv (gather)";
+                    if ((nr = N->Recv(q.dst, q.count, q.ty, g, m->comm[0], R)) != ncclSuccess) break;
+                }
+            }
+            if (grp.open) {
+                const ncclResult_t er = grp.end();
+                if (nr == ncclSuccess && er != ncclSuccess) { nr = er; what = "ncclGroupEnd (gather)"; }
             }
         }
-        NCCL_TRY(N, grp.end());
+        if (nr != ncclSuccess) {
+            (void)set_error(LDPC_ERR_HIP, std::string(what) + ": " + N->GetErrorString(nr));
+            exchange_failed(m, R);
+            return LDPC_ERR_HIP;
+        }
     } else if (G > 1) {
         for (int g = 1; g < G; ++g) {
             int64_t lo, hi;
@@ -459,7 +532,8 @@ ldpc_status ldpc_bp_multi_last_status(ldpc_bp_multi *m)
     }
     if (m->timed) {
         (void)hipSetDevice(m->dev[0]);
-        if (hipEventSynchronize(m->ev_t[3]) != hipSuccess) (void)hipGetLastError();   // the gather on the root stream
+        const ldpc_status ws = ldpc_detail::wait_event(m->ev_t[3], m->dev[0], "ldpc_bp_multi_last_status (the gather on the root's stream)");
+        if (ws != LDPC_OK && first == LDPC_OK) { first = ws; msg = ldpc_last_error(); }
     }
     return first == LDPC_OK ? LDPC_OK : set_error(first, msg);
 }
@@ -474,7 +548,10 @@ ldpc_status ldpc_bp_multi_get_info(ldpc_bp_multi *m, ldpc_bp_multi_info *info)
     if (!m->timed) return LDPC_OK;
     DeviceGuard guard;
     MHIP_TRY(hipSetDevice(m->dev[0]));
-    MHIP_TRY(hipEventSynchronize(m->ev_t[3]));
+    {
+        const ldpc_status ws = ldpc_detail::wait_event(m->ev_t[3], m->dev[0], "ldpc_bp_multi_get_info (wait for the most recent root-device call)");
+        if (ws != LDPC_OK) return ws;
+    }
     float a = 0.f, b = 0.f, c = 0.f;
     MHIP_TRY(hipEventElapsedTime(&a, m->ev_t[0], m->ev_t[1]));
     MHIP_TRY(hipEventElapsedTime(&b, m->ev_t[1], m->ev_t[2]));

@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported(experiments):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/ldpc_mi355x.h but not exported"
     assert sorted(ldpc._capi.EXPORTED_SYMBOLS) == declared
-    assert lib.ldpc_abi_version() == 3 and lib.ldpc_build_target() == b"gfx950"
+    assert lib.ldpc_abi_version() == 4 and lib.ldpc_build_target() == b"gfx950"
     # the test hooks live in a header of their own, outside the drop-in boundary
     hooks = _declared_functions("ldpc_mi355x_debug.h")
     assert sorted(ldpc._capi.DEBUG_SYMBOLS) == hooks and not set(hooks) & set(declared)
@@ -223,18 +223,56 @@ def test_hot_kernels_keep_their_register_budget(tmp_path):
             assert xinfo[k]["private_segment_fixed_size"] == 0 and xinfo[k]["agpr_count"] == 0 and xinfo[k]["vgpr_count"] == 256, (k, xinfo[k])
         top = re.compile(r"\bv(19[2-9]|2[0-4]\d|25[0-5])\b|\bv\[\d+:(19[2-9]|2[0-4]\d|25[0-5])\]")
         ok_form = re.compile(r"^\s*v_mov_b32_e32 (v\d+, v19[23]|v19[23], v\d+)\b")
-        checked = 0
+        checked = idx_pairs = 0
         for co in cos:
             dis = subprocess.run([f"{llvm}/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout
             if "ELb0ELb1ELi32EEE" not in dis:
                 continue
             cur = None
+            # M0: s_set_gpr_idx_on writes it, so every accessor saves it into a scalar register first and puts it back after
+            # s_set_gpr_idx_off, with nothing in between but the s_nop and the two moves (bp_team_kernels.hpp)
+            prev, inside, saved = "", None, None
             for line in dis.splitlines():
                 m = re.match(r"[0-9a-f]+ <(\S+)>:", line)
                 if m:
+                    assert inside is None, (cur, "index mode left on at the end of a function")
                     cur = m.group(1)
+                    prev = ""
                     continue
-                if cur in regs and top.search(line.split("//")[0]):
+                if cur not in regs:
+                    continue
+                ins = line.split("//")[0].strip()
+                if not ins:
+                    continue
+                if top.search(ins):
                     assert ok_form.match(line), (cur, line)
+                    assert inside is not None, (cur, line, "a top register touched outside the index mode")
                     checked += 1
-        assert checked > 100, checked
+                if ins.startswith("s_set_gpr_idx_on"):
+                    ms = re.match(r"s_mov_b32 (s\d+), m0$", prev)
+                    assert ms, (cur, prev, ins, "M0 is not saved right before s_set_gpr_idx_on")
+                    saved, inside = ms.group(1), []
+                    idx_pairs += 1
+                elif ins.startswith("s_set_gpr_idx_off"):
+                    assert inside is not None and len(inside) == 3 and inside[0].startswith("s_nop") and \
+                        all(q.startswith("v_mov_b32") for q in inside[1:]), (cur, inside)
+                    inside = None
+                elif inside is not None:
+                    inside.append(ins)
+                elif saved is not None:
+                    assert ins == f"s_mov_b32 m0, {saved}", (cur, ins, "M0 is not restored right after s_set_gpr_idx_off")
+                    saved = None
+                prev = ins
+        assert checked > 100 and idx_pairs * 2 == checked, (checked, idx_pairs)
+
+
+def test_wait_limit_is_a_per_process_setting(ldpc):
+    """ldpc_set_wait_limit_ms / ldpc_get_wait_limit_ms (host_wait.hpp): the bound of every host-side wait; default ten
+    minutes, 0 = unbounded, negative rejected; needs no device."""
+    for exp_build in (False, True):
+        L = ldpc._capi.lib(exp_build)
+        assert L.ldpc_get_wait_limit_ms() == 600000
+        assert L.ldpc_set_wait_limit_ms(-1) == 1 and b"negative" in L.ldpc_last_error()
+        assert L.ldpc_set_wait_limit_ms(0) == 0 and L.ldpc_get_wait_limit_ms() == 0
+        assert L.ldpc_set_wait_limit_ms(12345) == 0 and L.ldpc_get_wait_limit_ms() == 12345
+        assert L.ldpc_set_wait_limit_ms(600000) == 0

@@ -21,13 +21,25 @@ DRY = os.environ.get("FUZZ_DRY") == "1"
 FROM, TO = int(os.environ.get("FUZZ_FROM", "0")), int(os.environ.get("FUZZ_TO", str(1 << 60)))
 VERBOSE = os.environ.get("FUZZ_VERBOSE") == "1"
 MAXCASES = int(os.environ.get("FUZZ_CASES", str(1 << 60)))
+# FUZZ_ORACLE_ONLY=1: no GPU at all -- time the CPU oracles of the cases FUZZ_FROM ... FUZZ_TO (every leg over 3 s is reported, and
+# with FUZZ_VERBOSE=1 every leg's seconds); FUZZ_OTS_CAP: syndromes the BP-OTS leg takes at most (600; 0 = the whole batch, as
+# the runs of round 3 before the cap did)
+ORACLE_ONLY = os.environ.get("FUZZ_ORACLE_ONLY") == "1"
+OTS_CAP = int(os.environ.get("FUZZ_OTS_CAP", "600"))
+if not (DRY or ORACLE_ONLY):
+    # every host-side wait of the library is bounded (host_wait.hpp): on these small graphs no leg needs more than seconds,
+    # so a stall names itself after 40 s (LDPC_ERR_HIP, "<which wait>: the device did not get there ...") instead of
+    # sitting silent until the runner's limit
+    for exp_build in (False, True):
+        ldpc._capi.check(ldpc._capi.lib(exp_build).ldpc_set_wait_limit_ms(int(os.environ.get("FUZZ_WAIT_LIMIT_MS", "40000"))), ldpc._capi.lib(exp_build))
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 t0, cases, decoded = time.time(), 0, 0
 last_note = t0
 while time.time() - t0 < budget and cases < MAXCASES:
-    skip = DRY or not (FROM <= cases <= TO)
+    in_range = FROM <= cases <= TO
+    skip = DRY or ORACLE_ONLY or not in_range
     kind = rng.integers(0, 5)
     mid = False
     if kind == 0:      # Gallager regular
@@ -68,10 +80,12 @@ while time.time() - t0 < budget and cases < MAXCASES:
         syn[rng.integers(0, B), rng.integers(0, s)] = rng.integers(2, 5)
     if DRY or VERBOSE:
         print(f"case {cases}: kind {int(kind)} shape {H.shape} nnz {H.nnz} per {per} iters {iters} B {B}", flush=True)
-    if not skip or os.environ.get("FUZZ_ORACLE_ONLY") == "1":
+    if not skip or (ORACLE_ONLY and in_range):
         t_or = time.time()
         oc = BPOracle(csc=(H.indptr, H.indices), shape=H.shape, per=per, max_iters=iters)
         oerr, oconv, ollr, oits = oc.batchdecode(syn)
+        if ORACLE_ONLY and VERBOSE:
+            print(f"   BP oracle {time.time() - t_or:.2f} s", flush=True)
         if time.time() - t_or > 3.0:
             print(f"SLOW ORACLE {time.time() - t_or:.1f} s: seed {seed} case {cases} kind {int(kind)} shape {H.shape} nnz {H.nnz} per {per} iters {iters} B {B}", flush=True)
     for variant in (0, 1, 3, 4):
@@ -171,16 +185,18 @@ while time.time() - t0 < budget and cases < MAXCASES:
         T, C = int(rng.choice([2, 3, 9])), float(rng.choice([1.0, 2.0, 3.0]))
         # (the CPU oracle of BP-OTS re-runs with biases and takes minutes for 5,000 syndromes x 50 iterations -- what looked
         #  like a stalled run in round 3 was this: the leg decodes the first 600 syndromes of the batch at most)
-        syn_ots = syn[:600]
+        syn_ots = syn[:OTS_CAP] if OTS_CAP > 0 else syn
         pp = max(per, 1e-3) if per < 0.9 else 0.3
         os.environ.pop("LDPC_BPOTS_FORCE_NODE", None)
         if rng.random() < 0.6:      # the node-parallel kernel (graphs beyond the LDS) or the unlimited one on a small graph
             os.environ["LDPC_BPOTS_FORCE_NODE"] = str(int(rng.integers(1, 3)))
         if DRY or VERBOSE:
             print(f"   BP-OTS T {T} C {C} per {pp} force {os.environ.get('LDPC_BPOTS_FORCE_NODE')}", flush=True)
-        if skip and os.environ.get("FUZZ_ORACLE_ONLY") == "1":
+        if ORACLE_ONLY and in_range:
             t_or = time.time()
             BPOTSOracle((H.indptr, H.indices), H.shape, pp, iters, T, C).batchdecode(syn_ots)
+            if VERBOSE:
+                print(f"   BP-OTS oracle {time.time() - t_or:.2f} s ({len(syn_ots)} syndromes)", flush=True)
             if time.time() - t_or > 3.0:
                 print(f"SLOW BP-OTS ORACLE {time.time() - t_or:.1f} s: seed {seed} case {cases} shape {H.shape} nnz {H.nnz} per {pp} iters {iters} B {B} T {T} C {C}", flush=True)
         if not skip:
