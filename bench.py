@@ -275,6 +275,109 @@ def also_workloads(ldpc, torch, H, Hcsr, n, nnz, device, local_rank, names=("c3_
     return res
 
 
+def also_small_configs(ldpc, torch, device, local_rank):
+    """BASELINE configs 1, 2 and 5 in the driver's own run, a few steps each, every result held against the oracle:
+      c2_n1008_batch4096   (3,6)-regular n = 1008, per 0.01, batchdecode! of 4096 HBM-resident syndromes (LDS-resident kernel);
+      c1_single_decode     the same code, batch = 1 through the HOST entry ldpc_bp_decode_batch with LLRs -- what a Julia
+                           `decode!` costs (BASELINE config 1 names the reference's CPU path for this case; the CPU oracle is
+                           timed beside it);
+      c5_bb72_bposd        BB [[72,12,6]] H_X, per 0.005, 2^20 syndromes: BP on the GPU, OSD-0 on the host for what BP
+                           leaves unconverged (ldpc_osd_postprocess_batch), end to end per step."""
+    import scipy.sparse as sp
+
+    from oracle import BPOracle, osd_oracle_postprocess
+
+    res = {}
+    # ---- config 2 and config 1: (3,6)-regular n = 1008
+    n, wr, wc, batch, per, max_iters = WORKLOADS["c2_n1008"]
+    H = ldpc.codes.parity_check_csc(n, wr, wc)
+    Hcsr = H.tocsr()
+    dec = ldpc.BeliefPropagationDecoder(H, per, max_iters, device=local_rank)
+    syn = make_syndromes(torch, Hcsr, n, batch, per, seed=4321, device=device)
+    err = torch.empty((batch, n), dtype=torch.uint8, device=device)
+    conv = torch.empty(batch, dtype=torch.uint8, device=device)
+    iters = torch.empty(batch, dtype=torch.int32, device=device)
+    for _ in range(3):
+        dec.decode_batch_device(syn, err, conv, None, iters)
+    torch.cuda.synchronize()
+    steps = 20
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        dec.decode_batch_device(syn, err, conv, None, iters)
+    dec.last_status()
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) / steps * 1e3
+    kernel_ms = sum(dec.last_timing(i)[0] for i in range(8)) / 8
+    h_syn, h_err, h_conv, h_it = (t.cpu().numpy() for t in (syn, err, conv, iters))
+    oc = BPOracle(csc=(H.indptr, H.indices), shape=H.shape, per=per, max_iters=max_iters)
+    t0 = time.perf_counter()
+    oerr, oconv, ollr, oits = oc.batchdecode(h_syn, want_llr=True)
+    cpu_s = time.perf_counter() - t0
+    ok = np.array_equal(oerr, h_err) and np.array_equal(oconv, h_conv) and np.array_equal(oits, h_it)
+    res["c2_n1008_batch4096"] = {"per": per, "batch": batch, "steps": steps, "ms_per_step": wall_ms, "kernel_ms": kernel_ms,
+                                 "value": batch / (wall_ms * 1e-3), "unit": "syndromes/s", "mean_iters": float(h_it.mean()),
+                                 "converged_frac": float(h_conv.mean()), "kernel": {1: "bp_tile_kernel", 2: "bp_lds_kernel", 3: "bp_node_kernel", 4: "bp_team_kernel"}.get(int(dec.info().last_kernel), "?"),
+                                 "gpu_matches_oracle_on_sample": bool(ok), "oracle_sample": int(batch),
+                                 "cpu_oracle_1_thread_syndromes_per_s": batch / cpu_s}
+    # config 1: one syndrome at a time through the host-pointer entry, LLRs included (decode! fills scratch.log_probabs)
+    k = 64
+    lat, ok1, worst = [], True, 0.0
+    for b in range(k):
+        e1, c1, l1, i1 = dec.decode_batch_host(h_syn[b:b + 1], want_llr=True, want_iters=True)   # (first calls: warm-up, kept out below)
+        t0 = time.perf_counter()
+        e1, c1, l1, i1 = dec.decode_batch_host(h_syn[b:b + 1], want_llr=True, want_iters=True)
+        lat.append(time.perf_counter() - t0)
+        ok1 = ok1 and np.array_equal(e1[0], oerr[b]) and c1[0] == oconv[b] and i1[0] == oits[b]
+        fin = np.isfinite(ollr[b])
+        ok1 = ok1 and np.array_equal(l1[0][~fin], ollr[b][~fin])
+        worst = max(worst, float(np.max(np.abs(l1[0][fin] - ollr[b][fin]))) if fin.any() else 0.0)
+    t0 = time.perf_counter()
+    for b in range(k):
+        oc.decode(h_syn[b])
+    cpu_us = (time.perf_counter() - t0) / k * 1e6
+    res["c1_single_decode"] = {"what": "decode! = ldpc_bp_decode_batch(batch = 1, host buffers, LLRs) on the (3,6) n = 1008 code, per 0.01, 50 iterations at most",
+                               "calls": k, "us_per_decode_median": float(np.median(lat) * 1e6), "us_per_decode_mean": float(np.mean(lat) * 1e6),
+                               "value": 1.0 / float(np.median(lat)), "unit": "syndromes/s",
+                               "gpu_matches_oracle_on_sample": bool(ok1 and worst <= 1e-5), "llr_max_abs_diff_vs_oracle": worst,
+                               "cpu_oracle_edge_list_us_per_decode": cpu_us}
+    dec.close()
+    del syn, err, conv, iters
+    # ---- config 5: BB [[72,12,6]], BP + OSD-0 on the host
+    n5, _, _, batch5, per5, it5 = WORKLOADS["c5_bb72_bposd"]
+    Hd = ldpc.codes.bivariate_bicycle_72_12_6()[0]
+    H5 = sp.csc_matrix(Hd)
+    H5.sort_indices()
+    bposd = ldpc.BeliefPropagationOSDDecoder(H5, per5, it5, osd_order=0, device=local_rank)
+    syn5 = make_syndromes(torch, H5.tocsr(), n5, batch5, per5, seed=555, device=device)
+    e5, c5, k5 = bposd.batchdecode_device(syn5)
+    torch.cuda.synchronize()
+    steps5 = 5
+    t0 = time.perf_counter()
+    for _ in range(steps5):
+        e5, c5, k5 = bposd.batchdecode_device(syn5)
+    torch.cuda.synchronize()
+    ms5 = (time.perf_counter() - t0) / steps5 * 1e3
+    # gate: every syndrome BP left unconverged (what OSD touched) and the first 2048 others, against the oracle chain
+    # BP oracle -> OSD oracle (dense restatement of belief_propagation_osd.jl:52-60, :63-125)
+    hc = c5.cpu().numpy()
+    pick = np.unique(np.concatenate([np.flatnonzero(hc == 0)[:512], np.arange(2048)]))
+    hs, he = syn5[torch.from_numpy(pick).to(device)].cpu().numpy(), e5[torch.from_numpy(pick).to(device)].cpu().numpy()
+    oc5 = BPOracle(csc=(H5.indptr, H5.indices), shape=H5.shape, per=per5, max_iters=it5)
+    o_err, o_conv, o_llr, _ = oc5.batchdecode(hs, want_llr=True)
+    ok5 = np.array_equal(o_conv, hc[pick])
+    satisfied = True
+    for q in range(len(pick)):
+        want = o_err[q] if o_conv[q] else osd_oracle_postprocess(Hd, hs[q], o_err[q], o_llr[q], 0)
+        ok5 = ok5 and np.array_equal(want, he[q])
+        satisfied = satisfied and np.array_equal((Hd.astype(np.int64) @ he[q].astype(np.int64)) % 2, hs[q])   # test_bposd_decoder.jl:37-47
+    res["c5_bb72_bposd"] = {"per": per5, "batch": batch5, "steps": steps5, "ms_per_step": ms5, "value": batch5 / (ms5 * 1e-3), "unit": "syndromes/s",
+                            "converged_frac": float(hc.mean()), "osd_postprocessed_per_step": int(k5),
+                            "what": "BP on the GPU for all, the unconverged ones once more with LLRs, OSD-0 for those on the host (ldpc_osd_postprocess_batch), results back in HBM",
+                            "gpu_matches_oracle_on_sample": bool(ok5), "oracle_sample": int(len(pick)), "output_satisfies_syndrome_on_sample": bool(satisfied)}
+    bposd.bp_decoder.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -300,6 +403,7 @@ def main():
     ap.add_argument("--llr", action="store_true",
                     help="the timed step asks for the LLRs of every syndrome as well (scratch.log_probabs, belief_propagation.jl:163; "
                          "one GPU, decode straight into the result arrays)")
+    ap.add_argument("--llr-exact", action="store_true", help="with --llr: ldpc_bp_options.llr_exact (LLRs from the full posterior odds)")
     ap.add_argument("--prealloc-gib", type=float, default=0.0,
                     help="experiment: hold this much HBM before anything else is allocated (shifts physical placement)")
     # rehearsal of the N>1 control flow on a box with fewer GPUs than ranks (never used by the driver):
@@ -368,7 +472,8 @@ def main():
     else:
         dec = ldpc.BeliefPropagationDecoder(H, per, max_iters, device=local_rank,
                                             waves_per_tile=args.waves_per_tile, resident_tiles=args.resident_tiles,
-                                            kernel_variant=args.kernel_variant, defer_threshold=args.defer_threshold)
+                                            kernel_variant=args.kernel_variant, defer_threshold=args.defer_threshold,
+                                            llr_exact=args.llr_exact)
     # Synthetic data: shard g of the job is Bernoulli(per) errors from seed 1234 + g.  scatter mode: the root holds
     # all N shards as ONE caller-owned matrix (belief_propagation.jl:220: one `syndromes`, columns independent).
     Hcsr = H.tocsr()
@@ -562,6 +667,7 @@ def main():
         if args.workload == "c3_full50" and shards == 1 and mode != "replicas" and not args.no_also and not args.batch and not args.per \
                 and not args.kernel_variant and not args.waves_per_tile and not args.resident_tiles:
             out["also"] = also_workloads(ldpc, torch, H, Hcsr, n, nnz, device, local_rank)
+            out["also"].update(also_small_configs(ldpc, torch, device, local_rank))
         print(json.dumps(out), flush=True)
     # explicit teardown, in this order, before the interpreter starts dismantling modules: the decoder handles
     # (hipDeviceSynchronize + frees), then the process group

@@ -90,7 +90,16 @@ typedef struct ldpc_bp_options {
     int32_t defer_threshold;  /* HBM-streaming kernel: a 64-syndrome tile hands its unconverged syndromes to a
                                  densely packed second pass once at most this many are left (same results,
                                  fewer nearly-empty sweeps).  0 = auto (16), -1 = off, else 1..48 */
-    int32_t reserved[11];
+    int32_t llr_exact;        /* What `llr` holds.  0 (default): log(1 / T~), T~ = the posterior odds T of :163 cut to their upper
+                                 32 bits (20 fraction bits) -- the same bits whatever kernel finishes a syndrome, within
+                                 5e-7 of the reference's log(1 / T) (BASELINE.json asks for 1e-5); +-Inf come out exactly.
+                                 The team kernel of large codes then captures 4 bytes per bit and iteration instead of 8
+                                 (LLRs at C3 size: +10 % kernel time instead of +20 %).  1: log(1 / T) of T itself, as
+                                 before ABI version 4 -- what the BP+OSD hosts ask for, because OSD orders the bits by
+                                 reliability (belief_propagation_osd.jl:53-55) and two reliabilities that differ in the
+                                 21st bit must not become a tie.  Hard decisions, flags and iteration counts do not
+                                 depend on it */
+    int32_t reserved[10];
 } ldpc_bp_options;
 
 /* Library / ABI version and build target ("gfx950"). */

@@ -24,7 +24,7 @@ ldpc_status ldpc_debug_team_plan(int64_t nnz, int64_t max_iters, int64_t batch, 
 
 /* The tables with which the team kernel keeps message rows ON CHIP -- in the members' LDS and in the registers of
    their waves -- for a REGULAR graph (every check dc edges, every bit dv) whose degree pair has an instantiation --
-   (6,3), (8,4), (10,5); LDPC_ERR_UNSUPPORTED otherwise -- and teams of `members` workgroups of 8 waves.
+   check degree 6 ... 10 x bit degree 3 ... 5; LDPC_ERR_UNSUPPORTED otherwise -- and teams of `members` workgroups of 8 waves.
    In: regs_per_wave (0 ... 32) rows a wave may keep in registers; static_quarters (0 ... 4): the share of a member's
    chunks per sweep that its waves own by right (only edges between such chunks of ONE wave can live in its registers).
    Out: degrees = {dc, dv}; shape = {words per position record (8 or 16), R = LDS rows per member (at most 312),
@@ -39,6 +39,20 @@ ldpc_status ldpc_debug_team_plan(int64_t nnz, int64_t max_iters, int64_t batch, 
 ldpc_status ldpc_debug_team_rows(int64_t s, int64_t n, const int64_t *colptr, const int64_t *rowval, int32_t members,
                                  int32_t regs_per_wave, int32_t static_quarters, int32_t *degrees, int32_t *shape,
                                  int32_t *vtab, int32_t *ctab, int32_t *lds_edge, int32_t *reg_edge);
+
+/* Two builds of the library in one process (the product and the -DLDPC_EXPERIMENTS build: the Python host of the tests)
+   must not run team grids on one device at the same time -- every member of a team has to be resident.  Each build
+   orders its own team launches through a per-device event table; the build loaded second adopts the table of the
+   first: adopt(process_state of the other build).  Call before the adopting build has launched anything. */
+void *ldpc_debug_process_state(void);
+ldpc_status ldpc_debug_adopt_process_state(void *state);
+
+/* The one entry here that needs the GPU: out_core[i] = div_core(num[i], den[i]) -- the nine instructions in the middle of
+   hipcc's IEEE double division, which the check sweep runs alone where a wave's operands rule the end cases out
+   (bp_kernels.hpp, LDPC_FAST_DIV) -- and out_ieee[i] = num[i] / den[i], computed on the device from HOST arrays of
+   `count` doubles each.  A GPU test holds the two against each other over the ranges the kernels take the short form
+   in, edges included.  No reference counterpart (Julia's `/` is the IEEE division). */
+ldpc_status ldpc_debug_div_check(int64_t count, const double *num, const double *den, double *out_core, double *out_ieee);
 
 #ifdef __cplusplus
 }

@@ -62,7 +62,8 @@ EXPORTED_SYMBOLS = (
     "ldpc_bpots_decode_batch_device",
 )
 # ... and include/ldpc_mi355x_debug.h (test hooks, not part of the boundary)
-DEBUG_SYMBOLS = ("ldpc_debug_team_rows", "ldpc_debug_team_plan")
+DEBUG_SYMBOLS = ("ldpc_debug_team_rows", "ldpc_debug_team_plan", "ldpc_debug_div_check", "ldpc_debug_process_state",
+                 "ldpc_debug_adopt_process_state")
 
 MULTI_MAX_DEVICES = 16
 EXCHANGE_AUTO, EXCHANGE_COPY, EXCHANGE_RCCL, EXCHANGE_NONE = 0, 1, 2, 3
@@ -101,7 +102,7 @@ class BPOptions(ctypes.Structure):
     _fields_ = [
         ("device", ctypes.c_int32), ("waves_per_tile", ctypes.c_int32),
         ("resident_tiles", ctypes.c_int32), ("kernel_variant", ctypes.c_int32),
-        ("defer_threshold", ctypes.c_int32), ("reserved", ctypes.c_int32 * 11),
+        ("defer_threshold", ctypes.c_int32), ("llr_exact", ctypes.c_int32), ("reserved", ctypes.c_int32 * 10),
     ]
 
 
@@ -160,6 +161,8 @@ def lib(experiments: bool = False) -> ctypes.CDLL:
     L.ldpc_get_wait_limit_ms.restype = i64
     L.ldpc_debug_team_plan.restype = i32
     L.ldpc_debug_team_plan.argtypes = [i64, i64, i64, i32, i32, ctypes.POINTER(i32 * 6)]
+    L.ldpc_debug_div_check.restype = i32
+    L.ldpc_debug_div_check.argtypes = [i64, vp, vp, vp, vp]
     L.ldpc_debug_team_rows.restype = i32
     L.ldpc_debug_team_rows.argtypes = [i64, i64, vp, vp, i32, i32, i32, ctypes.POINTER(i32 * 2), ctypes.POINTER(i32 * 5), vp, vp, vp, vp]
     L.ldpc_bp_create_multi.restype = i32
@@ -210,6 +213,14 @@ def lib(experiments: bool = False) -> ctypes.CDLL:
     L.ldpc_bpots_decode_batch.argtypes = [vp, i64, vp, vp, vp, vp]
     L.ldpc_bpots_decode_batch_device.restype = i32
     L.ldpc_bpots_decode_batch_device.argtypes = [vp, i64, vp, vp, vp, vp, vp]
+    L.ldpc_debug_process_state.restype = vp
+    L.ldpc_debug_adopt_process_state.restype = i32
+    L.ldpc_debug_adopt_process_state.argtypes = [vp]
+    # both builds in one process: the one loaded second orders its team grids through the first one's per-device events,
+    # so that no two team grids of the process share a device (include/ldpc_mi355x_debug.h)
+    other = _LIBS.get(not experiments)
+    if other is not None and os.path.realpath(path) != os.path.realpath(EXP_LIB_PATH if not experiments else LIB_PATH):
+        check(L.ldpc_debug_adopt_process_state(other.ldpc_debug_process_state()), L)
     _LIBS[experiments] = L
     return L
 

@@ -146,7 +146,56 @@ struct BPParams {
     const unsigned int *count_dev;  // a pass over a packed level: number of compact syndromes (device word; nullptr = p.batch)
     unsigned int count_skip;    // ... do nothing while *count_dev <= count_skip (bp_node_kernels.hpp takes those)
     int resumed;                // 1: a pass over a packed level (cold->index / cold->it0 are set, messages are in the packed tiles)
+    int llr_exact;              // LLRs from the full posterior odds (llr_of)
 };
+
+// LLRs in 32 bits (the team kernel's capture, TeamParams::llr_raw = 3).  The reference's log_probabs[j] = log(1 / T)
+// (:163) is wanted to 1e-5 (BASELINE.json north_star); the posterior odds T with a 20-bit significand give it to 1e-6.
+// Code = [sign 1][exponent 12][significand 19]: T = (-1)^sign x m x 2^(exponent - 1100), m in [0.5, 1) truncated to its 19
+// leading fraction bits (the decoder puts the middle of the truncation interval back); +-0 and +-infinity have codes of
+// their own and come back exactly (LLR = +-Inf must match the reference's exactly); denormal T is covered (frexp).
+// T is never NaN (:158-160 resets it to 1).
+__device__ __forceinline__ unsigned int llr_pack(double T)
+{
+    const unsigned int sign = (unsigned int)__double2hiint(T) & 0x80000000u;
+    const double a = __builtin_fabs(T);
+    const int e = __builtin_amdgcn_frexp_exp(a);            // a = m * 2^e, m in [0.5, 1)
+    const double m = __builtin_amdgcn_frexp_mant(a);
+    unsigned int code = ((unsigned int)(e + 1100) << 19) | (((unsigned int)__double2hiint(m) >> 1) & 0x7FFFFu);
+    code = (a == 0.0) ? 0u : code;
+    code = (a == __builtin_huge_val()) ? 0x7FFFFFFFu : code;
+    return sign | code;
+}
+__device__ __forceinline__ double llr_unpack(unsigned int code)
+{
+    const unsigned int mag = code & 0x7FFFFFFFu;
+    // m: exponent field of [0.5, 1), the 19 fraction bits, and a 1 below them (the middle of what was cut off)
+    const double m = __hiloint2double((int)(0x3FE00000u | ((mag & 0x7FFFFu) << 1) | 1u), 0);
+    double T = __builtin_ldexp(m, (int)(mag >> 19) - 1100);
+    T = (mag == 0u) ? 0.0 : T;
+    T = (mag == 0x7FFFFFFFu) ? __builtin_huge_val() : T;
+    return (code & 0x80000000u) ? -T : T;
+}
+
+// ... and the cheapest code of all (TeamParams::llr_raw = 4): the UPPER 32 BITS of T -- sign, exponent, the 20 leading
+// fraction bits -- cost nothing to make (they are a register of T already); the decoder puts the middle of what was
+// cut off back (2^-21 relative: the LLR good to 5e-7), except under an all-ones exponent (+-infinity stays itself).
+// T = +-0 comes back as a denormal whose reciprocal overflows, so log(1 / T) = +-Inf exactly as for 0; and every T
+// below 2^-1024 -- where the reference's own 1 / T overflows to Inf -- still decodes below 2^-1024.
+__device__ __forceinline__ unsigned int llr_hi32(double T) { return (unsigned int)__double2hiint(T); }
+__device__ __forceinline__ double llr_from_hi32(unsigned int hi)
+{
+    return __hiloint2double((int)hi, (hi & 0x7FF00000u) == 0x7FF00000u ? 0 : (int)0x80000000u);
+}
+
+// log_probabs[j] as EVERY kernel of the library returns it (:163): log(1 / T) of the posterior odds T cut to their
+// upper 32 bits (above) -- whatever kernel finishes a syndrome, its LLRs are the same bits, and within 5e-7 of the
+// reference's, inside the 1e-5 of BASELINE.json -- unless the decoder was created with llr_exact (ldpc_bp_options):
+// then log(1 / T) of T itself, as before round 4 (the team kernel then captures 8 bytes per bit and iteration, not 4).
+__device__ __forceinline__ double llr_of(double T, int exact)
+{
+    return log(1.0 / (exact ? T : llr_from_hi32(llr_hi32(T))));
+}
 
 // a value known to be the same in every lane -> scalar registers
 __device__ __forceinline__ u64 uniform64(u64 v)
@@ -163,6 +212,74 @@ __device__ __forceinline__ u64 wave_or(u64 v)
         v |= ((u64)hi << 32) | lo;
     }
     return v;
+}
+
+// ---------------------------------------------------------------------------
+// The two fp64 divisions per edge of the check sweep (:140 = :148, and :147) are 22 of its ~41 vector instructions.
+// hipcc expands an IEEE double division into v_div_scale x2, v_rcp, four FMAs (two Newton steps), a multiply, the
+// residual FMA, v_div_fmas and v_div_fixup.  The two scale instructions only do something when an operand or the
+// quotient is near the ends of the exponent range (zero, denormal, |d| >= 2^1022, exponent(n) - exponent(d) >= 768,
+// a denormal quotient, |n| <= 2^-970), v_div_fmas is then a plain FMA, and v_div_fixup only replaces the result for
+// zero / infinite / NaN operands -- for all other operands the quotient IS what the nine instructions in the middle
+// compute, correctly rounded.  LDPC_FAST_DIV=1: where a whole wave's operands of a node are inside a range that
+// rules all of that out (one compare per division, a wave-uniform branch per node) run those instructions alone
+// (div_core), otherwise the full division: the same bits either way (tests/test_gpu_parity.py holds div_core
+// against `/` on the range's edges, and every parity test runs through it).
+//   :140  2 / (1 + m): d = 1 + m in [1, 2^500)  (m >= 0: odds)                -> quotient in (2^-499, 2]
+//   :147  (1 - t) / (1 + t): |t| < 1, so both operands are in [2^-53, 2)       -> quotient in [2^-54, 2^54]
+#ifndef LDPC_FAST_DIV
+#define LDPC_FAST_DIV 0
+#endif
+__device__ __forceinline__ double div_core(double n, double d)
+{
+    double y = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    const double q = n * y;
+    const double r = __builtin_fma(-d, q, n);
+    return __builtin_fma(r, y, q);
+}
+__device__ __forceinline__ bool wave_all(bool ok) { return __builtin_amdgcn_ballot_w64(!ok) == 0ull; }
+
+// a[k] = 2 / (1 + m[k]) - 1  (:140 / :148: the same value both times)
+template <int D>
+__device__ __forceinline__ void check_factors(const double (&m)[D], double (&a)[D])
+{
+#if LDPC_FAST_DIV
+    double d[D];
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < D; ++k) { d[k] = 1.0 + m[k]; ok = ok && d[k] >= 1.0 && d[k] < 0x1p+500; }
+    if (wave_all(ok)) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) a[k] = div_core(2.0, d[k]) - 1.0;
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) a[k] = 2.0 / d[k] - 1.0;
+#else
+#pragma unroll
+    for (int k = 0; k < D; ++k) a[k] = 2.0 / (1.0 + m[k]) - 1.0;
+#endif
+}
+// out[k] = (1 - t[k]) / (1 + t[k])  (:147)
+template <int D>
+__device__ __forceinline__ void check_to_odds(const double (&t)[D], double (&out)[D])
+{
+#if LDPC_FAST_DIV
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < D; ++k) ok = ok && __builtin_fabs(t[k]) < 1.0;
+    if (wave_all(ok)) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) out[k] = div_core(1.0 - t[k], 1.0 + t[k]);
+        return;
+    }
+#endif
+#pragma unroll
+    for (int k = 0; k < D; ++k) out[k] = (1.0 - t[k]) / (1.0 + t[k]);
 }
 
 // ---------------------------------------------------------------------------
@@ -184,12 +301,26 @@ __device__ __forceinline__ void check_finish_exact(double *M, const double (&a)[
 #pragma unroll
     for (int k = 0; k < D; ++k) { pre[k] = P; P = P * a[k]; }          // :139-140
     double S = 1.0;                                       // :143
+#if LDPC_FAST_DIV
+    double t[D], o[D];
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) { t[k] = pre[k] * S; S = S * a[k]; }   // :146, :148
+    if (TF) {
+#pragma unroll
+        for (int k = D - 1; k >= 0; --k) stm(M + (size_t)k * kTile, t[k]);
+        return;
+    }
+    check_to_odds<D>(t, o);                               // :147
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) stm(M + (size_t)k * kTile, o[k]);
+#else
 #pragma unroll
     for (int k = D - 1; k >= 0; --k) {
         const double t = pre[k] * S;                      // :146
         stm(M + (size_t)k * kTile, TF ? t : (1.0 - t) / (1.0 + t));  // :147
         S = S * a[k];                                     // :148
     }
+#endif
 }
 
 // ... the same with the D new messages handed back instead of stored (rows that do not lie k * 64 doubles apart:
@@ -202,12 +333,24 @@ __device__ __forceinline__ void check_compute_exact(const double (&a)[D], double
 #pragma unroll
     for (int k = 0; k < D; ++k) { pre[k] = P; P = P * a[k]; }          // :139-140
     double S = 1.0;                                       // :143
+#if LDPC_FAST_DIV
+    double t[D];
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) { t[k] = pre[k] * S; S = S * a[k]; }   // :146, :148
+    if (TF) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) out[k] = t[k];
+        return;
+    }
+    check_to_odds<D>(t, out);                             // :147
+#else
 #pragma unroll
     for (int k = D - 1; k >= 0; --k) {
         const double t = pre[k] * S;                      // :146
         out[k] = TF ? t : (1.0 - t) / (1.0 + t);          // :147
         S = S * a[k];                                     // :148
     }
+#endif
 }
 
 template <int D, bool FIRST, bool TF = false>
@@ -222,8 +365,7 @@ __device__ __forceinline__ void check_update_exact(double *M, double sigma, doub
         double m[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) m[k] = ldm(M + (size_t)k * kTile);
-#pragma unroll
-        for (int k = 0; k < D; ++k) a[k] = 2.0 / (1.0 + m[k]) - 1.0;   // :140 / :148 (same value both times)
+        check_factors<D>(m, a);                                        // :140 / :148 (same value both times)
     }
     check_finish_exact<D, TF>(M, a, sigma);
 }
@@ -240,11 +382,9 @@ __device__ __forceinline__ void check_update_pair(double *M0, double *M1, double
     for (int k = 0; k < D; ++k) m1[k] = ldm(M1 + (size_t)k * kTile);
     loads_first();
     double a[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) a[k] = 2.0 / (1.0 + m0[k]) - 1.0;
+    check_factors<D>(m0, a);
     check_finish_exact<D, TF>(M0, a, sigma0);
-#pragma unroll
-    for (int k = 0; k < D; ++k) a[k] = 2.0 / (1.0 + m1[k]) - 1.0;
+    check_factors<D>(m1, a);
     check_finish_exact<D, TF>(M1, a, sigma1);
 }
 
@@ -350,10 +490,7 @@ __device__ __forceinline__ double bit_update_exact_v(double *Mt, const int (&pos
     for (int k = 0; k < D; ++k) at[k] = (size_t)pos[k] * kTile;
 #pragma unroll
     for (int k = 0; k < D; ++k) c[k] = ldm(Mt + at[k]);
-    if (TF) {
-#pragma unroll
-        for (int k = 0; k < D; ++k) c[k] = (1.0 - c[k]) / (1.0 + c[k]);   // :147
-    }
+    if (TF) check_to_odds<D>(c, c);   // :147
     return bit_finish_exact<D>(Mt, at, c, r);
 }
 
@@ -369,10 +506,7 @@ __device__ __forceinline__ void bit_update_pair_v(double *Mt, const int (&pos0)[
 #pragma unroll
     for (int k = 0; k < D; ++k) c1[k] = ldm(Mt + at1[k]);
     loads_first();
-    if (TF) {
-#pragma unroll
-        for (int k = 0; k < D; ++k) { c0[k] = (1.0 - c0[k]) / (1.0 + c0[k]); c1[k] = (1.0 - c1[k]) / (1.0 + c1[k]); }   // :147
-    }
+    if (TF) { check_to_odds<D>(c0, c0); check_to_odds<D>(c1, c1); }   // :147
     T0 = bit_finish_exact<D>(Mt, at0, c0, r);
     T1 = bit_finish_exact<D>(Mt, at1, c1, r);
 }
@@ -581,7 +715,7 @@ bp_tile_kernel(BPParams p, const int *__restrict__ row_ptr, const int *__restric
                 const u64 dec = __ballot(T >= 1.0);                            // :164-168
                 if (WANT_LLR) {
                     if ((active >> lane) & 1ull)
-                        p.llr[((size_t)tile * n + j) * kTile + lane] = log(1.0 / T);  // :163
+                        p.llr[((size_t)tile * n + j) * kTile + lane] = llr_of(T, p.llr_exact);  // :163
                 }
                 if (lane == 0) em[j] = dec;   // every lane, also the stopped ones: theirs were captured when they stopped
             };
@@ -703,6 +837,15 @@ __global__ void __launch_bounds__(64) store_cold_kernel(BPCold c0, BPCold c1, BP
     if (threadIdx.x == 0) { dst[0] = c0; dst[1] = c1; dst[2] = c2; }
 }
 
+// include/ldpc_mi355x_debug.h ldpc_debug_div_check: div_core against the IEEE division
+__global__ void __launch_bounds__(256) div_check_kernel(const double *num, const double *den, double *out_core, double *out_ieee, long long count)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    out_core[i] = div_core(num[i], den[i]);
+    out_ieee[i] = num[i] / den[i];
+}
+
 // ---------------------------------------------------------------------------
 // placement probe: the two sweeps' access patterns on a candidate workspace, with the real kernel's geometry (one
 // 8-wave workgroup per slot, three per CU, every workgroup starting at a rotation of its own) -- every wave gathers
@@ -789,11 +932,12 @@ __global__ void __launch_bounds__(64) unpack_errors_kernel(const u64 *errmask, l
     }
 }
 
-// llr transpose: llr_t[tile][n][64] -> llr[batch][n]; 64x64 tile through LDS.  raw: llr_t holds the posterior odds T
-// (the team kernel's fresh pass, TeamParams::llr_raw) and log(1 / T) (:163) is taken here, once per syndrome and bit
+// llr transpose: llr_t[tile][n][64] -> llr[batch][n]; 64x64 tile through LDS.  raw != 0: llr_t holds the posterior odds T
+// (the team kernel's fresh pass, TeamParams::llr_raw; 3: as 32-bit codes, llr_pack) and log(1 / T) (:163) is taken
+// here, once per syndrome and bit
 __global__ void __launch_bounds__(256) unpack_llr_kernel(const double *llr_t, long long batch, int n,
                                                          double *llr, const int *index,
-                                                         const unsigned int *count_dev, unsigned int count_skip, int raw)
+                                                         const unsigned int *count_dev, unsigned int count_skip, int raw, int exact)
 {
     __shared__ double t[64][65];
     if (count_dev) { batch = (long long)*count_dev; if (batch <= (long long)count_skip) return; }   // uniform
@@ -804,13 +948,16 @@ __global__ void __launch_bounds__(256) unpack_llr_kernel(const double *llr_t, lo
     const int rows = (int)((batch - b0) < kTile ? (batch - b0) : kTile);
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int jj = ty; jj < 64; jj += 4)
-        if (j0 + jj < n) t[jj][tx] = llr_t[((size_t)tile * n + j0 + jj) * kTile + tx];
+        if (j0 + jj < n) {
+            const size_t at = ((size_t)tile * n + j0 + jj) * kTile + tx;
+            t[jj][tx] = raw == 4 ? llr_from_hi32(((const unsigned int *)llr_t)[at]) : raw == 3 ? llr_unpack(((const unsigned int *)llr_t)[at]) : llr_t[at];
+        }
     __syncthreads();
     for (int rr = ty; rr < rows; rr += 4)
         if (j0 + tx < n) {
             const long long b = index ? (long long)index[b0 + rr] : b0 + rr;
             const double v = t[tx][rr];
-            llr[(size_t)b * n + j0 + tx] = raw ? log(1.0 / v) : v;
+            llr[(size_t)b * n + j0 + tx] = !raw ? v : (raw == 3 || raw == 4) ? log(1.0 / v) : llr_of(v, exact);   // (raw 3 / 4: v is the cut T already)
         }
 }
 

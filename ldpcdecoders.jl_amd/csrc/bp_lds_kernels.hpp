@@ -43,6 +43,7 @@ struct LdsParams {
     unsigned char *conv;        // [batch]
     int *iters;                 // [batch] or nullptr
     double *llr;                // [batch][n] or nullptr
+    int llr_exact;              // LLRs from the full posterior odds (bp_kernels.hpp llr_of)
     unsigned int *queue;
     u64 *sum_iters;
     u64 *phase_ticks;     // [3] 100 MHz ticks: check sweep, variable sweep, everything else (I/O, test, barriers)
@@ -279,7 +280,7 @@ bp_lds_kernel(LdsParams p, const int *__restrict__ g_row_ptr, const int *__restr
                     const int deg = col_ptr[j + 1] - c0;
                     T = lds_bit_unit<DV, idx_t>(M + sig, S, csc2csr + c0, deg, r);
                     if (WANT_LLR) {
-                        if ((active >> sig) & 1ull) L[(size_t)j * S + sig] = log(1.0 / T);   // :163
+                        if ((active >> sig) & 1ull) L[(size_t)j * S + sig] = llr_of(T, p.llr_exact);   // :163
                     }
                 }
                 const u64 bal = __ballot(in && (T >= 1.0));                       // :164-168

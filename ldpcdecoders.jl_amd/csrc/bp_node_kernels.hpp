@@ -31,6 +31,7 @@ struct NodeParams {
     unsigned char *conv;        // [batch]
     int *iters;                 // [batch] or nullptr
     double *llr;                // [batch][n] or nullptr
+    int llr_exact;              // LLRs from the full posterior odds (bp_kernels.hpp llr_of)
     double *msg;                // [gridDim.x][slot_stride] workspace
     long long slot_stride;      // doubles per workgroup slot (>= nnz)
     unsigned int *queue;
@@ -197,7 +198,7 @@ bp_node_kernel(NodeParams p, const int *__restrict__ row_ptr, const int *__restr
                 const int deg = col_ptr[j + 1] - c0;
                 const double T = MSG == 2 ? hybrid_bit_unit<DV>(Ml, Mg, split_edge, csc2csr + c0, deg, r)
                                           : lds_bit_unit<DV, int>(M, 1, csc2csr + c0, deg, r);
-                if (WANT_LLR) p.llr[(size_t)b * n + j] = log(1.0 / T);   // :163, final at the last iteration run
+                if (WANT_LLR) p.llr[(size_t)b * n + j] = llr_of(T, p.llr_exact);   // :163, final at the last iteration run
                 ebit[j] = (unsigned char)(T >= 1.0);                      // :164-168
             }
             __syncthreads();

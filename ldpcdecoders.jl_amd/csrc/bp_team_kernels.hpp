@@ -45,8 +45,8 @@
 #ifndef LDPC_TEAM_ROWS_WIDE   // 1 = the rows-in-LDS instantiation may use 256 VGPRs (it runs one workgroup per CU)
 #define LDPC_TEAM_ROWS_WIDE 1
 #endif
-#ifndef LDPC_TEAM_TFORM   // 1 = the rows-on-chip instantiations make the division of :147 in the variable sweep (0: experiments)
-#define LDPC_TEAM_TFORM 0
+#ifndef LDPC_TEAM_TFORM   // 1 = the rows-on-chip instantiations of check degree <= 8 make the division of :147 in the variable sweep
+#define LDPC_TEAM_TFORM 1
 #endif
 #ifndef LDPC_TEAM_TEST_DIRECT   // 1: the waves of a member OR their share of the convergence test into the team's word directly
 #define LDPC_TEAM_TEST_DIRECT 1
@@ -58,7 +58,7 @@
 namespace ldpc {
 
 // Rows in LDS (instantiations with LROWS: REGULAR graphs, every check exactly DC edges and every bit exactly DV --
-// (3,6), (4,8), (5,10): team_rows_degrees_ok()).  A member decodes the same share of
+// DC = 6 ... 10, DV = 3 ... 5, the codes of north_star's range: team_rows_degrees_ok()).  A member decodes the same share of
 // the checks AND of the bits in every iteration, so an edge whose check and whose bit are both its own is never touched
 // by anybody else: its message row can live in the member's LDS instead of the team's slot.  The host deals the bits
 // to the members by the graph (team_rows_build(): a bit goes to a member that owns one of its checks -- 1 / DV of
@@ -73,7 +73,7 @@ namespace ldpc {
 //                             bit (| 1 << 31 when one of its edges is in LDS), padding to VT = 8 or 16 words
 __host__ __device__ constexpr int team_vtab_words(int dv) { return 2 * dv + 1 <= 8 ? 8 : 16; }
 // the degree pairs that have a rows-in-LDS instantiation (pick_team.hip)
-__host__ __device__ constexpr bool team_rows_degrees_ok(int dc, int dv) { return (dc == 6 && dv == 3) || (dc == 8 && dv == 4) || (dc == 10 && dv == 5); }
+__host__ __device__ constexpr bool team_rows_degrees_ok(int dc, int dv) { return dc >= 6 && dc <= 10 && dv >= 3 && dv <= 5; }
 
 // One position record of vtab, read with as few scalar loads as its width allows (words 0 ... 7 in one, the rest in one more).
 template <int DV>
@@ -229,8 +229,16 @@ struct TeamParams {
     // LLRs (WANT_LLR instantiations, fresh tiles): what the variable sweep leaves in p.llr for every active lane and bit in
     // every iteration -- 0: log(1 / T) (:163), as the other kernels do; 1: the posterior odds T themselves, the logarithm
     // is taken once per syndrome and bit by unpack_llr_kernel (same OCML log on the same operand: the same bits) instead
-    // of once per iteration; 2: as 1 with non-temporal stores
+    // of once per iteration; 2: as 1 with non-temporal stores; 3: T as a 32-bit code (llr_pack: 20-bit significand, the
+    // LLR good to 1e-6, +-Inf exact), half the bytes per iteration; 4 (the default): the upper 32 bits of T (llr_hi32)
+    // (5, decoders created with llr_exact: T itself, 8 bytes)
+    // into the TEAM's own scratch rows llr_scratch[team][bit][64] -- lanes that have stopped keep what they stopped
+    // with, a tile's rows are copied out to p.llr once, when the team is through with it.  (1 ... 3 write p.llr's rows of
+    // the tile in every iteration: rows that are new to the cache for every tile, so that at ~3 iterations a tile they
+    // cost DRAM writes for every iteration's capture -- per 0.02: +16 % kernel time with 32-bit codes, +20 % with T;
+    // the scratch rows are the same eight regions for the whole launch and stay in the Infinity Cache with the slots)
     int llr_raw;
+    unsigned int *llr_scratch;  // [nteams][n][64] u32 (llr_raw = 4) / f64 (llr_raw = 5)
 };
 constexpr unsigned int kTeamRollcallFailed = 0x80000000u;
 
@@ -363,8 +371,7 @@ __device__ __forceinline__ void check_update_mixed(double *M, double *L, unsigne
         double m[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) m[k] = *ptr[k];
-#pragma unroll
-        for (int k = 0; k < D; ++k) a[k] = 2.0 / (1.0 + m[k]) - 1.0;
+        check_factors<D>(m, a);
     }
     check_compute_exact<D, TF>(a, sigma, out);
 #pragma unroll
@@ -383,10 +390,7 @@ __device__ __forceinline__ double bit_update_mixed(double *Mt, double *L, const 
     double c[D], out[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) c[k] = *ptr[k];
-    if (TF) {
-#pragma unroll
-        for (int k = 0; k < D; ++k) c[k] = (1.0 - c[k]) / (1.0 + c[k]);   // :147
-    }
+    if (TF) check_to_odds<D>(c, c);   // :147
     const double F = bit_compute_exact<D>(c, r, out);
 #pragma unroll
     for (int k = D - 1; k >= 0; --k) *ptr[k] = out[k];
@@ -424,8 +428,7 @@ __device__ __forceinline__ void check_update_onchip(double *M, double *L, double
 #pragma unroll
         for (int k = 0; k < D; ++k)
             if ((rmask >> k) & 1u) m[k] = rget(rbase + __builtin_popcount(rmask & ((1u << k) - 1u)));
-#pragma unroll
-        for (int k = 0; k < D; ++k) a[k] = 2.0 / (1.0 + m[k]) - 1.0;
+        check_factors<D>(m, a);
     }
     check_compute_exact<D, TF>(a, sigma, out);
 #pragma unroll
@@ -451,10 +454,7 @@ __device__ __forceinline__ double bit_update_onchip(double *Mt, double *L, doubl
 #pragma unroll
     for (int k = 0; k < D; ++k)
         if (loc[k] <= -2) c[k] = rget(-2 - loc[k]);
-    if (TF) {
-#pragma unroll
-        for (int k = 0; k < D; ++k) c[k] = (1.0 - c[k]) / (1.0 + c[k]);   // :147
-    }
+    if (TF) check_to_odds<D>(c, c);   // :147
     const double F = bit_compute_exact<D>(c, r, out);
 #pragma unroll
     for (int k = D - 1; k >= 0; --k) *ptr[k] = out[k];
@@ -477,8 +477,7 @@ __device__ __forceinline__ void check_update_regs(int rbase, double sigma, doubl
         double m[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) m[k] = rget(rbase + k);
-#pragma unroll
-        for (int k = 0; k < D; ++k) a[k] = 2.0 / (1.0 + m[k]) - 1.0;
+        check_factors<D>(m, a);
     }
     check_compute_exact<D, TF>(a, sigma, out);
 #pragma unroll
@@ -509,10 +508,7 @@ __device__ __forceinline__ void bit_update_pair_first(double *Mt, double *L, con
     else if (loc1 >= 0) c1[0] = L[(size_t)loc1 * kTile];
     else c1[0] = rget(-2 - loc1);
     loads_first();
-    if (TF) {
-#pragma unroll
-        for (int k = 0; k < D; ++k) { c0[k] = (1.0 - c0[k]) / (1.0 + c0[k]); c1[k] = (1.0 - c1[k]) / (1.0 + c1[k]); }   // :147
-    }
+    if (TF) { check_to_odds<D>(c0, c0); check_to_odds<D>(c1, c1); }   // :147
     T0 = bit_compute_exact<D>(c0, r, o0);
 #pragma unroll
     for (int k = D - 1; k >= 1; --k) stm(Mt + at0[k], o0[k]);
@@ -548,10 +544,7 @@ __device__ __forceinline__ void bit_update_multi_first(double *Mt, double *L, co
     loads_first();
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        if (TF) {
-#pragma unroll
-            for (int k = 0; k < D; ++k) c[b][k] = (1.0 - c[b][k]) / (1.0 + c[b][k]);   // :147
-        }
+        if (TF) check_to_odds<D>(c[b], c[b]);   // :147
         double o[D];
         T[b] = bit_compute_exact<D>(c[b], r, o);
 #pragma unroll
@@ -587,7 +580,10 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     // teams is bound by them, not by the memory side; the variable sweep has no division at all and waits for its
     // scattered rows.  One division per edge in either sweep: the same operations on the same operands, the same
     // bits -- and at every iteration boundary (hand-off, write-back) the rows are bit -> check messages as ever.
-    constexpr bool TF = LROWS && (LDPC_TEAM_TFORM != 0);
+    // Measured on the final kernels of round 4, alternating builds on one box (profiles/r04_tform_ab.txt): C3 full-50
+    // 721.4 -> 713.9 ms, (3,6) n = 16380 521.6 -> 515.1 ms, (5,10) n = 16000 491.0 -> 493.1 ms -- hence check degree <= 8.
+    // (Round 3, before the on-chip rows were whole checks: 873 -> 876 ms, and the form stayed off.)
+    constexpr bool TF = LROWS && (LDPC_TEAM_TFORM != 0) && DC <= 8;
     // rows in registers (RR > 0): v[192 + 2 * row], v[193 + 2 * row] of this wave (team_reg_get / team_reg_put)
     auto rget = [&](const int row) -> double {
         if constexpr (RR > 0) return team_reg_get(row);
@@ -763,12 +759,43 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     auto var_sweep = [&]() {
         const int vb = (one_xcd || LROWS) ? 4 : 16;     // (LROWS: the host dealt the bits in chunks of 4)
         const int nch = (n + vb - 1) / vb;
-        auto decide = [&](int j, double T) {
+        // LLR capture into the team's scratch rows (tp.llr_raw >= 4).  Element (position, lane) sits at
+        // ((position / 4) * 64 + lane) * 4 + position % 4: the four positions of a chunk are ONE 16-byte store per lane
+        // (32 bytes with llr_exact) -- a store instruction costs the address path the same whatever its width, and a
+        // 4-byte store per bit made the variable sweep 12 % longer.  Position = place in the dealt bit order (LROWS), else
+        // the bit.  Only lanes that are still active store: a stopped lane keeps what it stopped with.
+        const bool cap_on = WANT_LLR && tp.llr_raw >= 4 && ((active >> lane) & 1ull);
+        const size_t cap_rows = ((size_t)n + 3) & ~(size_t)3;
+        unsigned int *const cap32 = tp.llr_scratch + (size_t)team * cap_rows * kTile;
+        double *const cap64 = (double *)tp.llr_scratch + (size_t)team * cap_rows * kTile;
+        auto cap_at = [&](int pos) { return ((size_t)(pos >> 2) * kTile + lane) * 4 + (size_t)(pos & 3); };
+        auto capture1 = [&](int pos, double T) {
+            if (!cap_on) return;
+            if (tp.llr_raw == 4) cap32[cap_at(pos)] = llr_hi32(T);
+            else cap64[cap_at(pos)] = T;
+        };
+        auto capture2 = [&](int pos, double T0, double T1) {      // pos even
+            if (!cap_on) return;
+            typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            if (tp.llr_raw == 4) *(v2u *)(cap32 + cap_at(pos)) = v2u{llr_hi32(T0), llr_hi32(T1)};
+            else *(v2d *)(cap64 + cap_at(pos)) = v2d{T0, T1};
+        };
+        auto capture4 = [&](int pos, const double (&T)[4]) {      // pos a multiple of 4
+            if (!cap_on) return;
+            typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            if (tp.llr_raw == 4) *(v4u *)(cap32 + cap_at(pos)) = v4u{llr_hi32(T[0]), llr_hi32(T[1]), llr_hi32(T[2]), llr_hi32(T[3])};
+            else { *(v2d *)(cap64 + cap_at(pos)) = v2d{T[0], T[1]}; *(v2d *)(cap64 + cap_at(pos) + 2) = v2d{T[2], T[3]}; }
+        };
+        auto decide = [&](int pos, int j, double T, bool cap = true) {
             const u64 dec = __ballot(T >= 1.0);                                // :164-168
             if (WANT_LLR) {
-                if ((active >> lane) & 1ull) {
+                if (tp.llr_raw >= 4) { if (cap) capture1(pos, T); }
+                else if ((active >> lane) & 1ull) {
                     double *const dst = p.llr + ((size_t)tile * n + j) * kTile + lane;
-                    if (tp.llr_raw == 0) *dst = log(1.0 / T);  // :163
+                    if (tp.llr_raw == 3) ((unsigned int *)p.llr)[((size_t)tile * n + j) * kTile + lane] = llr_pack(T);   // (32-bit codes: half the bytes)
+                    else if (tp.llr_raw == 0) *dst = llr_of(T, p.llr_exact);  // :163
                     else if (tp.llr_raw == 1) *dst = T;        // (the logarithm: unpack_llr_kernel)
                     else __builtin_nontemporal_store(T, dst);
                 }
@@ -782,33 +809,35 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
                 // positions of the dealt bit order; every bit has the full degree; csc2csr is vtab.  Everything the
                 // table says about the four positions of a chunk is asked for at once (one scalar round trip per chunk)
                 constexpr int VT = team_vtab_words(DV);
-                auto single = [&](const TeamVRec<DV> &a) {
-                    if (a.bit >= 0) { decide(a.bit, bit_update_exact_v<DV, TF>(Mt, a.pos, r)); return; }
+                auto single = [&](const TeamVRec<DV> &a, const int pa) {
+                    if (a.bit >= 0) { decide(pa, a.bit, bit_update_exact_v<DV, TF>(Mt, a.pos, r)); return; }
                     if constexpr (RR > 0) {
                         int lo = a.lrow[0];
 #pragma unroll
                         for (int k = 1; k < DV; ++k) lo = min(lo, a.lrow[k]);
-                        if (lo <= -2) { decide(a.bit & 0x7fffffff, bit_update_onchip<DV, TF>(Mt, Lr, Ldummy, a.pos, a.lrow, r, rget, rput)); return; }
+                        if (lo <= -2) { decide(pa, a.bit & 0x7fffffff, bit_update_onchip<DV, TF>(Mt, Lr, Ldummy, a.pos, a.lrow, r, rget, rput)); return; }
                     }
-                    decide(a.bit & 0x7fffffff, bit_update_mixed<DV, TF>(Mt, Lr, a.pos, a.lrow, r));
+                    decide(pa, a.bit & 0x7fffffff, bit_update_mixed<DV, TF>(Mt, Lr, a.pos, a.lrow, r));
                 };
-                auto two = [&](const TeamVRec<DV> &a, const TeamVRec<DV> &b) {
+                auto two = [&](const TeamVRec<DV> &a, const TeamVRec<DV> &b, const int pa) {   // positions pa (even), pa + 1
                     int rest = -1;                            // stays -1: the edges 1 ... DV-1 of both are rows of the slot
 #pragma unroll
                     for (int k = 1; k < DV; ++k) rest &= a.lrow[k] & b.lrow[k];
                     if ((a.bit | b.bit) >= 0 && tp.pairs) {   // neither has a row on chip: both loaded together
                         double T0, T1;
                         bit_update_pair_v<DV, TF>(Mt, a.pos, b.pos, r, T0, T1);
-                        decide(a.bit, T0);
-                        decide(b.bit, T1);
+                        decide(pa, a.bit, T0, false);
+                        decide(pa + 1, b.bit, T1, false);
+                        capture2(pa, T0, T1);
                     } else if (rest == -1 && tp.pairs) {      // on chip at most the first edge of either (whole checks of the first block)
                         double T0, T1;
                         bit_update_pair_first<DV, TF>(Mt, Lr, a.pos, a.lrow[0], b.pos, b.lrow[0], r, rget, rput, T0, T1);
-                        decide(a.bit & 0x7fffffff, T0);
-                        decide(b.bit & 0x7fffffff, T1);
+                        decide(pa, a.bit & 0x7fffffff, T0, false);
+                        decide(pa + 1, b.bit & 0x7fffffff, T1, false);
+                        capture2(pa, T0, T1);
                     } else {
-                        single(a);
-                        single(b);
+                        single(a, pa);
+                        single(b, pa + 1);
                     }
                 };
                 int q = j;
@@ -827,23 +856,24 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
                             const int lc[4] = {A.lrow[0], B.lrow[0], C.lrow[0], D.lrow[0]};
                             double T[4];
                             bit_update_multi_first<DV, 4, TF>(Mt, Lr, ps, lc, r, rget, rput, T);
-                            decide(A.bit & 0x7fffffff, T[0]);
-                            decide(B.bit & 0x7fffffff, T[1]);
-                            decide(C.bit & 0x7fffffff, T[2]);
-                            decide(D.bit & 0x7fffffff, T[3]);
+                            decide(q, A.bit & 0x7fffffff, T[0], false);
+                            decide(q + 1, B.bit & 0x7fffffff, T[1], false);
+                            decide(q + 2, C.bit & 0x7fffffff, T[2], false);
+                            decide(q + 3, D.bit & 0x7fffffff, T[3], false);
+                            capture4(q, T);
                             return;
                         }
                     }
-                    two(A, B);
-                    two(C, D);
+                    two(A, B, q);
+                    two(C, D, q + 2);
                     return;
                 }
                 for (; q + 1 < j1; q += 2) {
                     const int *const vt = csc2csr + (size_t)q * VT;
                     const TeamVRec<DV> A = team_vrec_load<DV>(vt), B = team_vrec_load<DV>(vt + VT);
-                    two(A, B);
+                    two(A, B, q);
                 }
-                for (; q < j1; ++q) single(team_vrec_load<DV>(csc2csr + (size_t)q * VT));
+                for (; q < j1; ++q) single(team_vrec_load<DV>(csc2csr + (size_t)q * VT), q);
                 return;
             }
             for (; tp.pairs && j + 1 < j1; j += 2) {           // two bits of the full degree: all 2 DV rows in flight at once
@@ -851,13 +881,14 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
                 if (c1 - c0 != DV || c2 - c1 != DV) break;
                 double T0, T1;
                 bit_update_pair<DV>(Mt, csc2csr + c0, csc2csr + c1, r, T0, T1);
-                decide(j, T0);
-                decide(j + 1, T1);
+                decide(j, j, T0, false);
+                decide(j + 1, j + 1, T1, false);
+                capture2(j, T0, T1);
             }
             for (; j < j1; ++j) {
                 const int c0 = col_ptr[j];
                 const int deg = col_ptr[j + 1] - c0;
-                decide(j, bit_update<DV>(Mt, csc2csr + c0, deg, r));
+                decide(j, j, bit_update<DV>(Mt, csc2csr + c0, deg, r));
             }
         };
         const int mine = (nch - rank + G - 1) / G;
@@ -874,8 +905,10 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
         u64 mism = 0;
         for (int i = gw * 64 + lane; i < s; i += GW * 64) {
             u64 par = 0;
-            const int e1 = row_ptr[i + 1];
-            for (int e = row_ptr[i]; e < e1; e += 8) {
+            // (regular graphs of the rows-on-chip instantiations: check i's edges are rows DC i ... DC i + DC - 1 -- one
+            //  dependent round trip less in front of the decision words)
+            const int e1 = LROWS ? (i + 1) * DC : row_ptr[i + 1];
+            for (int e = LROWS ? i * DC : row_ptr[i]; e < e1; e += 8) {
                 int jb[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) jb[q] = (e + q < e1) ? edge_bit[e + q] : -1;
@@ -999,6 +1032,41 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
         }
     }
     horizon = it;
+    if (WANT_LLR && tp.llr_raw >= 4) {
+        // The tile's LLR rows leave the team's scratch for p.llr's rows of the tile -- every lane of every row (the lanes
+        // handed to the next level get theirs from the pass that finishes them, which writes after this one), one chunk of
+        // four positions per wave step: one wide load per lane, four row stores, the position -> bit map of the dealt
+        // order applied on the way.  Every capture is behind a team barrier by now; nobody writes the scratch again
+        // before the two barriers of the tile change below.
+        typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const size_t cap_rows = ((size_t)n + 3) & ~(size_t)3;
+        const int nch4 = (n + 3) >> 2;
+        for (int c = gw; c < nch4; c += GW) {
+            int bit[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int pos = 4 * c + k;
+                if constexpr (LROWS) bit[k] = pos < n ? (csc2csr[(size_t)pos * team_vtab_words(DV) + 2 * DV] & 0x7fffffff) : -1;
+                else bit[k] = pos < n ? pos : -1;
+            }
+            if (tp.llr_raw == 4) {
+                const v4u v = *(const v4u *)(tp.llr_scratch + (size_t)team * cap_rows * kTile + ((size_t)c * kTile + lane) * 4);
+                unsigned int *const dst = (unsigned int *)p.llr + (size_t)tile * n * kTile + lane;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (bit[k] >= 0) __builtin_nontemporal_store(v[k], dst + (size_t)bit[k] * kTile);
+            } else {
+                const double *const src = (const double *)tp.llr_scratch + (size_t)team * cap_rows * kTile + ((size_t)c * kTile + lane) * 4;
+                const v2d a = *(const v2d *)src, b = *(const v2d *)(src + 2);
+                const double v[4] = {a[0], a[1], b[0], b[1]};
+                double *const dst = p.llr + (size_t)tile * n * kTile + lane;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (bit[k] >= 0) __builtin_nontemporal_store(v[k], dst + (size_t)bit[k] * kTile);
+            }
+        }
+    }
     if (rank == 0 && w == 0) {
         if (((valid & ~deferred) >> lane) & 1ull) {
             const long long ob = resumed ? (long long)cd->index[b0 + lane] : b0 + lane;

@@ -490,6 +490,12 @@ struct ldpc_bp_decoder {
     int team_flip = 3;                // LDPC_TEAM_FLIP: bit 0 / 1: upper half of the waves walks its check / position chunks by right backwards (TeamRows::flip)
     int team_static_quarters = 3;     // LDPC_TEAM_STATIC: quarters of a member's chunks per sweep that its waves own by right (0: only each wave's first)
     unsigned int *team_fault = nullptr, *team_fault_dev = nullptr;
+    // (LDPC_TEAM_PER_CU, LDPC_TEAM_MIN_ROWS, LDPC_TEAM_NO_MARGIN, LDPC_TEAM_ALWAYS_RELEASE, LDPC_TEAM_COOP_LAUNCH: read at create
+    //  like the other knobs, so that a test or the fuzzer can vary them from decoder to decoder)
+    int team_per_cu_want = 2;       // team workgroups per CU the plan asks for
+    int64_t team_min_rows = 2048;   // message rows per sweep a member must have ...
+    bool team_min_rows_set = false; // ... given by the environment (then also for the one team of an XCD: kTeamMinRowsOne does not apply)
+    bool team_no_margin = false, team_always_release = false, team_coop = false;
     int team_max = 32;        // workgroups per tile at most (LDPC_TEAM_MAX; 1 = team kernel off)
     bool team_max_set = false;   // ... given by the environment: no automatic large teams for batches of <= 3 tiles
     // (read at create, so that a test or the fuzzer can vary them from decoder to decoder)
@@ -499,7 +505,9 @@ struct ldpc_bp_decoder {
     int team_pairs = 3;       // LDPC_TEAM_PAIRS: bit 0: two nodes of the full degree are loaded together; bit 1: the four bits of a position chunk (rows-on-chip kernels)
     int team_ahead_from = 1;  // LDPC_TEAM_AHEAD_FROM: first iteration whose test may ride with the next check sweep (1: realistic -1.6 %, waterfall -0.7 % against 2, profiles/r03_ahead_from1.txt)
     bool team_ahead_set = false;   // LDPC_TEAM_AHEAD given (else: 1 for a single round of teams over all XCDs)
-    int team_llr_raw = 1;     // LDPC_TEAM_LLR_RAW: what the team kernel's variable sweep stores per bit when LLRs are wanted (TeamParams::llr_raw)
+    DevBuf team_llr;          // [teams][n][64] u32 / f64: the teams' LLR scratch rows (TeamParams::llr_scratch)
+    bool llr_exact = false;   // ldpc_bp_options.llr_exact: LLRs from the full posterior odds (bp_kernels.hpp llr_of)
+    int team_llr_raw = 4;     // LDPC_TEAM_LLR_RAW (4 becomes 5 with llr_exact): what the team kernel's variable sweep stores per bit when LLRs are wanted (TeamParams::llr_raw)
     bool team_llr_footprint = true;   // LDPC_TEAM_LLR_FOOTPRINT: the plan counts a tile's LLR rows (n x 512 B, rewritten in every iteration) as part of its slot
     int team_ahead = 32;      // LDPC_TEAM_AHEAD: active lanes from which on a team starts the next check sweep with the convergence
                               // test still under way (two team barriers an iteration instead of three); 0 = never
@@ -564,7 +572,7 @@ struct ldpc_bp_decoder {
         const bool stalled = ldpc_detail::device_stalled(device);   // (then nothing is freed: host_wait.hpp)
         const bool idle = device_idle && !stalled;
         DevBuf *all[] = {&row_ptr, &edge_bit, &col_ptr, &csc2csr, &msg, &ctrl, &synmask, &nevermask,
-                         &errmask, &finmask, &llr_t, &st_all, &node_msg, &done_ctr, &team_ws, &team_ws_lvl[0], &team_ws_lvl[1], &cold,
+                         &errmask, &finmask, &llr_t, &st_all, &node_msg, &done_ctr, &team_ws, &team_ws_lvl[0], &team_ws_lvl[1], &cold, &team_llr,
                          &rows_ctab, &rows_vtab, &rows_lds_edge, &rows_reg_edge};
         for (DevBuf *b : all) b->release(idle);
         for (int l = 0; l < 2; ++l)
@@ -904,6 +912,7 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     if (d->defer_thresh > 48 || d->defer_thresh < -1) { delete d; return fail(LDPC_ERR_INVALID_ARGUMENT, "defer_threshold must be -1, 0 or 1..48"); }
     for (auto &row : d->blocks_cache)
         for (int &v : row) v = -1;
+    d->llr_exact = options && options->llr_exact != 0;
     d->variant = options ? options->kernel_variant : 0;
     if (d->variant < 0 || d->variant > 4) { delete d; return fail(LDPC_ERR_INVALID_ARGUMENT, "kernel_variant must be 0 ... 4"); }
     if (const char *e = exp_env("LDPC_TEAM_INJECT_FAULT")) d->inject_fault = std::max(1, std::atoi(e));   // (tests, experiments build: 1 = fault word at once, 2 = a member misses the roll call)
@@ -915,11 +924,17 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     if (const char *e = exp_env("LDPC_TEAM_PAIRS")) d->team_pairs = std::atoi(e) & 3;   // (bit 1: four bits at once in the variable sweep)
     if (const char *e = exp_env("LDPC_TEAM_AHEAD")) { d->team_ahead = std::max(0, std::min(65, std::atoi(e))); d->team_ahead_set = true; }
     if (const char *e = exp_env("LDPC_TEAM_AHEAD_FROM")) d->team_ahead_from = std::max(1, std::atoi(e));
-    if (const char *e = exp_env("LDPC_TEAM_LLR_RAW")) d->team_llr_raw = std::max(0, std::min(2, std::atoi(e)));
+    if (const char *e = exp_env("LDPC_TEAM_LLR_RAW")) d->team_llr_raw = std::max(0, std::min(5, std::atoi(e)));
+    if (d->llr_exact && (d->team_llr_raw == 4 || d->team_llr_raw == 3)) d->team_llr_raw = d->team_llr_raw == 4 ? 5 : 1;   // (exact LLRs need all of T)
     if (const char *e = exp_env("LDPC_TEAM_LLR_FOOTPRINT")) d->team_llr_footprint = std::atoi(e) != 0;
     if (const char *e = exp_env("LDPC_TEAM_REGS")) d->team_regs = std::max(0, std::min(kTeamRegRows, std::atoi(e)));
     if (const char *e = exp_env("LDPC_TEAM_FLIP")) d->team_flip = std::atoi(e) & 3;
     if (const char *e = exp_env("LDPC_TEAM_STATIC")) d->team_static_quarters = std::max(0, std::min(4, std::atoi(e)));
+    if (const char *e = exp_env("LDPC_TEAM_PER_CU")) d->team_per_cu_want = std::max(1, std::min(3, std::atoi(e)));
+    if (const char *e = exp_env("LDPC_TEAM_MIN_ROWS")) { d->team_min_rows = std::max<int64_t>(1, std::atoll(e)); d->team_min_rows_set = true; }
+    d->team_no_margin = exp_env("LDPC_TEAM_NO_MARGIN") != nullptr;          // (experiments: fill the CUs exactly)
+    d->team_always_release = exp_env("LDPC_TEAM_ALWAYS_RELEASE") != nullptr;
+    d->team_coop = exp_env("LDPC_TEAM_COOP_LAUNCH") != nullptr;
     if (const char *e = exp_env("LDPC_TEAM_MAX")) { d->team_max = std::max(1, std::min(kTeamMaxMembers, std::atoi(e))); d->team_max_set = true; }
     {
         void *fp = nullptr, *fd = nullptr;
@@ -1025,7 +1040,7 @@ ldpc_status ldpc_bp_get_info(const ldpc_bp_decoder *d, ldpc_bp_info *info)
                            &d->nevermask, &d->errmask, &d->finmask, &d->llr_t, &d->st_all, &d->node_msg, &d->pipe_dev[0], &d->pipe_dev[1], &d->pipe_dev[2],
                            &d->lvl_state[0], &d->lvl_state[1], &d->lvl_list[0], &d->lvl_list[1], &d->lvl_it[0], &d->lvl_it[1],
                            &d->lvl_syn[0], &d->lvl_syn[1], &d->lvl_never[0], &d->lvl_never[1], &d->lvl_err[0], &d->lvl_err[1], &d->lvl_fin[0], &d->lvl_fin[1],
-                           &d->lvl_llr[0], &d->lvl_llr[1], &d->team_ws, &d->team_ws_lvl[0], &d->team_ws_lvl[1],
+                           &d->lvl_llr[0], &d->lvl_llr[1], &d->team_ws, &d->team_ws_lvl[0], &d->team_ws_lvl[1], &d->team_llr,
                            &d->rows_ctab, &d->rows_vtab, &d->rows_lds_edge, &d->rows_reg_edge};
     for (const DevBuf *b : all) info->workspace_bytes += (int64_t)b->cap;
     info->last_kernel = d->last_kernel;
@@ -1048,10 +1063,24 @@ ldpc_status ldpc_bp_get_info(const ldpc_bp_decoder *d, ldpc_bp_info *info)
 // after the tool has finalised: profiles/README.md, round 2), and the launch costs 15-19 us more.  A plain
 // launch of the same grid has the same residency (MI355X_MICROARCH.md, "Residency and cooperative launch").
 // LDPC_TEAM_COOP_LAUNCH=1 brings the cooperative launch back (experiments).
+// (Two builds of this library in one process -- the product and the experiments build, which the Python host loads
+// side by side -- would each keep an event table of their own and could put two team grids on one device together;
+// the host lets the second build ADOPT the first one's table: ldpc_debug_adopt_process_state().)
 namespace {
-std::mutex g_team_mu;
-hipEvent_t g_team_ev[64] = {};   // per device: completion of the most recent team grid (process lifetime)
+struct ProcessState {
+    std::mutex team_mu;
+    hipEvent_t team_ev[64] = {};   // per device: completion of the most recent team grid (process lifetime)
+};
+ProcessState g_own_state;
+ProcessState *g_ps = &g_own_state;
 }  // namespace
+extern "C" void *ldpc_debug_process_state(void) { return g_ps; }
+extern "C" ldpc_status ldpc_debug_adopt_process_state(void *state)
+{
+    if (!state) return fail(LDPC_ERR_INVALID_ARGUMENT, "state is NULL");
+    g_ps = (ProcessState *)state;   // (same sources, same layout: both builds come out of one make)
+    return LDPC_OK;
+}
 
 // Dynamic LDS a team workgroup asks for although it uses none (LDPC_TEAM_LDS_KIB): a way to bound how many
 // members the dispatcher can put on one CU (81+ KiB: one, 54+ KiB: two), so that a grid of exactly that many
@@ -1064,10 +1093,9 @@ static size_t team_lds_bytes()
 
 static hipError_t launch_team_grid(ldpc_bp_decoder *d, team_kernel_t tk, int grid, void **args, hipStream_t stream, size_t lds)
 {
-    static const bool coop = exp_env("LDPC_TEAM_COOP_LAUNCH") != nullptr;
-    if (coop) return hipLaunchCooperativeKernel((const void *)tk, dim3((unsigned)grid), dim3(LDPC_TEAM_THREADS), args, (unsigned)lds, stream);
-    std::lock_guard<std::mutex> lk(g_team_mu);
-    hipEvent_t *gev = (d->device >= 0 && d->device < 64) ? &g_team_ev[d->device] : nullptr;
+    if (d->team_coop) return hipLaunchCooperativeKernel((const void *)tk, dim3((unsigned)grid), dim3(LDPC_TEAM_THREADS), args, (unsigned)lds, stream);
+    std::lock_guard<std::mutex> lk(g_ps->team_mu);
+    hipEvent_t *gev = (d->device >= 0 && d->device < 64) ? &g_ps->team_ev[d->device] : nullptr;
     if (gev) {
         if (!*gev) {
             if (hipEventCreateWithFlags(gev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); *gev = nullptr; }
@@ -1103,15 +1131,15 @@ constexpr int64_t kTeamMinRowsOne = 1100;   // message rows per sweep a member o
 static bool team_geometry(ldpc_bp_decoder *d, bool want_llr, int *per_xcd, int *gcap, int *gcap_one = nullptr)
 {
     if (!(d->variant == 0 || d->variant == 4) || d->team_max < 2 || d->wpt_fixed || d->resident_fixed || d->nnz <= 0) return false;
-    static const int per_cu_want = [] { const char *e = exp_env("LDPC_TEAM_PER_CU"); return e ? std::max(1, std::min(3, std::atoi(e))) : 2; }();
+    const int per_cu_want = d->team_per_cu_want;
     // what this instantiation's registers admit (the wide-degree buckets: one 8-wave workgroup per CU), less one
     // as the margin where that leaves at least one
     int occ = 0;
     if (d->prepare_kernel((const void *)pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr), LDPC_TEAM_THREADS, team_lds_bytes(), &occ) != LDPC_OK) return false;
-    static const bool no_margin = exp_env("LDPC_TEAM_NO_MARGIN") != nullptr;   // (experiments: fill the CUs exactly)
+    const bool no_margin = d->team_no_margin;
     const int per_cu = no_margin ? std::min(per_cu_want, occ) : std::min(per_cu_want, occ >= 2 ? occ - (occ > per_cu_want ? 0 : 1) : occ);
     if (per_cu < 1) return false;
-    static const int64_t min_rows = [] { const char *e = exp_env("LDPC_TEAM_MIN_ROWS"); return e ? std::max<int64_t>(1, std::atoll(e)) : (int64_t)2048; }();
+    const int64_t min_rows = d->team_min_rows;
     *per_xcd = per_cu * (d->num_cus / 8);
     *gcap = (int)std::min<int64_t>(d->team_max, std::max<int64_t>(1, d->nnz / min_rows));   // (LDPC_TEAM_MIN_ROWS=1: tests put teams on tiny graphs)
     // ONE persistent team per XCD may have more members than that -- ALL the CUs of its XCD, or it stays as it is --
@@ -1119,7 +1147,7 @@ static bool team_geometry(ldpc_bp_decoder *d, bool want_llr, int *per_xcd, int *
     // rows 132 ms, with 23 of 2136 rows 156 ms; (4,8) n = 12288 / 11264 / 10240 / 9216 with 32 members 139 / 126 / 117 /
     // 105 ms against 155 / 149 / 152 / 110 ms under the 2048-row rule; (3,6) n = 12288 100 against 112 ms; but n = 8192,
     // 1024 rows a member: 96 ms against 90 ms for sixteen teams of 16 -- profiles/r03_minrows_ab.txt, r03_minrows2.txt)
-    static const bool min_rows_set = exp_env("LDPC_TEAM_MIN_ROWS") != nullptr;
+    const bool min_rows_set = d->team_min_rows_set;
     if (gcap_one) {
         const int64_t full = std::min<int64_t>(d->team_max, d->num_cus / 8);
         *gcap_one = (!min_rows_set && d->nnz / kTeamMinRowsOne >= full) ? (int)std::max<int64_t>(*gcap, full) : *gcap;
@@ -1155,6 +1183,11 @@ struct TeamPlanIn {
     // bytes a team keeps rewriting besides its message slot: with LLRs wanted the posterior odds of every bit of the tile in
     // hand, n x 512 B per iteration (they live in the cache with the slot, and count against the same budget)
     size_t extra = 0;
+    // WIDE teams (round 4; LDPC_TEAM_WIDE = 1, 2, 4: experiments, 0 = off): `wide` persistent teams of (all workgroups) / wide
+    // members each, dealt over ALL XCDs, rows on chip -- for graphs whose slot alone is a large part of the Infinity Cache
+    // (n = 65536: 128 MiB a slot, 96 MiB with a quarter of the rows on chip; two of them fit where eight one-XCD teams'
+    // slots are four times the cache).  Every barrier then writes the XCDs' L2s back (the members share no L2).
+    int wide = 0;
 };
 
 // What a member is expected to keep on chip (a bit dealt to a member that owns one of its dv checks: 1 / dv of the edges
@@ -1380,6 +1413,29 @@ extern "C" ldpc_status ldpc_debug_team_rows(int64_t s, int64_t n, const int64_t 
     return LDPC_OK;
 }
 
+// include/ldpc_mi355x_debug.h: div_core against `/` on the device (a GPU test)
+extern "C" ldpc_status ldpc_debug_div_check(int64_t count, const double *num, const double *den, double *out_core, double *out_ieee)
+{
+    if (count < 0 || (count > 0 && (!num || !den || !out_core || !out_ieee))) return fail(LDPC_ERR_INVALID_ARGUMENT, "bad argument");
+    if (count == 0) return LDPC_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return fail(LDPC_ERR_NO_DEVICE, "no HIP device available"); }
+    const size_t bytes = (size_t)count * sizeof(double);
+    double *dv = nullptr;
+    HIP_TRY(hipMalloc((void **)&dv, 4 * bytes));
+    hipError_t e = hipMemcpy(dv, num, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dv + count, den, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(div_check_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, nullptr, dv, dv + count, dv + 2 * count, dv + 3 * count, (long long)count);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out_core, dv + 2 * count, bytes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_ieee, dv + 3 * count, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(dv);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(LDPC_ERR_HIP, std::string("ldpc_debug_div_check: ") + hipGetErrorString(e)); }
+    return LDPC_OK;
+}
+
 static ldpc_status team_rows_build(ldpc_bp_decoder *d, int G)
 {
     if (d->rows_G == G) return LDPC_OK;
@@ -1467,6 +1523,7 @@ struct TeamPlan {
     int grid = 0;         // workgroups to launch
     int xcds = 8, tpx = 0;   // XCDs that host teams, teams per XCD (not in scatter mode)
     bool scatter = false;
+    bool wide = false;       // a few persistent teams over all XCDs (TeamPlanIn::wide)
     bool rows = false;       // members keep the rows that only they touch in LDS (TeamRows)
 };
 
@@ -1478,7 +1535,12 @@ static TeamPlan team_plan_pure(const TeamPlanIn &in, int64_t batch)
     if (ntiles < 1 || per_xcd < 1) return pl;
     if ((size_t)ntiles * ((size_t)in.max_iters + 32) * sizeof(u64) > ((size_t)64 << 20)) return pl;   // mismatch words per tile and iteration
     int64_t team = 1, nteams = 0;
-    if (ntiles <= in.scatter_tiles && !in.team_max_set) {
+    if (in.wide > 0 && ntiles > in.scatter_tiles) {
+        team = std::min<int64_t>(kTeamMaxMembers, (int64_t)8 * per_xcd / in.wide);
+        nteams = std::min<int64_t>(in.wide, ntiles);
+        pl.scatter = true;
+        pl.wide = true;
+    } else if (ntiles <= in.scatter_tiles && !in.team_max_set) {
         // dealt over all 8 XCDs (scatter mode of the kernel): larger teams pay -- one tile of the C3 code, 50
         // iterations: 32 members 5.4 ms, 48: 4.3 ms, 64: 3.4 ms, 128: 2.6 ms (a member still has >= 512 message rows per sweep)
         const int64_t cap = std::min<int64_t>(in.scatter_max, std::max<int64_t>(gcap, in.nnz / std::max(in.scatter_rows, 1)));
@@ -1505,7 +1567,7 @@ static TeamPlan team_plan_pure(const TeamPlanIn &in, int64_t batch)
     }
     if (team < 3) return pl;   // two workgroups per tile measured no better than the tile kernel's one of 16 waves
     pl.G = (int)std::min<int64_t>(team, kTeamMaxMembers);
-    pl.rows = !pl.scatter && in.rows_possible && team_rows_expected(in, pl.G) >= 16;
+    pl.rows = (!pl.scatter || pl.wide) && in.rows_possible && team_rows_expected(in, pl.G) >= 16;
     pl.nteams = (int)nteams;
     pl.grid = pl.scatter ? pl.nteams * pl.G : 8 * pl.G * pl.tpx;
     return pl;
@@ -1514,7 +1576,7 @@ static TeamPlan team_plan_pure(const TeamPlanIn &in, int64_t batch)
 static TeamPlanIn team_plan_in(const ldpc_bp_decoder *d, int per_xcd, int gcap, int gcap_one = 0, bool want_llr = false)
 {
     TeamPlanIn in;
-    in.extra = (want_llr && d->team_llr_footprint) ? (size_t)std::max<int64_t>(d->n, 0) * kTile * sizeof(double) : 0;
+    in.extra = (want_llr && d->team_llr_footprint) ? (size_t)std::max<int64_t>(d->n, 0) * kTile * ((d->team_llr_raw == 3 || d->team_llr_raw == 4) ? sizeof(unsigned int) : sizeof(double)) : 0;
     in.nnz = d->nnz; in.max_iters = d->max_iters; in.cache = d->team_cache; in.xcds_forced = d->team_xcds;
     in.team_max_set = d->team_max_set; in.rows_possible = team_rows_possible(d); in.rows_dv = std::max(d->rows_dv, 1); in.num_cus = d->num_cus;
     in.reg_rows = in.rows_possible ? d->team_regs * (LDPC_TEAM_THREADS / 64) : 0;
@@ -1522,6 +1584,7 @@ static TeamPlanIn team_plan_in(const ldpc_bp_decoder *d, int per_xcd, int gcap, 
     if (const char *e = exp_env("LDPC_TEAM_SCATTER_MAX")) in.scatter_max = std::max(3, std::min(kTeamMaxMembers, std::atoi(e)));
     if (const char *e = exp_env("LDPC_TEAM_SCATTER_ROWS")) in.scatter_rows = std::max(1, std::atoi(e));
     if (const char *e = exp_env("LDPC_TEAM_SCATTER_TILES")) in.scatter_tiles = std::max(0, std::min(16, std::atoi(e)));
+    if (const char *e = exp_env("LDPC_TEAM_WIDE")) in.wide = std::max(0, std::min(8, std::atoi(e)));
     return in;
 }
 
@@ -1664,6 +1727,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         lp.logS = logS; lp.ngroups = (int)ngroups64; lp.batch = batch;
         lp.r = d->per / (1 - d->per);
         lp.syn = d_syn; lp.err = d_err; lp.conv = d_conv; lp.iters = d_iters; lp.llr = d_llr;
+        lp.llr_exact = d->llr_exact ? 1 : 0;
         lp.queue = (unsigned int *)ctrl;
         lp.sum_iters = (u64 *)(ctrl + 8);
         lp.phase_ticks = (u64 *)(ctrl + 16);
@@ -1730,7 +1794,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         NodeParams np{};
         np.s = (int)s; np.n = (int)n; np.nnz = (int)d->nnz; np.max_iters = (int)d->max_iters;
         np.batch = batch; np.r = d->per / (1 - d->per);
-        np.syn = d_syn; np.err = d_err; np.conv = d_conv; np.iters = d_iters; np.llr = d_llr;
+        np.syn = d_syn; np.err = d_err; np.conv = d_conv; np.iters = d_iters; np.llr = d_llr; np.llr_exact = d->llr_exact ? 1 : 0;
         np.msg = (double *)d->node_msg.p; np.slot_stride = (long long)stride;
         np.queue = (unsigned int *)ctrl;
         np.sum_iters = (u64 *)(ctrl + 8);
@@ -1943,6 +2007,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     p.count_dev = nullptr;
     p.count_skip = 0;
     p.resumed = 0;
+    p.llr_exact = d->llr_exact ? 1 : 0;
     for (BPCold &c : cold) {
         c.iters = d_iters;
         c.conv = d_conv;
@@ -1959,7 +2024,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     hipLaunchKernelGGL(store_cold_kernel, dim3(1), dim3(64), 0, stream, cold[0], cold[1], cold[2], d_cold);
     HIP_TRY(hipGetLastError());
     bp_kernel_t kfn = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, threads);
-    static const int always_release = exp_env("LDPC_TEAM_ALWAYS_RELEASE") ? 1 : 0;
+    const int always_release = d->team_always_release ? 1 : 0;
     auto team_params = [&](DevBuf &wsbuf, int nteams, int tiles, TeamParams &tp) -> ldpc_status {
         const size_t ctl_bytes = ((size_t)nteams + 1) * kTeamCtlWords * sizeof(unsigned int);   // + the block of the tile queue
         const size_t mism_stride = ((size_t)d->max_iters + 31) & ~(size_t)31;
@@ -1985,6 +2050,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         tp.ahead_min = 0;
         tp.ahead_from = 2;
         tp.llr_raw = 0;
+        tp.llr_scratch = nullptr;
         return LDPC_OK;
     };
     bool team_ran = team > 1;
@@ -2001,7 +2067,12 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         tp.ahead_min = d->team_ahead;
         tp.ahead_from = d->team_ahead_from;
         tp.llr_raw = want_llr ? d->team_llr_raw : 0;
-        llr_raw_out = tp.llr_raw != 0;
+        tp.llr_scratch = nullptr;
+        if (tp.llr_raw >= 4) {
+            if ((st = d->team_llr.ensure(std::max<size_t>((size_t)plan.nteams * (((size_t)n + 3) & ~(size_t)3), 1) * kTile * (tp.llr_raw == 4 ? sizeof(unsigned int) : sizeof(double)))) != LDPC_OK) return st;
+            tp.llr_scratch = (unsigned int *)d->team_llr.p;
+        }
+        llr_raw_out = tp.llr_raw;
         // one round of teams over all XCDs (<= 3 tiles: a single decode!): no other tile waits for this team, so a sweep
         // ahead that turns out to be for nothing costs one sweep at the end, and the barrier saved in every iteration
         // is worth it whatever the number of active lanes (one syndrome, 50 iterations: 2.62 -> 2.31 ms)
@@ -2128,7 +2199,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         HIP_TRY(hipGetLastError());
         if (want_llr) {
             hipLaunchKernelGGL(unpack_llr_kernel, g, dim3(256), 0, stream, (const double *)d->llr_t.p,
-                               (long long)batch, (int)n, d_llr, (const int *)nullptr, (const unsigned int *)nullptr, 0u, llr_raw_out);
+                               (long long)batch, (int)n, d_llr, (const int *)nullptr, (const unsigned int *)nullptr, 0u, llr_raw_out, d->llr_exact ? 1 : 0);
             HIP_TRY(hipGetLastError());
         }
         for (int l = 1; l <= nlevels; ++l) {
@@ -2140,7 +2211,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             if (want_llr) {
                 hipLaunchKernelGGL(unpack_llr_kernel, g2, dim3(256), 0, stream, (const double *)d->lvl_llr[l - 1].p,
                                    (long long)0, (int)n, d_llr, (const int *)d->lvl_list[l - 1].p,
-                                   (const unsigned int *)lv[l].count, lv[l].node_take, 0);
+                                   (const unsigned int *)lv[l].count, lv[l].node_take, 0, 0);
                 HIP_TRY(hipGetLastError());
             }
         }
@@ -2163,7 +2234,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         NodeParams np{};
         np.s = (int)s; np.n = (int)n; np.nnz = (int)d->nnz; np.max_iters = (int)d->max_iters;
         np.batch = 0; np.r = p.r;
-        np.syn = d_syn; np.err = d_err; np.conv = d_conv; np.iters = d_iters; np.llr = d_llr;
+        np.syn = d_syn; np.err = d_err; np.conv = d_conv; np.iters = d_iters; np.llr = d_llr; np.llr_exact = d->llr_exact ? 1 : 0;
         np.msg = (double *)d->node_msg.p; np.slot_stride = (long long)stride;
         np.queue = L.node_queue;
         np.sum_iters = (u64 *)(ctrl + 8);

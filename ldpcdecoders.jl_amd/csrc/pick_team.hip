@@ -29,8 +29,12 @@ team_kernel_t team_pick_dc(int dc, int dv)
 #define LDPC_TEAM_ROWS 0
 #endif
 #if LDPC_TEAM_ROWS
-// (a third compilation: -DLDPC_TEAM_ROWS=1) rows in LDS: regular graphs, EXACT degrees (team_rows_degrees_ok()), fresh
-// tiles.  nullptr: no instantiation for this pair.
+// (further compilations: -DLDPC_TEAM_ROWS=1 -DLDPC_TEAM_ROWS_DC=6 ... 10, one object per check degree so that they build in
+// parallel) rows on chip: regular graphs, EXACT degrees (team_rows_degrees_ok(): check degree 6 ... 10 x bit degree
+// 3 ... 5, north_star's "row-weight ~6-10"), fresh tiles.  nullptr: no instantiation for this pair.
+#ifndef LDPC_TEAM_ROWS_DC
+#error "compile with -DLDPC_TEAM_ROWS_DC=<check degree>"
+#endif
 namespace {
 template <int DC, int DV>
 team_kernel_t rows_pick(bool llr, bool regs)
@@ -45,11 +49,13 @@ team_kernel_t rows_pick(bool llr, bool regs)
 }
 }  // namespace
 // regs: the instantiation whose waves also keep rows in registers (TeamRows::regs > 0)
-team_kernel_t pick_team_kernel_rows(int dc, int dv, bool llr, bool regs)
+#define LDPC_ROWS_PICK_NAME2(dc) pick_team_kernel_rows_dc##dc
+#define LDPC_ROWS_PICK_NAME(dc) LDPC_ROWS_PICK_NAME2(dc)
+team_kernel_t LDPC_ROWS_PICK_NAME(LDPC_TEAM_ROWS_DC)(int dv, bool llr, bool regs)
 {
-    if (dc == 8 && dv == 4) return rows_pick<8, 4>(llr, regs);
-    if (dc == 6 && dv == 3) return rows_pick<6, 3>(llr, regs);
-    if (dc == 10 && dv == 5) return rows_pick<10, 5>(llr, regs);
+    if (dv == 3) return rows_pick<LDPC_TEAM_ROWS_DC, 3>(llr, regs);
+    if (dv == 4) return rows_pick<LDPC_TEAM_ROWS_DC, 4>(llr, regs);
+    if (dv == 5) return rows_pick<LDPC_TEAM_ROWS_DC, 5>(llr, regs);
     return nullptr;
 }
 #elif LDPC_TEAM_RESUMED
@@ -59,6 +65,23 @@ team_kernel_t pick_team_kernel_resumed(int dc, int dv, bool llr)
 }
 #else
 team_kernel_t pick_team_kernel_resumed(int dc, int dv, bool llr);
+team_kernel_t pick_team_kernel_rows_dc6(int dv, bool llr, bool regs);
+team_kernel_t pick_team_kernel_rows_dc7(int dv, bool llr, bool regs);
+team_kernel_t pick_team_kernel_rows_dc8(int dv, bool llr, bool regs);
+team_kernel_t pick_team_kernel_rows_dc9(int dv, bool llr, bool regs);
+team_kernel_t pick_team_kernel_rows_dc10(int dv, bool llr, bool regs);
+team_kernel_t pick_team_kernel_rows(int dc, int dv, bool llr, bool regs)
+{
+    if (!team_rows_degrees_ok(dc, dv)) return nullptr;
+    switch (dc) {
+    case 6: return pick_team_kernel_rows_dc6(dv, llr, regs);
+    case 7: return pick_team_kernel_rows_dc7(dv, llr, regs);
+    case 8: return pick_team_kernel_rows_dc8(dv, llr, regs);
+    case 9: return pick_team_kernel_rows_dc9(dv, llr, regs);
+    case 10: return pick_team_kernel_rows_dc10(dv, llr, regs);
+    }
+    return nullptr;
+}
 team_kernel_t pick_team_kernel(int dc, int dv, bool llr, bool resumed)
 {
     if (resumed) return pick_team_kernel_resumed(dc, dv, llr);

@@ -91,7 +91,8 @@ class BeliefPropagationDecoder(AbstractDecoder):
     """Drop-in for `BeliefPropagationDecoder(H, per::Float64, max_iters::Int)`.
 
     Extra keyword arguments select the device and tuning knobs; defaults give
-    the reference behaviour.  ``devices=[0, 1, ...]`` makes ``batchdecode_`` / ``decode_batch_host`` /
+    the reference behaviour (``llr_exact=True``: LLRs from the full posterior odds instead of their upper 32 bits;
+    include/ldpc_mi355x.h ldpc_bp_options).  ``devices=[0, 1, ...]`` makes ``batchdecode_`` / ``decode_batch_host`` /
     ``decode_batch_device`` partition the batch over those GPUs from this one process
     (ldpc_bp_create_multi: contiguous shards, one handle and stream per device; ``exchange`` picks how the
     root-device form moves shards: 0 auto, 1 hipMemcpyPeer, 2 RCCL).  ``experiments=True`` binds the build of
@@ -101,7 +102,7 @@ class BeliefPropagationDecoder(AbstractDecoder):
     def __init__(self, H, per: float, max_iters: int, *, device: Optional[int] = None,
                  devices: Optional[Sequence[int]] = None, exchange: int = 0,
                  waves_per_tile: int = 0, resident_tiles: int = 0, kernel_variant: int = 0,
-                 defer_threshold: int = 0, experiments: Optional[bool] = None):
+                 defer_threshold: int = 0, llr_exact: bool = False, experiments: Optional[bool] = None):
         if not isinstance(per, float):
             raise TypeError("per must be a Float64 (reference signature: per::Float64)")
         if isinstance(max_iters, bool) or not isinstance(max_iters, (int, np.integer)):
@@ -122,6 +123,7 @@ class BeliefPropagationDecoder(AbstractDecoder):
         opts.resident_tiles = int(resident_tiles)
         opts.kernel_variant = int(kernel_variant)   # 0 auto, 1 HBM-streaming, 2 LDS-resident, 3 node-parallel, 4 team
         opts.defer_threshold = int(defer_threshold)  # 0 auto (16), -1 off: straggler hand-off of the streaming kernel
+        opts.llr_exact = 1 if llr_exact else 0       # LLRs from the full posterior odds (default: their upper 32 bits, within 5e-7)
         self._h = ctypes.c_void_p()
         self._m = None                         # the multi-device handle when devices= is given
         self._L = L = _capi.lib_for(experiments)

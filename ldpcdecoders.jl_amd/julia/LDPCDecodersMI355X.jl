@@ -63,7 +63,10 @@ mutable struct MI355XBeliefPropagationDecoder <: AbstractDecoder
 end
 
 """
-    MI355XBeliefPropagationDecoder(H, per, max_iters; device=-1, devices=nothing, exchange=0)
+    MI355XBeliefPropagationDecoder(H, per, max_iters; device=-1, devices=nothing, exchange=0, llr_exact=false)
+
+`llr_exact = true`: `scratch.log_probabs` from the full posterior odds (`ldpc_bp_options.llr_exact`; the default cuts the odds
+to their upper 32 bits: LLRs within 5e-7 of the reference's).  The BP+OSD type below asks for it.
 
 `devices = 0:7` makes `batchdecode!` one call that partitions the columns of its `syndromes` matrix over those GPUs
 (`ldpc_bp_create_multi`: contiguous shards, one handle and stream per GPU; the host arrays go pinned host -> each
@@ -71,13 +74,15 @@ shard's own GPU and back).  `exchange` only matters for device-resident batches 
 0 auto = RCCL send/recv from `devices[1]`, 1 hipMemcpyPeer, 2 RCCL).
 """
 function MI355XBeliefPropagationDecoder(H, per::Float64, max_iters::Int; device::Integer=-1,
-                                        devices::Union{Nothing,AbstractVector{<:Integer}}=nothing, exchange::Integer=0)
+                                        devices::Union{Nothing,AbstractVector{<:Integer}}=nothing, exchange::Integer=0,
+                                        llr_exact::Bool=false)
     s, n = size(H)
     sparse_H = SparseMatrixCSC{Bool,Int}(sparse(H))          # :63
     sparse_HT = SparseMatrixCSC{Bool,Int}(sparse(H'))        # :64
     colptr = Int64.(sparse_H.colptr .- 1)                    # zero-based for the ABI
     rowval = Int64.(rowvals(sparse_H) .- 1)
-    opts = zeros(Int32, 16); opts[1] = Int32(device)
+    opts = zeros(Int32, 16); opts[1] = Int32(device)         # ldpc_bp_options: device, waves_per_tile, resident_tiles,
+    opts[6] = Int32(llr_exact)                               # kernel_variant, defer_threshold, llr_exact, reserved[10]
     h = Ref{Ptr{Cvoid}}(C_NULL)
     m = C_NULL
     if devices === nothing
@@ -174,6 +179,22 @@ function batchdecode!(d::MI355XBeliefPropagationDecoder, syndromes::AbstractMatr
             errors[j, i] = d.err_u8[(i - 1) * d.n + j]        # :227 (0/1 -> eltype(errors))
         end
     end
+    # the reference's per-column loop (:224-228) leaves the scratch with the LAST column's decision and LLRs: the
+    # decision is in hand, the LLRs come from a second call on that one column (deterministic per syndrome)
+    @inbounds for j in 1:d.n
+        d.scratch.err[j] = d.err_u8[(B - 1) * d.n + j]
+    end
+    GC.@preserve d begin
+        last_err = Vector{UInt8}(undef, d.n); last_conv = Vector{UInt8}(undef, 1)
+        syn_last = pointer(d.syn_u8, (B - 1) * d.s + 1)
+        check(d.multi != C_NULL ?
+              ccall((:ldpc_bp_decode_batch_multi, libldpc), Cint,
+                    (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{UInt8}, Ptr{UInt8}, Ptr{Float64}, Ptr{Int32}),
+                    d.multi, 1, syn_last, last_err, last_conv, d.scratch.log_probabs, C_NULL) :
+              ccall((:ldpc_bp_decode_batch, libldpc), Cint,
+                    (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{UInt8}, Ptr{UInt8}, Ptr{Float64}, Ptr{Int32}),
+                    d.handle, 1, syn_last, last_err, last_conv, d.scratch.log_probabs, C_NULL))
+    end
     return errors, success                                    # :230
 end
 
@@ -195,7 +216,7 @@ end
 
 function MI355XBeliefPropagationOSDDecoder(H::BitMatrix, per::Float64, max_iters::Int;
                                            osd_order::Int=0, device::Integer=-1)     # :26-29
-    bp = MI355XBeliefPropagationDecoder(H, per, max_iters; device=device)
+    bp = MI355XBeliefPropagationDecoder(H, per, max_iters; device=device, llr_exact=true)   # (OSD orders bits by reliability, :53-55)
     colptr = Int64.(bp.sparse_H.colptr .- 1); rowval = Int64.(rowvals(bp.sparse_H) .- 1)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:ldpc_osd_create, libldpc), Cint,

@@ -16,7 +16,8 @@
 # (abstract_decoder.jl:44-48), QuantumClifford's extension.  `reset!` stays the reference's (:83-91) for whoever calls
 # it, but the methods below do NOT: it fills the two dense s x n Float64 matrices of the scratch (2 GiB at n = 16384),
 # which nobody reads here -- the messages live in HBM, and the device state is reset inside every call; the library
-# overwrites `scratch.log_probabs` and this file `scratch.err` completely on every decode!.  What stays of the
+# overwrites `scratch.log_probabs` and this file `scratch.err` completely on every decode! and, with the last column's
+# values, on every batchdecode! (as the reference's per-column loop leaves them, :224-228).  What stays of the
 # reference's cost is its CONSTRUCTOR, which still allocates those 2 * s * n * 8 bytes on the host once
 # (belief_propagation.jl:20-22); LDPCDecodersMI355X.jl next to this file has types of its own and avoids that too.
 #
@@ -67,14 +68,17 @@ function handle_of(d::BeliefPropagationDecoder)
             rowval = Int64.(rowvals(d.sparse_H) .- 1)
             h = Ref{Ptr{Cvoid}}(C_NULL)
             multi = !isempty(DEVICES)
+            # ldpc_bp_options with llr_exact = 1: a decoder of the reference's type may sit inside the reference's own
+            # BeliefPropagationOSDDecoder, which orders the bits by scratch.log_probabs (belief_propagation_osd.jl:52-55)
+            opts = zeros(Int32, 16); opts[1] = Int32(-1); opts[6] = Int32(1)
             if multi
                 check(ccall((:ldpc_bp_create_multi, libldpc), Cint,
                             (Int32, Ptr{Int32}, Int32, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Float64, Int64, Ptr{Int32}, Ptr{Ptr{Cvoid}}),
-                            length(DEVICES), DEVICES, 0, d.s, d.n, length(rowval), colptr, rowval, d.per, d.max_iters, C_NULL, h))
+                            length(DEVICES), DEVICES, 0, d.s, d.n, length(rowval), colptr, rowval, d.per, d.max_iters, opts, h))
             else
                 check(ccall((:ldpc_bp_create, libldpc), Cint,
                             (Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Float64, Int64, Ptr{Int32}, Ptr{Ptr{Cvoid}}),
-                            d.s, d.n, length(rowval), colptr, rowval, d.per, d.max_iters, C_NULL, h))
+                            d.s, d.n, length(rowval), colptr, rowval, d.per, d.max_iters, opts, h))
             end
             hd = Handle(h[], multi, UInt8[], UInt8[], UInt8[])
             finalizer(hd) do x
@@ -137,11 +141,24 @@ function LDPCDecoders.batchdecode!(d::BeliefPropagationDecoder, syndromes::Abstr
             errors[j, i] = h.err_u8[(i - 1) * d.n + j]                                     # :227
         end
     end
-    # the reference leaves the scratch holding the last column's state: `scratch.err` gets that column's decision
-    # here; `scratch.log_probabs` is NOT refreshed by a batch call (nothing in the reference reads it after one, and
-    # shipping 8 n bytes per column back for it would double the call's I/O) -- decode!(d, syndromes[:, end]) gives it
+    # The reference leaves the scratch holding the LAST column's state (:224-228 runs decode! per column, and decode!
+    # fills scratch.err and scratch.log_probabs, :163-168): `scratch.err` gets that column's decision, and
+    # `scratch.log_probabs` its LLRs -- asked for from the library for that one column alone (a second call with
+    # batch = 1 on the bytes already marshalled: the decoder is deterministic per syndrome, so these are the LLRs of the
+    # decode above; shipping 8 n bytes back for EVERY column would double the batch call's I/O for nothing)
     @inbounds for j in 1:d.n
         d.scratch.err[j] = h.err_u8[(B - 1) * d.n + j]
+    end
+    GC.@preserve h begin
+        last_err = Vector{UInt8}(undef, d.n); last_conv = Vector{UInt8}(undef, 1)
+        syn_last = pointer(h.syn_u8, (B - 1) * d.s + 1)
+        check(h.multi ?
+              ccall((:ldpc_bp_decode_batch_multi, libldpc), Cint,
+                    (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{UInt8}, Ptr{UInt8}, Ptr{Float64}, Ptr{Int32}),
+                    h.ptr, 1, syn_last, last_err, last_conv, d.scratch.log_probabs, C_NULL) :
+              ccall((:ldpc_bp_decode_batch, libldpc), Cint,
+                    (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{UInt8}, Ptr{UInt8}, Ptr{Float64}, Ptr{Int32}),
+                    h.ptr, 1, syn_last, last_err, last_conv, d.scratch.log_probabs, C_NULL))
     end
     return errors, success                                                                 # :230
 end

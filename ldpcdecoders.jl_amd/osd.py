@@ -57,6 +57,8 @@ class BeliefPropagationOSDDecoder(AbstractDecoder):
     """`BeliefPropagationOSDDecoder(H, per, max_iters; osd_order=0)` (belief_propagation_osd.jl:26-29)."""
 
     def __init__(self, H, per: float, max_iters: int, *, osd_order: int = 0, **bp_kwargs):
+        # (exact LLRs: OSD orders the bits by reliability, :53-55 -- two that differ beyond the 21st bit must not tie)
+        bp_kwargs.setdefault("llr_exact", True)
         self.bp_decoder = BeliefPropagationDecoder(H, per, max_iters, **bp_kwargs)   # :27
         self.H = H                                                                    # :21
         self.osd_order = int(osd_order)                                               # :23

@@ -141,7 +141,9 @@ def _syndromes_on_device(H, wr, batch, per, seed):
 
 
 @pytest.mark.parametrize("n,wr,wc,batch,per", [(16380, 6, 3, 65536, 0.10), (16380, 6, 3, 65536, 0.055),
-                                              (16000, 10, 5, 32768, 0.10), (16000, 10, 5, 32768, 0.05)])
+                                              (16000, 10, 5, 32768, 0.10), (16000, 10, 5, 32768, 0.05),
+                                              # round 4: the other pairs of north_star's range (row weight 6 ... 10): (3,9) and (4,10)
+                                              (16380, 9, 3, 32768, 0.10), (16380, 9, 3, 32768, 0.02), (16380, 10, 4, 32768, 0.10)])
 def test_other_regular_codes_keep_rows_in_lds_full_batch(ldpc, gpu, n, wr, wc, batch, per):
     """Rows in LDS beyond the (4,8) code: a (3,6)-regular code of the C3 size and bench.py's wide_16000_10_5
     ((5,10)-regular, the 16-wide register bucket) at full batch through the default path -- persistent teams whose
@@ -192,3 +194,64 @@ def test_other_regular_codes_keep_rows_in_lds_full_batch(ldpc, gpu, n, wr, wc, b
     oerr, oconv, oits = (np.concatenate([r[k] for r in res]) for k in (0, 1, 3))
     assert np.array_equal(conv[tidx].cpu().numpy(), oconv) and np.array_equal(its[tidx].cpu().numpy(), oits)
     assert np.array_equal(err[tidx].cpu().numpy(), oerr)
+
+
+@pytest.mark.parametrize("per,exact", [(0.10, False), (0.02, False), (0.06, True)])
+def test_c3_full_batch_with_llrs(ldpc, gpu, per, exact):
+    """The LLR-producing instantiation at the C3 size (the reference's decode! always fills scratch.log_probabs,
+    belief_propagation.jl:163; BP+OSD reads them): the whole batch through the default path -- persistent teams that
+    capture the posterior odds of every active lane in every iteration in their own scratch rows (their upper 32 bits;
+    all 64 with llr_exact) and copy a tile's rows out once.  Hard decisions, flags and iteration counts must be what the
+    call without LLRs gives, bit for bit; the LLRs must be the tile kernel's bit for bit on a slice of the batch (every
+    kernel cuts the odds the same way), and the oracle's to 1e-5 (default) / 1e-9 (exact) with +-Inf exact on a sample --
+    per 0.10: every lane stops at iteration 50; 0.02: lanes stop at different iterations, tiles hand stragglers on;
+    0.06 (exact): the waterfall."""
+    H = ldpc.codes.parity_check_csc(N, WR, WC)
+    syn, cols = _device_syndromes(H, per, seed=int(per * 1000) + 7)
+    err0, conv0, its0 = _decode(ldpc, H, per, syn)
+    dec = ldpc.BeliefPropagationDecoder(H, per, ITERS, llr_exact=exact)
+    err = torch.empty((B, N), dtype=torch.uint8, device=syn.device)
+    conv = torch.empty(B, dtype=torch.uint8, device=syn.device)
+    its = torch.empty(B, dtype=torch.int32, device=syn.device)
+    llr = torch.full((B, N), float("nan"), dtype=torch.float64, device=syn.device)
+    dec.decode_batch_device(syn, err, conv, llr, its)
+    dec.last_status()
+    assert dec.info().last_kernel == 4 and dec.info().last_team_size == 32
+    dec.close()
+    assert torch.equal(err, err0) and torch.equal(conv, conv0) and torch.equal(its, its0)
+    del err0, conv0, its0
+    assert not bool(torch.isnan(llr).any())
+    # the sign of an LLR is the hard decision (T >= 1 <=> log(1 / T) <= 0), on the whole batch
+    for b0 in range(0, B, 8192):
+        assert bool(((llr[b0:b0 + 8192] <= 0) == (err[b0:b0 + 8192] == 1)).all())
+    # the tile kernel (no teams, no scratch rows) on a slice from the middle of the batch: the same bits
+    sl = slice(30000, 30000 + 2048)
+    tile = ldpc.BeliefPropagationDecoder(H, per, ITERS, kernel_variant=1, llr_exact=exact)
+    e2 = torch.empty((2048, N), dtype=torch.uint8, device=syn.device); c2 = torch.empty(2048, dtype=torch.uint8, device=syn.device)
+    l2 = torch.empty((2048, N), dtype=torch.float64, device=syn.device)
+    tile.decode_batch_device(syn[sl].contiguous(), e2, c2, l2, None)
+    tile.last_status()
+    tile.close()
+    assert torch.equal(e2, err[sl]) and torch.equal(l2.view(torch.int64), llr[sl].view(torch.int64))
+    del e2, c2, l2
+    # the oracle on a sample
+    idx = np.sort(np.random.default_rng(11).choice(B, 192, replace=False))
+    tidx = torch.from_numpy(idx).to(syn.device)
+    h_syn = syn[tidx].cpu().numpy()
+
+    def work(chunk):
+        oc = BPOracle(csc=(H.indptr, H.indices), shape=H.shape, per=per, max_iters=ITERS)
+        return oc.batchdecode(chunk, want_llr=True)
+
+    with cf.ThreadPoolExecutor(12) as ex:
+        res = list(ex.map(work, np.array_split(h_syn, 12)))
+    oerr, oconv, ollr, oits = (np.concatenate([r[k] for r in res]) for k in range(4))
+    assert np.array_equal(err[tidx].cpu().numpy(), oerr) and np.array_equal(conv[tidx].cpu().numpy(), oconv)
+    assert np.array_equal(its[tidx].cpu().numpy(), oits)
+    g = llr[tidx].cpu().numpy()
+    fin = np.isfinite(ollr)
+    assert np.array_equal(g[~fin], ollr[~fin])
+    worst = float(np.max(np.abs(g[fin] - ollr[fin])))
+    assert worst <= (1e-9 if exact else 1e-5), worst
+    if not exact:
+        assert worst <= 1e-6, worst      # (the cut is 2^-21 relative in the odds: 4.8e-7 in the logarithm)

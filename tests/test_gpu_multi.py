@@ -102,3 +102,49 @@ def test_root_device_form_with_llrs_and_ragged_shards(ldpc, gpu):
         assert np.array_equal(e.cpu().numpy(), oerr) and np.array_equal(c.cpu().numpy(), oconv)
         assert np.array_equal(it.cpu().numpy(), oits) and _close_llr(llr.cpu().numpy(), ollr)
     dec.close()
+
+
+def test_eight_way_control_flow_on_one_gpu(ldpc, gpu):
+    """First-contact rehearsal for BASELINE config 4 (one caller-held matrix over the 8 GPUs of a node): EIGHT logical
+    devices, all on GPU 0, through both forms of the one-process host -- shard_bounds for G = 8, seven peers' shard
+    buffers and streams, the scatter to and the gather from every peer (hipMemcpyPeerAsync here: logical devices that
+    share a GPU cannot form an RCCL clique; the RCCL calls themselves: the self-exchange test above).  The n = 16384
+    code at a small batch, so that every shard is a few tiles of the team kernel; a ragged batch; LLRs and iteration
+    counts gathered too.  Bit-equal to a single-device decode and to the oracle on a sample of every shard.  No N > 1
+    number is taken from this."""
+    import torch
+
+    n = 16384
+    H = ldpc.codes.parity_check_csc(n, 8, 4)
+    B = 8 * 160 + 5
+    per, iters = 0.05, 12
+    syn_h = ldpc.codes.syndromes_of(H, ldpc.codes.random_errors(n, B, per, seed=808))
+    syn = torch.from_numpy(syn_h).cuda()
+    single = ldpc.BeliefPropagationDecoder(H, per, iters, device=0)
+    e0 = torch.empty((B, n), dtype=torch.uint8, device="cuda"); c0 = torch.empty(B, dtype=torch.uint8, device="cuda")
+    i0 = torch.empty(B, dtype=torch.int32, device="cuda"); l0 = torch.empty((B, n), dtype=torch.float64, device="cuda")
+    single.decode_batch_device(syn, e0, c0, l0, i0)
+    single.last_status()
+    single.close()
+    dec = ldpc.BeliefPropagationDecoder(H, per, iters, devices=[0] * 8)
+    mi = dec.multi_info()
+    assert mi.ndev == 8 and mi.exchange == ldpc._capi.EXCHANGE_COPY
+    # root-device form
+    e1 = torch.full((B, n), 9, dtype=torch.uint8, device="cuda"); c1 = torch.full((B,), 9, dtype=torch.uint8, device="cuda")
+    i1 = torch.full((B,), -1, dtype=torch.int32, device="cuda"); l1 = torch.full((B, n), float("nan"), dtype=torch.float64, device="cuda")
+    dec.decode_batch_device(syn, e1, c1, l1, i1)
+    dec.last_status()
+    torch.cuda.synchronize()
+    assert torch.equal(e1, e0) and torch.equal(c1, c0) and torch.equal(i1, i0) and torch.equal(l1.view(torch.int64), l0.view(torch.int64))
+    mi = dec.multi_info()
+    lo7, hi7 = B * 7 // 8, B                                 # the last shard is the largest one of a ragged batch
+    assert mi.scatter_bytes_per_peer == (hi7 - lo7) * H.shape[0] and mi.gather_bytes_per_peer == (hi7 - lo7) * (n + 1 + 4 + 8 * n)
+    # host form: eight host threads, eight pipelines
+    err, conv, llr, its = dec.decode_batch_host(syn_h, want_llr=True, want_iters=True)
+    assert np.array_equal(err, e0.cpu().numpy()) and np.array_equal(conv, c0.cpu().numpy()) and np.array_equal(its, i0.cpu().numpy())
+    assert np.array_equal(llr.view(np.int64), l0.cpu().numpy().view(np.int64))
+    # the oracle on three syndromes of every shard
+    idx = np.concatenate([np.arange(B * g // 8, B * g // 8 + 3) for g in range(8)])
+    oerr, oconv, ollr, oits = _oracle(H, per, iters).batchdecode(syn_h[idx])
+    assert np.array_equal(err[idx], oerr) and np.array_equal(conv[idx], oconv) and np.array_equal(its[idx], oits) and _close_llr(llr[idx], ollr)
+    dec.close()

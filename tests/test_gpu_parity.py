@@ -530,3 +530,71 @@ def test_one_handle_driven_from_two_streams_alternately(ldpc, gpu):
         for k, (half, e, c, i) in enumerate(outs):
             assert torch.equal(e, refs[half][0]) and torch.equal(c, refs[half][1]) and torch.equal(i, refs[half][2]), (n, B, k)
         dec.close()
+
+
+def test_short_division_equals_the_ieee_division_where_the_kernels_take_it(ldpc, gpu):
+    """bp_kernels.hpp div_core (LDPC_FAST_DIV): hipcc's double division without v_div_scale / v_div_fixup, taken by
+    the check sweep for 2 / (1 + m) with 1 <= 1 + m < 2^500 and for (1 - t) / (1 + t) with |t| < 1.  On the device,
+    against `/`, bit for bit: dense random samples of both ranges, their edges (1, the last double below 2^500, t one
+    ulp inside +-1, t tiny), and the exact operand pairs of a decode (powers of two, values an ulp apart)."""
+    import ctypes
+
+    rng = np.random.default_rng(2024)
+    L = ldpc._capi.lib()
+
+    def check(num, den):
+        num = np.ascontiguousarray(num, dtype=np.float64); den = np.ascontiguousarray(den, dtype=np.float64)
+        a = np.empty_like(num); b = np.empty_like(num)
+        ldpc._capi.check(L.ldpc_debug_div_check(num.size, num.ctypes.data, den.ctypes.data, a.ctypes.data, b.ctypes.data), L)
+        assert np.array_equal(b, num / den), "the device's `/` is the IEEE division"
+        bad = np.flatnonzero(a.view(np.int64) != b.view(np.int64))
+        assert bad.size == 0, (num[bad[:4]], den[bad[:4]], a[bad[:4]], b[bad[:4]])
+
+    # :140  2 / (1 + m): m = odds over the whole range a decode meets, log-uniform, and near the edges
+    m = np.concatenate([np.exp(rng.uniform(np.log(1e-300), np.log(1e150), 2_000_000)), rng.uniform(0, 4, 500_000),
+                        [0.0, 5e-324, 1e-320, 2.0 ** -53, 2.0 ** -52, 1.0, 2.0 ** 52, 2.0 ** 499, np.nextafter(2.0 ** 500, 0) - 1.0]])
+    d = 1.0 + m
+    d = d[(d >= 1.0) & (d < 2.0 ** 500)]
+    check(np.full(d.size, 2.0), d)
+    # exponent edges of the denominator: every power of two below 2^500 and its neighbours
+    p2 = 2.0 ** np.arange(0, 500)
+    dd = np.concatenate([p2, np.nextafter(p2, np.inf), np.nextafter(p2[1:], 0)])
+    check(np.full(dd.size, 2.0), dd)
+    # :147  (1 - t) / (1 + t), |t| < 1: uniform, concentrated at +-1 and at 0, and the last doubles inside the range
+    u = rng.uniform(-1, 1, 2_000_000)
+    near1 = 1.0 - np.exp(rng.uniform(np.log(2.0 ** -53), 0, 500_000))
+    tiny = np.exp(rng.uniform(np.log(1e-300), 0, 200_000))
+    t = np.concatenate([u, near1, -near1, tiny, -tiny, [0.0, -0.0, np.nextafter(1.0, 0), -np.nextafter(1.0, 0), 5e-324, 0.5, -0.5]])
+    t = t[np.abs(t) < 1.0]
+    check(1.0 - t, 1.0 + t)
+
+
+def test_llr_precision_is_a_decoder_option_and_the_same_in_every_kernel(ldpc, gpu):
+    """ldpc_bp_options.llr_exact.  Default: every kernel returns log(1 / T~) with the posterior odds cut to their upper
+    32 bits -- the SAME bits from the tile, LDS, node and team kernels, within 5e-7 of the oracle's log(1 / T), +-Inf
+    exact; llr_exact = 1: log(1 / T) itself (<= 1e-9 from the oracle: two libms), again the same bits from every
+    kernel.  Decisions, flags and iteration counts do not depend on it.  A mid-size regular code (rows on chip in the
+    team kernel) at an error rate where lanes stop at different iterations, and a saturating one (per 1e-6: odds that
+    underflow, LLRs of +-Inf)."""
+    H = ldpc.codes.parity_check_csc(4032, 8, 4)
+    for per in (0.04, 1e-6):
+        syn = ldpc.codes.syndromes_of(H, ldpc.codes.random_errors(4032, 700, max(per, 0.01), seed=17))
+        oc = BPOracle(csc=(H.indptr, H.indices), shape=H.shape, per=per, max_iters=30)
+        oerr, oconv, ollr, oits = oc.batchdecode(syn, want_llr=True)
+        fin = np.isfinite(ollr)
+        for exact in (False, True):
+            seen = None
+            for variant, kw in ((1, {}), (3, {}), (4, {}), (0, {})):
+                dec = ldpc.BeliefPropagationDecoder(H, per, 30, kernel_variant=variant, llr_exact=exact, experiments=True, **kw)
+                err, conv, llr, its = dec.decode_batch_host(syn, want_llr=True, want_iters=True)
+                dec.close()
+                assert np.array_equal(err, oerr) and np.array_equal(conv, oconv) and np.array_equal(its, oits)
+                assert np.array_equal(llr[~fin], ollr[~fin])
+                worst = float(np.max(np.abs(llr[fin] - ollr[fin]))) if fin.any() else 0.0
+                assert worst <= (1e-9 if exact else 1e-6), (variant, exact, worst)
+                if seen is None:
+                    seen = llr
+                else:
+                    assert np.array_equal(seen.view(np.int64), llr.view(np.int64)), (variant, exact)
+            if not exact and fin.any():
+                assert float(np.max(np.abs(seen[fin] - ollr[fin]))) > 0.0   # (it IS a cut: not the exact logarithm)

@@ -57,7 +57,9 @@ def _worker(rank, world, port, B, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,B", [(2, 37), (2, 1), (3, 100), (1, 9)])
+# (8, ...): BASELINE config 4's world size -- seven peers' shard buffers, 7 grouped sends in the scatter and 3 x 7 grouped
+# receives in the gather on the root; a batch smaller than the world (empty shards) too
+@pytest.mark.parametrize("world,B", [(2, 37), (2, 1), (3, 100), (1, 9), (8, 203), (8, 5)])
 def test_scatter_decode_gather(tmp_path, world, B):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, B, str(tmp_path)), nprocs=world, join=True)

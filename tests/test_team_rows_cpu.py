@@ -41,7 +41,10 @@ def tables(n, members, wr=8, wc=4, regs=0, quarters=3):
 
 @pytest.mark.parametrize("n,members,wr,wc,regs", [(4096, 8, 8, 4, 0), (16384, 32, 8, 4, 0), (16384, 32, 8, 4, 32), (16384, 28, 8, 4, 32), (1024, 3, 8, 4, 32),
                                                   (32768, 32, 8, 4, 32), (16380, 32, 6, 3, 32), (1008, 5, 6, 3, 0), (16000, 32, 10, 5, 32),
-                                                  (4000, 7, 10, 5, 20)])
+                                                  (4000, 7, 10, 5, 20),
+                                                  # round 4: every regular pair of check degree 6 ... 10 x bit degree 3 ... 5 has an instantiation
+                                                  (16380, 32, 9, 3, 32), (16380, 32, 10, 4, 32), (16380, 32, 7, 4, 32), (16002, 32, 9, 5, 32),
+                                                  (16380, 32, 6, 5, 32), (3990, 6, 7, 3, 12), (16384, 32, 8, 3, 32)])
 def test_row_tables_describe_the_graph(n, members, wr, wc, regs):
     H, R, vtab, ctab, lds_edge, reg_edge, (static_c, static_v, regs_eff) = tables(n, members, wr, wc, regs)
     s, nnz = H.shape[0], H.nnz
@@ -115,7 +118,7 @@ def test_row_tables_describe_the_graph(n, members, wr, wc, regs):
         assert in_regs >= 0.5 * regs_eff * W * members, "most register rows should be in use on a graph of this size"
 
 
-@pytest.mark.parametrize("n,members,wr,wc", [(16384, 32, 8, 4), (16380, 23, 6, 3), (16000, 32, 10, 5)])
+@pytest.mark.parametrize("n,members,wr,wc", [(16384, 32, 8, 4), (16380, 23, 6, 3), (16000, 32, 10, 5), (16380, 32, 9, 3), (16380, 32, 10, 4), (16380, 32, 7, 5)])
 def test_on_chip_rows_are_whole_checks_of_the_first_block(n, members, wr, wc):
     """What the fast paths of the kernel live on (bp_team_kernels.hpp check_update_regs, bit_update_pair_first /
     bit_update_multi_first; ldpc_mi355x.hip team_rows_tables(): a bit goes to the owner of its FIRST check): in a

@@ -10,7 +10,8 @@ import numpy as np
 import scipy.sparse as sp
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("LDPC_TEAM_MIN_ROWS", "1")   # kernel_variant 4: teams of workgroups also on these tiny graphs
+MIN_ROWS_DEFAULT = os.environ.get("LDPC_TEAM_MIN_ROWS", "1")   # kernel_variant 4: teams of workgroups also on these tiny graphs
+os.environ["LDPC_TEAM_MIN_ROWS"] = MIN_ROWS_DEFAULT            # (read at create since round 4: the `big` legs below drop it)
 import ldpcdecoders_jl_amd as ldpc  # noqa: E402
 from oracle import BPOracle, BPOTSOracle  # noqa: E402
 
@@ -41,14 +42,19 @@ while time.time() - t0 < budget and cases < MAXCASES:
     in_range = FROM <= cases <= TO
     skip = DRY or ORACLE_ONLY or not in_range
     kind = rng.integers(0, 5)
-    mid = False
+    mid = big = False
     if kind == 0:      # Gallager regular
         wr, wc = int(rng.choice([4, 6, 8, 10])), int(rng.choice([2, 3, 4, 5]))
         n = wr * int(rng.integers(4, 60))
         H = ldpc.codes.parity_check_csc(n, wr, wc, seed=int(rng.integers(1 << 30)))
     elif kind == 4:    # regular with a rows-on-chip instantiation, large enough for the waves of a small team to own chunks
-        wr, wc = [(6, 3), (8, 4), (10, 5)][int(rng.integers(0, 3))]
-        n = wr * int(rng.integers(150, 500))
+        wr, wc = int(rng.integers(6, 11)), int(rng.integers(3, 6))       # (round 4: every pair of check degree 6 ... 10 x bit degree 3 ... 5)
+        big = rng.random() < 0.12
+        if big:        # >= 35,200 message rows: the plan's own rules apply (no LDPC_TEAM_MIN_ROWS): the one team of an XCD takes all its CUs
+            n = wr * int(rng.integers(36000 // (wr * wc) + 1, 50000 // (wr * wc)))
+            n -= n % (wr * 4)   # (so that n * wc / wr is whole and the Gallager blocks divide)
+        else:
+            n = wr * int(rng.integers(150, 500))
         H = ldpc.codes.parity_check_csc(n, wr, wc, seed=int(rng.integers(1 << 30)))
         mid = True
     else:              # irregular random, with empty and heavy nodes now and then
@@ -71,6 +77,9 @@ while time.time() - t0 < budget and cases < MAXCASES:
     if mid:
         B = int(rng.choice([64, 130, 400, 700]))
         iters = int(rng.choice([3, 7, 20]))
+    if big:
+        B = int(rng.choice([64, 130, 400]))
+        iters = int(rng.choice([3, 7]))
     if rng.random() < 0.5:
         E = (rng.random((B, n)) < min(per * rng.uniform(0.5, 3), 0.5)).astype(np.uint8)
         syn = ldpc.codes.syndromes_of(H, E)
@@ -116,8 +125,12 @@ while time.time() - t0 < budget and cases < MAXCASES:
             os.environ["LDPC_TEAM_REGS"] = str(int(rng.choice([0, 5, 32])))
         if rng.random() < 0.5:
             os.environ["LDPC_TEAM_STATIC"] = str(int(rng.choice([1, 2, 3, 4])))
-        if mid:
+        if mid and not big:
             os.environ["LDPC_TEAM_MAX"] = str(int(rng.choice([3, 4, 6, 8])))
+        if big:
+            os.environ.pop("LDPC_TEAM_MIN_ROWS", None)
+        else:
+            os.environ["LDPC_TEAM_MIN_ROWS"] = MIN_ROWS_DEFAULT
         # teams (read at create): a small cache budget makes them persistent on these small graphs (a team takes tile
         # after tile in its own slot); how a member's waves share its chunks; nodes loaded in pairs or singly
         if rng.random() < 0.6:
