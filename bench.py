@@ -56,6 +56,9 @@ WORKLOADS = {
     "wide_16000_10_5": (16000, 10, 5, 32768, 0.10, 50),
     # a (3,6)-regular code of the C3 size (24 MiB a message slot: eight persistent teams; rows on chip <6,3>)
     "reg36_16380": (16380, 6, 3, 65536, 0.10, 50),
+    # round 4: the other regular pairs of north_star's range keep their rows on chip too: (3,9) and (4,10) at the C3 size
+    "reg39_16380": (16380, 9, 3, 65536, 0.10, 50),
+    "reg410_16380": (16380, 10, 4, 32768, 0.10, 50),
     # BASELINE configs[4]: BB [[72,12,6]] H_X, BP on the GPU + OSD-0 on the host for what BP leaves
     "c5_bb72_bposd": (72, 6, 3, 1048576, 0.005, 50),
 }

@@ -1183,10 +1183,13 @@ struct TeamPlanIn {
     // bytes a team keeps rewriting besides its message slot: with LLRs wanted the posterior odds of every bit of the tile in
     // hand, n x 512 B per iteration (they live in the cache with the slot, and count against the same budget)
     size_t extra = 0;
-    // WIDE teams (round 4; LDPC_TEAM_WIDE = 1, 2, 4: experiments, 0 = off): `wide` persistent teams of (all workgroups) / wide
-    // members each, dealt over ALL XCDs, rows on chip -- for graphs whose slot alone is a large part of the Infinity Cache
-    // (n = 65536: 128 MiB a slot, 96 MiB with a quarter of the rows on chip; two of them fit where eight one-XCD teams'
-    // slots are four times the cache).  Every barrier then writes the XCDs' L2s back (the members share no L2).
+    // WIDE teams (round 4): T < 8 persistent teams of (all workgroups) / T members each, dealt over ALL XCDs, rows on
+    // chip -- for graphs of which eight slots do not fit the Infinity Cache but a few do (n = 65536: 128 MiB a slot, 96 MiB
+    // with a quarter of the rows on chip: two; n = 32768: four).  Every barrier then writes the XCDs' L2s back (the
+    // members share no L2), and still -- 16,384 syndromes x 50 iterations, profiles/r04_wide_teams.txt -- n = 65536: 910 ms
+    // against the tile kernel's 1238 and eight one-XCD teams' 1228 (T = 1: 1112, T = 4: 1133: four slots are 384 MiB);
+    // n = 32768: T = 4 442 ms against eight one-XCD teams' 496 (T = 2: 533).  Without rows on chip: no (n = 65536, T = 2:
+    // 1300 ms).  0 = automatic (team_wide_auto()), -1 = never, T > 0 = forced (LDPC_TEAM_WIDE, experiments).
     int wide = 0;
 };
 
@@ -1527,6 +1530,30 @@ struct TeamPlan {
     bool rows = false;       // members keep the rows that only they touch in LDS (TeamRows)
 };
 
+// How many wide teams (TeamPlanIn::wide) a batch of ntiles gets by itself: as many as keep their slots -- less the rows
+// their members keep on chip, plus a tile's LLR rows when wanted -- inside the cache budget, when that is fewer than the
+// eight one-XCD teams the plan would otherwise build (eight or more fit: nothing to do, the C3 code) and the graph has a
+// rows-on-chip instantiation (without rows on chip wide teams lose).  0 = none.
+static int team_wide_auto(const TeamPlanIn &in, int64_t ntiles)
+{
+    if (!in.cache || in.xcds_forced || in.team_max_set || !in.rows_possible || in.reg_rows <= 0 || in.per_xcd < 8) return 0;
+    const size_t state = std::max<size_t>((size_t)in.nnz, 1) * kTile * sizeof(double);
+    for (int T = 7; T >= 1; --T) {
+        const int G = (int)std::min<int64_t>(kTeamMaxMembers, (int64_t)8 * in.per_xcd / T);
+        if (in.nnz / G < in.scatter_rows) continue;                       // (a member keeps >= 512 message rows per sweep)
+        const size_t on_chip = (size_t)G * (size_t)team_rows_expected(in, G) * kTile * sizeof(double);
+        const size_t slot = state - std::min(on_chip, state) + in.extra;
+        if ((size_t)T * slot > in.cache) continue;
+        // eight one-XCD teams' slots would fit as well, or nearly (a quarter over the budget): that plan (no write-backs at
+        // the barriers) stays
+        const int G8 = std::min(std::max(in.gcap, in.gcap_one), in.per_xcd);
+        const size_t slot8 = state - std::min((size_t)G8 * (size_t)team_rows_expected(in, G8) * kTile * sizeof(double), state) + in.extra;
+        if ((size_t)8 * slot8 <= in.cache + in.cache / 4) return 0;
+        return (int)std::min<int64_t>(T, ntiles);
+    }
+    return 0;
+}
+
 static TeamPlan team_plan_pure(const TeamPlanIn &in, int64_t batch)
 {
     TeamPlan pl;
@@ -1535,9 +1562,10 @@ static TeamPlan team_plan_pure(const TeamPlanIn &in, int64_t batch)
     if (ntiles < 1 || per_xcd < 1) return pl;
     if ((size_t)ntiles * ((size_t)in.max_iters + 32) * sizeof(u64) > ((size_t)64 << 20)) return pl;   // mismatch words per tile and iteration
     int64_t team = 1, nteams = 0;
-    if (in.wide > 0 && ntiles > in.scatter_tiles) {
-        team = std::min<int64_t>(kTeamMaxMembers, (int64_t)8 * per_xcd / in.wide);
-        nteams = std::min<int64_t>(in.wide, ntiles);
+    const int wide = in.wide > 0 ? in.wide : in.wide == 0 ? team_wide_auto(in, ntiles) : 0;
+    if (wide > 0 && ntiles > in.scatter_tiles) {
+        team = std::min<int64_t>(kTeamMaxMembers, (int64_t)8 * per_xcd / wide);
+        nteams = std::min<int64_t>(wide, ntiles);
         pl.scatter = true;
         pl.wide = true;
     } else if (ntiles <= in.scatter_tiles && !in.team_max_set) {
@@ -1584,7 +1612,7 @@ static TeamPlanIn team_plan_in(const ldpc_bp_decoder *d, int per_xcd, int gcap, 
     if (const char *e = exp_env("LDPC_TEAM_SCATTER_MAX")) in.scatter_max = std::max(3, std::min(kTeamMaxMembers, std::atoi(e)));
     if (const char *e = exp_env("LDPC_TEAM_SCATTER_ROWS")) in.scatter_rows = std::max(1, std::atoi(e));
     if (const char *e = exp_env("LDPC_TEAM_SCATTER_TILES")) in.scatter_tiles = std::max(0, std::min(16, std::atoi(e)));
-    if (const char *e = exp_env("LDPC_TEAM_WIDE")) in.wide = std::max(0, std::min(8, std::atoi(e)));
+    if (const char *e = exp_env("LDPC_TEAM_WIDE")) in.wide = std::max(-1, std::min(8, std::atoi(e)));
     return in;
 }
 

@@ -308,7 +308,8 @@ def test_auto_dispatch_picks_the_kernel_by_code_and_batch(ldpc, gpu, monkeypatch
     """kernel_variant 0: LDS-resident kernel for a code that fits the LDS; node-parallel kernel with the messages
     in LDS at every batch size for a code whose messages alone fit it (n = 4096); beyond that the node-parallel
     kernel below one tile, the team kernel from there on -- persistent teams whose message slots stay in the
-    Infinity Cache (or are at most 2.2 x its budget: n = 32768) -- and the tile kernel beyond that (n = 65536)
+    Infinity Cache, as one team per XCD or, for larger graphs, as a few WIDE teams over all XCDs (n = 32768: four,
+    n = 65536: two) -- and the tile kernel beyond n = 131072
     (ldpc_bp_info.last_kernel, numbered like kernel_variant).  Results against the oracle on a sample."""
     small = ldpc.codes.parity_check_csc(1008, 6, 3)
     big = ldpc.codes.parity_check_csc(4096, 8, 4)
@@ -330,18 +331,39 @@ def test_auto_dispatch_picks_the_kernel_by_code_and_batch(ldpc, gpu, monkeypatch
         oerr, oconv, _, oits = oc.batchdecode(syn[:k])
         assert np.array_equal(err[:k], oerr) and np.array_equal(conv[:k], oconv) and np.array_equal(its[:k], oits)
     d_big.close()
-    # n = 32768: eight message slots are 512 MiB, twice the Infinity Cache -- still one persistent team per XCD
-    # (the second tier of the team plan), 19 tiles for 8 teams of 32
+    # n = 32768: eight message slots are 512 MiB, twice the Infinity Cache; with a quarter of the rows on chip FOUR slots
+    # fit it: four WIDE teams of 64 workgroups, each dealt over all XCDs (round 4), 19 tiles for the 4 teams -- and, with
+    # LLRs, hard decisions and LLRs against the oracle (the wide teams' variable sweep captures into the scratch rows)
     huge = ldpc.codes.parity_check_csc(32768, 8, 4)
     d_huge = ldpc.BeliefPropagationDecoder(huge, 0.03, 30)
     syn = ldpc.codes.syndromes_of(huge, ldpc.codes.random_errors(32768, 1200, 0.03, seed=5))
     err, conv, _, its = d_huge.decode_batch_host(syn, want_iters=True)
     info = d_huge.info()
-    assert info.last_kernel == 4 and info.last_team_size == 32 and info.resident_tiles == 8 * 32, (info.last_kernel, info.last_team_size, info.resident_tiles)
+    assert info.last_kernel == 4 and info.last_team_size == 64 and info.resident_tiles == 4 * 64, (info.last_kernel, info.last_team_size, info.resident_tiles)
+    assert info.last_rows_on_chip >= 0.9 * huge.nnz // 4
     oc = BPOracle(csc=(huge.indptr, huge.indices), shape=huge.shape, per=0.03, max_iters=30)
-    oerr, oconv, _, oits = oc.batchdecode(syn[:100])
+    oerr, oconv, ollr, oits = oc.batchdecode(syn[:100])
     assert np.array_equal(err[:100], oerr) and np.array_equal(conv[:100], oconv) and np.array_equal(its[:100], oits)
+    err2, conv2, llr2, its2 = d_huge.decode_batch_host(syn, want_llr=True, want_iters=True)
+    assert np.array_equal(err2, err) and np.array_equal(conv2, conv) and np.array_equal(its2, its)
+    fin = np.isfinite(ollr)
+    assert np.array_equal(llr2[:100][~fin], ollr[~fin]) and np.max(np.abs(llr2[:100][fin] - ollr[fin])) <= 1e-6
     d_huge.close()
+    # n = 65536 (128 MiB a slot): two wide teams of 128, against the tile kernel bit for bit and the oracle on a sample
+    vast = ldpc.codes.parity_check_csc(65536, 8, 4)
+    syn = ldpc.codes.syndromes_of(vast, ldpc.codes.random_errors(65536, 700, 0.03, seed=6))
+    res = {}
+    for variant in (0, 1):
+        d_vast = ldpc.BeliefPropagationDecoder(vast, 0.03, 20, kernel_variant=variant)
+        res[variant] = d_vast.decode_batch_host(syn, want_llr=True, want_iters=True)
+        info = d_vast.info()
+        assert (info.last_kernel, info.last_team_size) == ((4, 128) if variant == 0 else (1, 1)), (variant, info.last_kernel, info.last_team_size)
+        d_vast.close()
+    assert all(np.array_equal(a, b) for a, b in zip(res[0][:2] + res[0][3:], res[1][:2] + res[1][3:]))
+    assert np.array_equal(res[0][2].view(np.int64), res[1][2].view(np.int64))
+    oc = BPOracle(csc=(vast.indptr, vast.indices), shape=vast.shape, per=0.03, max_iters=20)
+    oerr, oconv, _, oits = oc.batchdecode(syn[:40], want_llr=False)
+    assert np.array_equal(res[0][0][:40], oerr) and np.array_equal(res[0][1][:40], oconv) and np.array_equal(res[0][3][:40], oits)
 
 
 def test_device_resident_entry(ldpc, gpu):

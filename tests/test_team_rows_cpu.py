@@ -204,12 +204,23 @@ def test_team_plan_by_graph_and_batch():
     # the (3,6) n = 16380 code (24 MiB slots): eight teams of 32 (1535 rows a member; measured 528 ms for the full batch
     # against 633 ms with eight teams of 23 -- members of >= 2048 rows --, and twelve teams of 16 on six XCDs before that)
     assert plan(49140, 65536, dv=3) == dict(members=32, teams=8, grid=256, xcds=8, scatter=0, rows=1)
-    # 64 MiB slots (n = 32768): twice the cache -- the second tier, one persistent team per XCD
-    assert plan(131072, 65536) == dict(members=32, teams=8, grid=256, xcds=8, scatter=0, rows=1)
-    # 128 MiB slots (n = 65536): the tile kernel for more tiles than CUs, one team per tile below
-    assert plan(262144, 65536)["members"] == 1
-    p = plan(262144, 1024)                                       # 16 tiles: two teams per XCD
+    # 64 MiB slots (n = 32768): eight of them are twice the cache.  With rows on chip (46 MiB a slot) FOUR fit: four WIDE
+    # teams of 64 members each, dealt over all XCDs (round 4: 442 ms for 16,384 syndromes x 50 iterations against 496 ms
+    # for one persistent team per XCD); a graph without rows on chip keeps the second tier, one persistent team per XCD
+    assert plan(131072, 65536) == dict(members=64, teams=4, grid=256, xcds=8, scatter=1, rows=1)
+    assert plan(131072, 65536, regular=0) == dict(members=32, teams=8, grid=256, xcds=8, scatter=0, rows=0)
+    # 128 MiB slots (n = 65536; 96 MiB with a quarter of the rows on chip): TWO wide teams of 128 (910 ms against the
+    # tile kernel's 1238 ms); without rows on chip the tile kernel for more tiles than CUs, one team per tile below
+    assert plan(262144, 65536) == dict(members=128, teams=2, grid=256, xcds=8, scatter=1, rows=1)
+    assert plan(262144, 1024) == dict(members=128, teams=2, grid=256, xcds=8, scatter=1, rows=1)
+    assert plan(262144, 65536, regular=0)["members"] == 1
+    p = plan(262144, 1024, regular=0)                            # 16 tiles: two teams per XCD
     assert p["teams"] == 16 and p["members"] == 16 and p["scatter"] == 0
+    # 256 MiB slots (n = 131072): ONE team of all 256 workgroups; beyond that (n = 262144) the tile kernel again
+    assert plan(524288, 65536) == dict(members=256, teams=1, grid=256, xcds=8, scatter=1, rows=1)
+    assert plan(1048576, 65536)["members"] == 1
+    # slots that miss the budget by less than a quarter keep the one-XCD teams (n = 20480: 8 x 31 MiB)
+    assert plan(81920, 65536)["scatter"] == 0
     # no budget at all (LDPC_TEAM_CACHE_MIB=0): round 1's rule
     assert plan(c3, 65536, cache_mib=0)["members"] == 1
     assert plan(c3, 2048, cache_mib=0) == dict(members=8, teams=32, grid=256, xcds=8, scatter=0, rows=0) or \
