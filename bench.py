@@ -202,6 +202,9 @@ def roofline_object(dec, args, kname, last_kernel, nnz, s_checks, n, batch, achi
     if in_cache:
         ceiling = CACHE_SIDE_CEILING_GBS.get(slots if slots <= 8 else 8, CACHE_SIDE_CEILING_GBS[8])
         fabric = traffic / (sweep_ms * 1e-3) / 1e9 if (traffic and sweep_ms > 0) else None
+        # the honest fraction: real bytes through the fabric against what the fabric's cache side streams -- lead with this one;
+        # `frac` above is BASELINE.json's yardstick (algorithmic bytes against an HBM peak these bytes never reach)
+        obj["frac_of_bound"] = fabric / ceiling if fabric else None
         obj["bound_ceiling"] = {
             "what": f"in-place streaming of {min(slots, 8)} cache-resident regions, one per XCD (tools/mall_probe.hip, profiles/r02_infinity_cache_probe.txt)",
             "peak": ceiling, "unit": "GB/s",

@@ -1042,28 +1042,52 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
         typedef double v2d __attribute__((ext_vector_type(2)));
         const size_t cap_rows = ((size_t)n + 3) & ~(size_t)3;
         const int nch4 = (n + 3) >> 2;
-        for (int c = gw; c < nch4; c += GW) {
-            int bit[4];
+        auto bit_of = [&](int pos) -> int {
+            if (pos >= n) return -1;
+            if constexpr (LROWS) return csc2csr[(size_t)pos * team_vtab_words(DV) + 2 * DV] & 0x7fffffff;
+            else return pos;
+        };
+        constexpr int U = 2;   // chunks per step (4: the <9,5> LLR instantiation spills): their loads (one wide load and four scalar table words each) are in flight together
+        if (tp.llr_raw == 4) {
+            const unsigned int *const src = tp.llr_scratch + (size_t)team * cap_rows * kTile + (size_t)lane * 4;
+            unsigned int *const dst = (unsigned int *)p.llr + (size_t)tile * n * kTile + lane;
+            for (int c0 = gw; c0 < nch4; c0 += U * GW) {
+                v4u v[U];
+                int bit[U][4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int pos = 4 * c + k;
-                if constexpr (LROWS) bit[k] = pos < n ? (csc2csr[(size_t)pos * team_vtab_words(DV) + 2 * DV] & 0x7fffffff) : -1;
-                else bit[k] = pos < n ? pos : -1;
+                for (int u = 0; u < U; ++u) {
+                    const int c = c0 + u * GW;
+                    if (c < nch4) v[u] = *(const v4u *)(src + (size_t)c * kTile * 4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) bit[u][k] = c < nch4 ? bit_of(4 * c + k) : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (bit[u][k] >= 0) __builtin_nontemporal_store(v[u][k], dst + (size_t)bit[u][k] * kTile);
+                }
             }
-            if (tp.llr_raw == 4) {
-                const v4u v = *(const v4u *)(tp.llr_scratch + (size_t)team * cap_rows * kTile + ((size_t)c * kTile + lane) * 4);
-                unsigned int *const dst = (unsigned int *)p.llr + (size_t)tile * n * kTile + lane;
+        } else {
+            const double *const src = (const double *)tp.llr_scratch + (size_t)team * cap_rows * kTile + (size_t)lane * 4;
+            double *const dst = p.llr + (size_t)tile * n * kTile + lane;
+            for (int c0 = gw; c0 < nch4; c0 += U * GW) {
+                v2d va[U], vb[U];
+                int bit[U][4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (bit[k] >= 0) __builtin_nontemporal_store(v[k], dst + (size_t)bit[k] * kTile);
-            } else {
-                const double *const src = (const double *)tp.llr_scratch + (size_t)team * cap_rows * kTile + ((size_t)c * kTile + lane) * 4;
-                const v2d a = *(const v2d *)src, b = *(const v2d *)(src + 2);
-                const double v[4] = {a[0], a[1], b[0], b[1]};
-                double *const dst = p.llr + (size_t)tile * n * kTile + lane;
+                for (int u = 0; u < U; ++u) {
+                    const int c = c0 + u * GW;
+                    if (c < nch4) { va[u] = *(const v2d *)(src + (size_t)c * kTile * 4); vb[u] = *(const v2d *)(src + (size_t)c * kTile * 4 + 2); }
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (bit[k] >= 0) __builtin_nontemporal_store(v[k], dst + (size_t)bit[k] * kTile);
+                    for (int k = 0; k < 4; ++k) bit[u][k] = c < nch4 ? bit_of(4 * c + k) : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const double v[4] = {va[u][0], va[u][1], vb[u][0], vb[u][1]};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (bit[u][k] >= 0) __builtin_nontemporal_store(v[k], dst + (size_t)bit[u][k] * kTile);
+                }
             }
         }
     }
