@@ -94,7 +94,7 @@ typedef struct ldpc_bp_options {
                                  32 bits (20 fraction bits) -- the same bits whatever kernel finishes a syndrome, within
                                  5e-7 of the reference's log(1 / T) (BASELINE.json asks for 1e-5); +-Inf come out exactly.
                                  The team kernel of large codes then captures 4 bytes per bit and iteration instead of 8
-                                 (LLRs at C3 size: +10 % kernel time instead of +20 %).  1: log(1 / T) of T itself, as
+                                 (LLRs at the C3 size: +5 % kernel time at 50 iterations instead of +19 %).  1: log(1 / T) of T itself, as
                                  before ABI version 4 -- what the BP+OSD hosts ask for, because OSD orders the bits by
                                  reliability (belief_propagation_osd.jl:53-55) and two reliabilities that differ in the
                                  21st bit must not become a tie.  Hard decisions, flags and iteration counts do not

@@ -149,37 +149,10 @@ struct BPParams {
     int llr_exact;              // LLRs from the full posterior odds (llr_of)
 };
 
-// LLRs in 32 bits (the team kernel's capture, TeamParams::llr_raw = 3).  The reference's log_probabs[j] = log(1 / T)
-// (:163) is wanted to 1e-5 (BASELINE.json north_star); the posterior odds T with a 20-bit significand give it to 1e-6.
-// Code = [sign 1][exponent 12][significand 19]: T = (-1)^sign x m x 2^(exponent - 1100), m in [0.5, 1) truncated to its 19
-// leading fraction bits (the decoder puts the middle of the truncation interval back); +-0 and +-infinity have codes of
-// their own and come back exactly (LLR = +-Inf must match the reference's exactly); denormal T is covered (frexp).
-// T is never NaN (:158-160 resets it to 1).
-__device__ __forceinline__ unsigned int llr_pack(double T)
-{
-    const unsigned int sign = (unsigned int)__double2hiint(T) & 0x80000000u;
-    const double a = __builtin_fabs(T);
-    const int e = __builtin_amdgcn_frexp_exp(a);            // a = m * 2^e, m in [0.5, 1)
-    const double m = __builtin_amdgcn_frexp_mant(a);
-    unsigned int code = ((unsigned int)(e + 1100) << 19) | (((unsigned int)__double2hiint(m) >> 1) & 0x7FFFFu);
-    code = (a == 0.0) ? 0u : code;
-    code = (a == __builtin_huge_val()) ? 0x7FFFFFFFu : code;
-    return sign | code;
-}
-__device__ __forceinline__ double llr_unpack(unsigned int code)
-{
-    const unsigned int mag = code & 0x7FFFFFFFu;
-    // m: exponent field of [0.5, 1), the 19 fraction bits, and a 1 below them (the middle of what was cut off)
-    const double m = __hiloint2double((int)(0x3FE00000u | ((mag & 0x7FFFFu) << 1) | 1u), 0);
-    double T = __builtin_ldexp(m, (int)(mag >> 19) - 1100);
-    T = (mag == 0u) ? 0.0 : T;
-    T = (mag == 0x7FFFFFFFu) ? __builtin_huge_val() : T;
-    return (code & 0x80000000u) ? -T : T;
-}
-
-// ... and the cheapest code of all (TeamParams::llr_raw = 4): the UPPER 32 BITS of T -- sign, exponent, the 20 leading
-// fraction bits -- cost nothing to make (they are a register of T already); the decoder puts the middle of what was
-// cut off back (2^-21 relative: the LLR good to 5e-7), except under an all-ones exponent (+-infinity stays itself).
+// LLRs from 32 bits.  The reference's log_probabs[j] = log(1 / T) (:163) is wanted to 1e-5 (BASELINE.json north_star).
+// The UPPER 32 BITS of the posterior odds T -- sign, exponent, the 20 leading fraction bits -- cost nothing to make (they
+// are a register of T already) and halve what the team kernel has to write per bit and iteration (TeamParams::llr_raw =
+// 4); the decoder puts the middle of what was cut off back (2^-21 relative: the LLR good to 5e-7), except under an all-ones exponent (+-infinity stays itself).
 // T = +-0 comes back as a denormal whose reciprocal overflows, so log(1 / T) = +-Inf exactly as for 0; and every T
 // below 2^-1024 -- where the reference's own 1 / T overflows to Inf -- still decodes below 2^-1024.
 __device__ __forceinline__ unsigned int llr_hi32(double T) { return (unsigned int)__double2hiint(T); }
@@ -932,12 +905,13 @@ __global__ void __launch_bounds__(64) unpack_errors_kernel(const u64 *errmask, l
     }
 }
 
-// llr transpose: llr_t[tile][n][64] -> llr[batch][n]; 64x64 tile through LDS.  raw != 0: llr_t holds the posterior odds T
-// (the team kernel's fresh pass, TeamParams::llr_raw; 3: as 32-bit codes, llr_pack) and log(1 / T) (:163) is taken
-// here, once per syndrome and bit
+// llr transpose: llr_t[tile][n][64] -> llr[batch][n]; 64x64 tile through LDS.  raw = 4 / 5: llr_t holds the posterior odds T
+// as the team kernel's fresh pass left them (TeamParams::llr_raw: upper 32 bits / all of T, position-chunk layout) and
+// log(1 / T) (:163) is taken here, once per syndrome and bit
 __global__ void __launch_bounds__(256) unpack_llr_kernel(const double *llr_t, long long batch, int n,
                                                          double *llr, const int *index,
-                                                         const unsigned int *count_dev, unsigned int count_skip, int raw, int exact)
+                                                         const unsigned int *count_dev, unsigned int count_skip, int raw, int exact,
+                                                         const int *posmap)
 {
     __shared__ double t[64][65];
     if (count_dev) { batch = (long long)*count_dev; if (batch <= (long long)count_skip) return; }   // uniform
@@ -949,15 +923,24 @@ __global__ void __launch_bounds__(256) unpack_llr_kernel(const double *llr_t, lo
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int jj = ty; jj < 64; jj += 4)
         if (j0 + jj < n) {
-            const size_t at = ((size_t)tile * n + j0 + jj) * kTile + tx;
-            t[jj][tx] = raw == 4 ? llr_from_hi32(((const unsigned int *)llr_t)[at]) : raw == 3 ? llr_unpack(((const unsigned int *)llr_t)[at]) : llr_t[at];
+            if (raw == 4 || raw == 5) {
+                // the team kernel's scratch layout (bp_team_kernels.hpp): element (position, lane) of a tile at
+                // ((position / 4) * 64 + lane) * 4 + position % 4, rows rounded up to a multiple of 4; posmap = the
+                // position of every bit in the dealt order (nullptr: the bit itself)
+                const int pos = posmap ? posmap[j0 + jj] : j0 + jj;
+                const size_t at = (size_t)tile * (((size_t)n + 3) & ~(size_t)3) * kTile + ((size_t)(pos >> 2) * kTile + tx) * 4 + (size_t)(pos & 3);
+                t[jj][tx] = raw == 4 ? llr_from_hi32(((const unsigned int *)llr_t)[at]) : llr_t[at];
+            } else {
+                const size_t at = ((size_t)tile * n + j0 + jj) * kTile + tx;
+                t[jj][tx] = llr_t[at];
+            }
         }
     __syncthreads();
     for (int rr = ty; rr < rows; rr += 4)
         if (j0 + tx < n) {
             const long long b = index ? (long long)index[b0 + rr] : b0 + rr;
             const double v = t[tx][rr];
-            llr[(size_t)b * n + j0 + tx] = !raw ? v : (raw == 3 || raw == 4) ? log(1.0 / v) : llr_of(v, exact);   // (raw 3 / 4: v is the cut T already)
+            llr[(size_t)b * n + j0 + tx] = !raw ? v : raw == 4 ? log(1.0 / v) : llr_of(v, exact);   // (raw 4: v is the cut T already)
         }
 }
 

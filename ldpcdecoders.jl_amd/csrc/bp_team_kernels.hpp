@@ -226,19 +226,18 @@ struct TeamParams {
     u64 *errmask_alt;           // [ntiles][n] or nullptr (no running ahead: passes over packed levels)
     int ahead_min;              // active lanes from which on a quiet tile's team runs ahead (0 = never)
     int ahead_from;             // ... and the first iteration whose test may have company (1; 2: a verdict must have been quiet first)
-    // LLRs (WANT_LLR instantiations, fresh tiles): what the variable sweep leaves in p.llr for every active lane and bit in
-    // every iteration -- 0: log(1 / T) (:163), as the other kernels do; 1: the posterior odds T themselves, the logarithm
-    // is taken once per syndrome and bit by unpack_llr_kernel (same OCML log on the same operand: the same bits) instead
-    // of once per iteration; 2: as 1 with non-temporal stores; 3: T as a 32-bit code (llr_pack: 20-bit significand, the
-    // LLR good to 1e-6, +-Inf exact), half the bytes per iteration; 4 (the default): the upper 32 bits of T (llr_hi32)
-    // (5, decoders created with llr_exact: T itself, 8 bytes)
-    // into the TEAM's own scratch rows llr_scratch[team][bit][64] -- lanes that have stopped keep what they stopped
-    // with, a tile's rows are copied out to p.llr once, when the team is through with it.  (1 ... 3 write p.llr's rows of
-    // the tile in every iteration: rows that are new to the cache for every tile, so that at ~3 iterations a tile they
-    // cost DRAM writes for every iteration's capture -- per 0.02: +16 % kernel time with 32-bit codes, +20 % with T;
-    // the scratch rows are the same eight regions for the whole launch and stay in the Infinity Cache with the slots)
+    // LLRs (WANT_LLR instantiations).  0: log(1 / T) (:163, llr_of) per bit into p.llr[tile][bit][64], as the tile kernel
+    // does (the passes over the packed levels).  4 (fresh tiles, the default) / 5 (decoders created with llr_exact): the
+    // posterior odds T themselves -- their upper 32 bits (llr_hi32) / all 64 -- for every lane that is still active,
+    // in every iteration, into p.llr's rows of the tile in POSITION-CHUNK layout: element (position, lane) at
+    // ((position / 4) * 64 + lane) * 4 + position % 4, so that the four positions of a chunk are ONE 16-byte (32-byte)
+    // store per lane; unpack_llr_kernel applies the position -> bit map of the dealt order, cuts / takes the logarithm
+    // once per syndrome and bit, and transposes.  A lane that has stopped keeps what it stopped with.
+    // (What this replaced, C3 full-50 / per 0.02 kernel time against 715 / 50 ms without LLRs -- DESIGN.md "LLRs": log(1 / T)
+    // per bit and iteration 1000 / 64 ms; T as f64 per bit 862 / 61; 32-bit codes per bit 783 / 59; the teams' own scratch
+    // rows + a copy-out per tile 745 / 57; this 752 / 55.)  6: experiments, no capture at all (LLRs undefined: what the
+    // instantiation costs by itself -- nothing).
     int llr_raw;
-    unsigned int *llr_scratch;  // [nteams][n][64] u32 (llr_raw = 4) / f64 (llr_raw = 5)
 };
 constexpr unsigned int kTeamRollcallFailed = 0x80000000u;
 
@@ -759,15 +758,13 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     auto var_sweep = [&]() {
         const int vb = (one_xcd || LROWS) ? 4 : 16;     // (LROWS: the host dealt the bits in chunks of 4)
         const int nch = (n + vb - 1) / vb;
-        // LLR capture into the team's scratch rows (tp.llr_raw >= 4).  Element (position, lane) sits at
-        // ((position / 4) * 64 + lane) * 4 + position % 4: the four positions of a chunk are ONE 16-byte store per lane
-        // (32 bytes with llr_exact) -- a store instruction costs the address path the same whatever its width, and a
-        // 4-byte store per bit made the variable sweep 12 % longer.  Position = place in the dealt bit order (LROWS), else
-        // the bit.  Only lanes that are still active store: a stopped lane keeps what it stopped with.
-        const bool cap_on = WANT_LLR && tp.llr_raw >= 4 && ((active >> lane) & 1ull);
+        // LLR capture (tp.llr_raw 4 / 5, TeamParams): a store instruction costs the address path the same whatever its
+        // width -- a 4-byte store per bit made the variable sweep 12 % longer, one 16-byte store per chunk of four
+        // positions 3 %.  Position = place in the dealt bit order (LROWS), else the bit.
+        const bool cap_on = WANT_LLR && (tp.llr_raw == 4 || tp.llr_raw == 5) && ((active >> lane) & 1ull);
         const size_t cap_rows = ((size_t)n + 3) & ~(size_t)3;
-        unsigned int *const cap32 = tp.llr_scratch + (size_t)team * cap_rows * kTile;
-        double *const cap64 = (double *)tp.llr_scratch + (size_t)team * cap_rows * kTile;
+        unsigned int *const cap32 = (unsigned int *)p.llr + (size_t)tile * cap_rows * kTile;
+        double *const cap64 = p.llr + (size_t)tile * cap_rows * kTile;
         auto cap_at = [&](int pos) { return ((size_t)(pos >> 2) * kTile + lane) * 4 + (size_t)(pos & 3); };
         auto capture1 = [&](int pos, double T) {
             if (!cap_on) return;
@@ -792,13 +789,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
             const u64 dec = __ballot(T >= 1.0);                                // :164-168
             if (WANT_LLR) {
                 if (tp.llr_raw >= 4) { if (cap) capture1(pos, T); }
-                else if ((active >> lane) & 1ull) {
-                    double *const dst = p.llr + ((size_t)tile * n + j) * kTile + lane;
-                    if (tp.llr_raw == 3) ((unsigned int *)p.llr)[((size_t)tile * n + j) * kTile + lane] = llr_pack(T);   // (32-bit codes: half the bytes)
-                    else if (tp.llr_raw == 0) *dst = llr_of(T, p.llr_exact);  // :163
-                    else if (tp.llr_raw == 1) *dst = T;        // (the logarithm: unpack_llr_kernel)
-                    else __builtin_nontemporal_store(T, dst);
-                }
+                else if (tp.llr_raw == 0 && ((active >> lane) & 1ull)) p.llr[((size_t)tile * n + j) * kTile + lane] = llr_of(T, p.llr_exact);  // :163
             }
             if (lane == 0) em[j] = dec;   // every lane; the stopped ones' decisions were captured when they stopped
         };
@@ -1032,65 +1023,6 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
         }
     }
     horizon = it;
-    if (WANT_LLR && tp.llr_raw >= 4) {
-        // The tile's LLR rows leave the team's scratch for p.llr's rows of the tile -- every lane of every row (the lanes
-        // handed to the next level get theirs from the pass that finishes them, which writes after this one), one chunk of
-        // four positions per wave step: one wide load per lane, four row stores, the position -> bit map of the dealt
-        // order applied on the way.  Every capture is behind a team barrier by now; nobody writes the scratch again
-        // before the two barriers of the tile change below.
-        typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-        typedef double v2d __attribute__((ext_vector_type(2)));
-        const size_t cap_rows = ((size_t)n + 3) & ~(size_t)3;
-        const int nch4 = (n + 3) >> 2;
-        auto bit_of = [&](int pos) -> int {
-            if (pos >= n) return -1;
-            if constexpr (LROWS) return csc2csr[(size_t)pos * team_vtab_words(DV) + 2 * DV] & 0x7fffffff;
-            else return pos;
-        };
-        constexpr int U = 2;   // chunks per step (4: the <9,5> LLR instantiation spills): their loads (one wide load and four scalar table words each) are in flight together
-        if (tp.llr_raw == 4) {
-            const unsigned int *const src = tp.llr_scratch + (size_t)team * cap_rows * kTile + (size_t)lane * 4;
-            unsigned int *const dst = (unsigned int *)p.llr + (size_t)tile * n * kTile + lane;
-            for (int c0 = gw; c0 < nch4; c0 += U * GW) {
-                v4u v[U];
-                int bit[U][4];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int c = c0 + u * GW;
-                    if (c < nch4) v[u] = *(const v4u *)(src + (size_t)c * kTile * 4);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) bit[u][k] = c < nch4 ? bit_of(4 * c + k) : -1;
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (bit[u][k] >= 0) __builtin_nontemporal_store(v[u][k], dst + (size_t)bit[u][k] * kTile);
-                }
-            }
-        } else {
-            const double *const src = (const double *)tp.llr_scratch + (size_t)team * cap_rows * kTile + (size_t)lane * 4;
-            double *const dst = p.llr + (size_t)tile * n * kTile + lane;
-            for (int c0 = gw; c0 < nch4; c0 += U * GW) {
-                v2d va[U], vb[U];
-                int bit[U][4];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int c = c0 + u * GW;
-                    if (c < nch4) { va[u] = *(const v2d *)(src + (size_t)c * kTile * 4); vb[u] = *(const v2d *)(src + (size_t)c * kTile * 4 + 2); }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) bit[u][k] = c < nch4 ? bit_of(4 * c + k) : -1;
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const double v[4] = {va[u][0], va[u][1], vb[u][0], vb[u][1]};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (bit[u][k] >= 0) __builtin_nontemporal_store(v[k], dst + (size_t)bit[u][k] * kTile);
-                }
-            }
-        }
-    }
     if (rank == 0 && w == 0) {
         if (((valid & ~deferred) >> lane) & 1ull) {
             const long long ob = resumed ? (long long)cd->index[b0 + lane] : b0 + lane;

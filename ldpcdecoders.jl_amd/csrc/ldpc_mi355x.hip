@@ -485,7 +485,7 @@ struct ldpc_bp_decoder {
     int rows_dc = 0, rows_dv = 0;     // the graph's (check, bit) degree when it is regular and has a rows-in-LDS instantiation
     int rows_G = 0, rows_R = 0;       // what the tables below were built for: members per team, LDS rows per member
     int rows_regs = 0, rows_static_c = 0, rows_static_v = 0;   // ... register rows per wave, chunks per sweep that waves own by right
-    DevBuf rows_ctab, rows_vtab, rows_lds_edge, rows_reg_edge;
+    DevBuf rows_ctab, rows_vtab, rows_lds_edge, rows_reg_edge, rows_posmap;   // (posmap [n]: position of every bit in the dealt order, for unpack_llr_kernel)
     int team_regs = kTeamRegRows;     // LDPC_TEAM_REGS: rows a wave may keep in its top registers (0 = none)
     int team_flip = 3;                // LDPC_TEAM_FLIP: bit 0 / 1: upper half of the waves walks its check / position chunks by right backwards (TeamRows::flip)
     int team_static_quarters = 3;     // LDPC_TEAM_STATIC: quarters of a member's chunks per sweep that its waves own by right (0: only each wave's first)
@@ -505,7 +505,6 @@ struct ldpc_bp_decoder {
     int team_pairs = 3;       // LDPC_TEAM_PAIRS: bit 0: two nodes of the full degree are loaded together; bit 1: the four bits of a position chunk (rows-on-chip kernels)
     int team_ahead_from = 1;  // LDPC_TEAM_AHEAD_FROM: first iteration whose test may ride with the next check sweep (1: realistic -1.6 %, waterfall -0.7 % against 2, profiles/r03_ahead_from1.txt)
     bool team_ahead_set = false;   // LDPC_TEAM_AHEAD given (else: 1 for a single round of teams over all XCDs)
-    DevBuf team_llr;          // [teams][n][64] u32 / f64: the teams' LLR scratch rows (TeamParams::llr_scratch)
     bool llr_exact = false;   // ldpc_bp_options.llr_exact: LLRs from the full posterior odds (bp_kernels.hpp llr_of)
     int team_llr_raw = 4;     // LDPC_TEAM_LLR_RAW (4 becomes 5 with llr_exact): what the team kernel's variable sweep stores per bit when LLRs are wanted (TeamParams::llr_raw)
     bool team_llr_footprint = true;   // LDPC_TEAM_LLR_FOOTPRINT: the plan counts a tile's LLR rows (n x 512 B, rewritten in every iteration) as part of its slot
@@ -572,8 +571,8 @@ struct ldpc_bp_decoder {
         const bool stalled = ldpc_detail::device_stalled(device);   // (then nothing is freed: host_wait.hpp)
         const bool idle = device_idle && !stalled;
         DevBuf *all[] = {&row_ptr, &edge_bit, &col_ptr, &csc2csr, &msg, &ctrl, &synmask, &nevermask,
-                         &errmask, &finmask, &llr_t, &st_all, &node_msg, &done_ctr, &team_ws, &team_ws_lvl[0], &team_ws_lvl[1], &cold, &team_llr,
-                         &rows_ctab, &rows_vtab, &rows_lds_edge, &rows_reg_edge};
+                         &errmask, &finmask, &llr_t, &st_all, &node_msg, &done_ctr, &team_ws, &team_ws_lvl[0], &team_ws_lvl[1], &cold,
+                         &rows_ctab, &rows_vtab, &rows_lds_edge, &rows_reg_edge, &rows_posmap};
         for (DevBuf *b : all) b->release(idle);
         for (int l = 0; l < 2; ++l)
             for (DevBuf *b : {&lvl_state[l], &lvl_list[l], &lvl_it[l], &lvl_syn[l], &lvl_never[l], &lvl_err[l], &lvl_fin[l], &lvl_llr[l]}) b->release(idle);
@@ -924,8 +923,8 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     if (const char *e = exp_env("LDPC_TEAM_PAIRS")) d->team_pairs = std::atoi(e) & 3;   // (bit 1: four bits at once in the variable sweep)
     if (const char *e = exp_env("LDPC_TEAM_AHEAD")) { d->team_ahead = std::max(0, std::min(65, std::atoi(e))); d->team_ahead_set = true; }
     if (const char *e = exp_env("LDPC_TEAM_AHEAD_FROM")) d->team_ahead_from = std::max(1, std::atoi(e));
-    if (const char *e = exp_env("LDPC_TEAM_LLR_RAW")) d->team_llr_raw = std::max(0, std::min(5, std::atoi(e)));
-    if (d->llr_exact && (d->team_llr_raw == 4 || d->team_llr_raw == 3)) d->team_llr_raw = d->team_llr_raw == 4 ? 5 : 1;   // (exact LLRs need all of T)
+    if (const char *e = exp_env("LDPC_TEAM_LLR_RAW")) { const int v = std::atoi(e); if (v == 0 || v == 4 || v == 5 || v == 6) d->team_llr_raw = v; }   // (6: a timing probe, LLRs undefined)
+    if (d->llr_exact && d->team_llr_raw == 4) d->team_llr_raw = 5;   // (exact LLRs need all of T)
     if (const char *e = exp_env("LDPC_TEAM_LLR_FOOTPRINT")) d->team_llr_footprint = std::atoi(e) != 0;
     if (const char *e = exp_env("LDPC_TEAM_REGS")) d->team_regs = std::max(0, std::min(kTeamRegRows, std::atoi(e)));
     if (const char *e = exp_env("LDPC_TEAM_FLIP")) d->team_flip = std::atoi(e) & 3;
@@ -1040,8 +1039,8 @@ ldpc_status ldpc_bp_get_info(const ldpc_bp_decoder *d, ldpc_bp_info *info)
                            &d->nevermask, &d->errmask, &d->finmask, &d->llr_t, &d->st_all, &d->node_msg, &d->pipe_dev[0], &d->pipe_dev[1], &d->pipe_dev[2],
                            &d->lvl_state[0], &d->lvl_state[1], &d->lvl_list[0], &d->lvl_list[1], &d->lvl_it[0], &d->lvl_it[1],
                            &d->lvl_syn[0], &d->lvl_syn[1], &d->lvl_never[0], &d->lvl_never[1], &d->lvl_err[0], &d->lvl_err[1], &d->lvl_fin[0], &d->lvl_fin[1],
-                           &d->lvl_llr[0], &d->lvl_llr[1], &d->team_ws, &d->team_ws_lvl[0], &d->team_ws_lvl[1], &d->team_llr,
-                           &d->rows_ctab, &d->rows_vtab, &d->rows_lds_edge, &d->rows_reg_edge};
+                           &d->lvl_llr[0], &d->lvl_llr[1], &d->team_ws, &d->team_ws_lvl[0], &d->team_ws_lvl[1],
+                           &d->rows_ctab, &d->rows_vtab, &d->rows_lds_edge, &d->rows_reg_edge, &d->rows_posmap};
     for (const DevBuf *b : all) info->workspace_bytes += (int64_t)b->cap;
     info->last_kernel = d->last_kernel;
     info->last_team_size = d->last_team;
@@ -1455,6 +1454,9 @@ static ldpc_status team_rows_build(ldpc_bp_decoder *d, int G)
     };
     ldpc_status st;
     if ((st = ldpc_detail::wait_device(d->device, "team row tables (device synchronise before the tables are replaced)")) != LDPC_OK) return st;   // (a launch that still reads the tables of another G)
+    std::vector<int> posmap((size_t)d->n, 0);
+    for (int p = 0; p < (int)d->n; ++p) posmap[(size_t)(t.vtab[(size_t)p * t.vt + 2 * d->rows_dv] & 0x7fffffff)] = p;
+    if ((st = up(d->rows_posmap, posmap)) != LDPC_OK) return st;
     if ((st = up(d->rows_ctab, t.ctab)) != LDPC_OK || (st = up(d->rows_vtab, t.vtab)) != LDPC_OK ||
         (st = up(d->rows_lds_edge, t.lds_edge)) != LDPC_OK || (st = up(d->rows_reg_edge, t.reg_edge)) != LDPC_OK)
         return st;
@@ -1604,7 +1606,7 @@ static TeamPlan team_plan_pure(const TeamPlanIn &in, int64_t batch)
 static TeamPlanIn team_plan_in(const ldpc_bp_decoder *d, int per_xcd, int gcap, int gcap_one = 0, bool want_llr = false)
 {
     TeamPlanIn in;
-    in.extra = (want_llr && d->team_llr_footprint) ? (size_t)std::max<int64_t>(d->n, 0) * kTile * ((d->team_llr_raw == 3 || d->team_llr_raw == 4) ? sizeof(unsigned int) : sizeof(double)) : 0;
+    in.extra = (want_llr && d->team_llr_footprint) ? (size_t)std::max<int64_t>(d->n, 0) * kTile * (d->team_llr_raw == 5 ? sizeof(double) : sizeof(unsigned int)) : 0;
     in.nnz = d->nnz; in.max_iters = d->max_iters; in.cache = d->team_cache; in.xcds_forced = d->team_xcds;
     in.team_max_set = d->team_max_set; in.rows_possible = team_rows_possible(d); in.rows_dv = std::max(d->rows_dv, 1); in.num_cus = d->num_cus;
     in.reg_rows = in.rows_possible ? d->team_regs * (LDPC_TEAM_THREADS / 64) : 0;
@@ -1869,7 +1871,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     // (two sets of decision words: a team that runs ahead -- bp_team_kernels.hpp -- writes those of odd iterations into the second)
     if ((st = d->errmask.ensure(2 * std::max<size_t>((size_t)ntiles * n, 1) * sizeof(u64))) != LDPC_OK) return st;
     if ((st = d->finmask.ensure(std::max<size_t>((size_t)ntiles * n, 1) * sizeof(u64))) != LDPC_OK) return st;
-    if (want_llr && (st = d->llr_t.ensure(std::max<size_t>((size_t)ntiles * n, 1) * kTile * sizeof(double))) != LDPC_OK)
+    if (want_llr && (st = d->llr_t.ensure(std::max<size_t>((size_t)ntiles * (((size_t)n + 3) & ~(size_t)3), 1) * kTile * sizeof(double))) != LDPC_OK)
         return st;
     // Geometry of this launch: 8 waves per tile (three workgroups per CU) is the measured best
     // whenever there are more tiles than CUs -- also against geometries that make every tile
@@ -2078,11 +2080,11 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         tp.ahead_min = 0;
         tp.ahead_from = 2;
         tp.llr_raw = 0;
-        tp.llr_scratch = nullptr;
         return LDPC_OK;
     };
     bool team_ran = team > 1;
     int llr_raw_out = 0;   // the fresh pass left posterior odds, not logarithms, in llr_t (TeamParams::llr_raw)
+    const int *llr_posmap = nullptr;   // ... in the dealt bit order of the rows-on-chip tables: position of every bit
     HIP_TRY(hipEventRecord(ev[1], stream));
     if (team > 1) {
         TeamParams tp{};
@@ -2095,12 +2097,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         tp.ahead_min = d->team_ahead;
         tp.ahead_from = d->team_ahead_from;
         tp.llr_raw = want_llr ? d->team_llr_raw : 0;
-        tp.llr_scratch = nullptr;
-        if (tp.llr_raw >= 4) {
-            if ((st = d->team_llr.ensure(std::max<size_t>((size_t)plan.nteams * (((size_t)n + 3) & ~(size_t)3), 1) * kTile * (tp.llr_raw == 4 ? sizeof(unsigned int) : sizeof(double)))) != LDPC_OK) return st;
-            tp.llr_scratch = (unsigned int *)d->team_llr.p;
-        }
-        llr_raw_out = tp.llr_raw;
+        llr_raw_out = tp.llr_raw == 6 ? 4 : tp.llr_raw;
         // one round of teams over all XCDs (<= 3 tiles: a single decode!): no other tile waits for this team, so a sweep
         // ahead that turns out to be for nothing costs one sweep at the end, and the barrier saved in every iteration
         // is worth it whatever the number of active lanes (one syndrome, 50 iterations: 2.62 -> 2.31 ms)
@@ -2123,6 +2120,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
                 tp.rows.static_c = d->rows_static_c; tp.rows.static_v = d->rows_static_v; tp.rows.flip = d->team_flip;
                 t_col = (const int *)d->rows_ctab.p;     // (this instantiation reads its tables through these two arguments)
                 t_c2r = (const int *)d->rows_vtab.p;
+                llr_posmap = (const int *)d->rows_posmap.p;
             }
         }
         const u64 *a_syn = (const u64 *)d->synmask.p, *a_nev = (const u64 *)d->nevermask.p;
@@ -2140,6 +2138,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             kfn = pick_kernel(d->max_cdeg, d->max_bdeg, want_llr, threads);
             team_ran = false;
             llr_raw_out = 0;
+            llr_posmap = nullptr;
         }
         if (team_ran && exp_env("LDPC_TEAM_DEBUG")) {   // diagnostics: which XCDs did the teams land on?
             const int nt = std::min(plan.nteams, ntiles);
@@ -2227,7 +2226,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         HIP_TRY(hipGetLastError());
         if (want_llr) {
             hipLaunchKernelGGL(unpack_llr_kernel, g, dim3(256), 0, stream, (const double *)d->llr_t.p,
-                               (long long)batch, (int)n, d_llr, (const int *)nullptr, (const unsigned int *)nullptr, 0u, llr_raw_out, d->llr_exact ? 1 : 0);
+                               (long long)batch, (int)n, d_llr, (const int *)nullptr, (const unsigned int *)nullptr, 0u, llr_raw_out, d->llr_exact ? 1 : 0, llr_posmap);
             HIP_TRY(hipGetLastError());
         }
         for (int l = 1; l <= nlevels; ++l) {
@@ -2239,7 +2238,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             if (want_llr) {
                 hipLaunchKernelGGL(unpack_llr_kernel, g2, dim3(256), 0, stream, (const double *)d->lvl_llr[l - 1].p,
                                    (long long)0, (int)n, d_llr, (const int *)d->lvl_list[l - 1].p,
-                                   (const unsigned int *)lv[l].count, lv[l].node_take, 0, 0);
+                                   (const unsigned int *)lv[l].count, lv[l].node_take, 0, 0, (const int *)nullptr);
                 HIP_TRY(hipGetLastError());
             }
         }

@@ -200,8 +200,8 @@ def test_other_regular_codes_keep_rows_in_lds_full_batch(ldpc, gpu, n, wr, wc, b
 def test_c3_full_batch_with_llrs(ldpc, gpu, per, exact):
     """The LLR-producing instantiation at the C3 size (the reference's decode! always fills scratch.log_probabs,
     belief_propagation.jl:163; BP+OSD reads them): the whole batch through the default path -- persistent teams that
-    capture the posterior odds of every active lane in every iteration in their own scratch rows (their upper 32 bits;
-    all 64 with llr_exact) and copy a tile's rows out once.  Hard decisions, flags and iteration counts must be what the
+    capture the posterior odds of every active lane in every iteration (their upper 32 bits; all 64 with llr_exact),
+    four positions of the dealt bit order per store, unpacked through the position map.  Hard decisions, flags and iteration counts must be what the
     call without LLRs gives, bit for bit; the LLRs must be the tile kernel's bit for bit on a slice of the batch (every
     kernel cuts the odds the same way), and the oracle's to 1e-5 (default) / 1e-9 (exact) with +-Inf exact on a sample --
     per 0.10: every lane stops at iteration 50; 0.02: lanes stop at different iterations, tiles hand stragglers on;
