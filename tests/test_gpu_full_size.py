@@ -224,7 +224,7 @@ def test_c3_full_batch_with_llrs(ldpc, gpu, per, exact):
     # the sign of an LLR is the hard decision (T >= 1 <=> log(1 / T) <= 0), on the whole batch
     for b0 in range(0, B, 8192):
         assert bool(((llr[b0:b0 + 8192] <= 0) == (err[b0:b0 + 8192] == 1)).all())
-    # the tile kernel (no teams, no scratch rows) on a slice from the middle of the batch: the same bits
+    # the tile kernel (no teams, bit-major LLR rows) on a slice from the middle of the batch: the same bits
     sl = slice(30000, 30000 + 2048)
     tile = ldpc.BeliefPropagationDecoder(H, per, ITERS, kernel_variant=1, llr_exact=exact)
     e2 = torch.empty((2048, N), dtype=torch.uint8, device=syn.device); c2 = torch.empty(2048, dtype=torch.uint8, device=syn.device)

@@ -333,7 +333,7 @@ def test_auto_dispatch_picks_the_kernel_by_code_and_batch(ldpc, gpu, monkeypatch
     d_big.close()
     # n = 32768: eight message slots are 512 MiB, twice the Infinity Cache; with a quarter of the rows on chip FOUR slots
     # fit it: four WIDE teams of 64 workgroups, each dealt over all XCDs (round 4), 19 tiles for the 4 teams -- and, with
-    # LLRs, hard decisions and LLRs against the oracle (the wide teams' variable sweep captures into the scratch rows)
+    # LLRs, hard decisions and LLRs against the oracle (the wide teams' variable sweep captures the odds in position order)
     huge = ldpc.codes.parity_check_csc(32768, 8, 4)
     d_huge = ldpc.BeliefPropagationDecoder(huge, 0.03, 30)
     syn = ldpc.codes.syndromes_of(huge, ldpc.codes.random_errors(32768, 1200, 0.03, seed=5))
