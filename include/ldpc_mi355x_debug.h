@@ -40,6 +40,18 @@ ldpc_status ldpc_debug_team_rows(int64_t s, int64_t n, const int64_t *colptr, co
                                  int32_t regs_per_wave, int32_t static_quarters, int32_t *degrees, int32_t *shape,
                                  int32_t *vtab, int32_t *ctab, int32_t *lds_edge, int32_t *reg_edge);
 
+/* The tables with which the team kernel keeps WHOLE CHECKS of an IRREGULAR graph (any CSC pattern) in the LDS of their
+   owners (csrc/ldpc_mi355x.hip team_irr_tables(); bp_team_kernels.hpp, IRR), for teams of `members` workgroups and nodes
+   inside the register buckets dc_bucket / dv_bucket.  Out: shape = {R = LDS rows per member (at most 312), rows in LDS in
+   all}; ctab2 [s + 1][2] = per check {its first CSR row, its first LDS row or -1}; ptab [n + 1][2] = per position of the
+   dealt bit order {first entry of its edge list in ploc, the bit | 1 << 31 when one of its edges is in LDS}; ploc [nnz] =
+   per edge of a position (checks ascending) its CSR row, or -1 - (LDS row); lds_edge [members][R] (pass room for
+   members * 312) = the CSR rows held, -1 beyond a member's count; posmap [n] = the position of every bit.
+   No reference counterpart. */
+ldpc_status ldpc_debug_team_irr(int64_t s, int64_t n, const int64_t *colptr, const int64_t *rowval, int32_t members,
+                                int32_t dc_bucket, int32_t dv_bucket, int32_t *shape, int32_t *ctab2, int32_t *ptab, int32_t *ploc,
+                                int32_t *lds_edge, int32_t *posmap);
+
 /* Two builds of the library in one process (the product and the -DLDPC_EXPERIMENTS build: the Python host of the tests)
    must not run team grids on one device at the same time -- every member of a team has to be resident.  Each build
    orders its own team launches through a per-device event table; the build loaded second adopts the table of the

@@ -554,6 +554,52 @@ __device__ __forceinline__ void bit_update_multi_first(double *Mt, double *L, co
     }
 }
 
+// IRREGULAR graphs with rows in LDS (instantiations with IRR; round 4).  The host packs WHOLE checks into the LDS of their
+// owners (team_irr_tables(): a check qualifies when every one of its bits can be given to the check's owner -- a set
+// packing over the checks -- and the member has LDS rows and positions left) and relabels the bits by position, as the
+// regular tables do.  The kernel reads its graph through the same four arguments, in these forms:
+//   row_ptr  -> ctab2 [s + 1][2]   {first CSR row of the check, its first LDS row or -1 (all its rows are consecutive there)}
+//   col_ptr  -> ptab  [n + 1][2]   {first entry of the position's edge list, the bit | 1 << 31 when one of its edges is in LDS}
+//   csc2csr  -> ploc  [nnz]        per edge of a position (checks ascending): its CSR row, or -1 - (LDS row) of the member
+//   edge_bit                       unchanged (the convergence test)
+// A check in LDS takes the ordinary update on a generic pointer (the hardware routes LDS and global accesses alike); a
+// bit with an edge in LDS takes bit_update_flat (a pointer per edge).  Nodes wider than the register buckets never
+// get rows in LDS (the host sees to it), so the O(deg^2) paths stay on the slot.
+template <int D>
+__device__ __forceinline__ double bit_update_exact_flat(double *Mt, double *L, const int *__restrict__ loc, double r)
+{
+    double *ptr[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const int q = loc[k];
+        ptr[k] = q >= 0 ? Mt + (size_t)q * kTile : L + (size_t)(-1 - q) * kTile;
+    }
+    double c[D], out[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) c[k] = *ptr[k];
+    const double F = bit_compute_exact<D>(c, r, out);
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) *ptr[k] = out[k];
+    return F;
+}
+template <int LO, int HI>
+__device__ __forceinline__ double bit_dispatch_flat(double *Mt, double *L, const int *__restrict__ loc, int deg, double r)
+{
+    if constexpr (LO == HI) {
+        return bit_update_exact_flat<LO>(Mt, L, loc, r);
+    } else {
+        constexpr int MID = (LO + HI) / 2;
+        if (deg <= MID) return bit_dispatch_flat<LO, MID>(Mt, L, loc, deg, r);
+        return bit_dispatch_flat<MID + 1, HI>(Mt, L, loc, deg, r);
+    }
+}
+template <int DV>
+__device__ __forceinline__ double bit_update_flat(double *Mt, double *L, const int *__restrict__ loc, int deg, double r)
+{
+    if (deg == 0) return r;
+    return bit_dispatch_flat<1, DV>(Mt, L, loc, deg <= DV ? deg : DV, r);   // (deg <= DV: the host's promise for such bits)
+}
+
 // Register budget: teams run one or two workgroups per CU (team_geometry() on the host), so the narrow-degree
 // instantiation may have 128 VGPRs instead of the tile kernel's 80 (three workgroups per CU) -- under 80 it spilled.
 template <int DC, int DV, int THREADS, bool LROWS = false>
@@ -565,15 +611,17 @@ constexpr int team_min_waves_per_simd()
 
 // RESUMED: the pass over a packed level (the messages are in the packed tiles, every lane has iterations behind it)
 // is an instantiation of its own -- it shows under its own name in a profile, and the fresh pass loses the tests.
-template <int DC, int DV, bool WANT_LLR, int THREADS, bool RESUMED, bool LROWS = false, int RR = 0>
+template <int DC, int DV, bool WANT_LLR, int THREADS, bool RESUMED, bool LROWS = false, int RR = 0, bool IRR = false>
 __global__ void
-__launch_bounds__(THREADS, (team_min_waves_per_simd<DC, DV, THREADS, LROWS>()))
+__launch_bounds__(THREADS, (team_min_waves_per_simd<DC, DV, THREADS, LROWS || IRR>()))
 bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const int *__restrict__ edge_bit,
                const int *__restrict__ col_ptr, const int *__restrict__ csc2csr,
                const u64 *__restrict__ synmask, const u64 *__restrict__ nevermask)
 {
     static_assert(!(LROWS && RESUMED), "packed tiles are decoded where they lie, all rows in global memory");
     static_assert(RR == 0 || (LROWS && RR == kTeamRegRows), "rows in registers come on top of the rows in LDS");
+    static_assert(!IRR || (!LROWS && !RESUMED && RR == 0), "irregular graphs: whole checks in LDS, fresh tiles");
+    constexpr int RS = IRR ? 2 : 1;   // stride of row_ptr / col_ptr entries (IRR: pairs, see above)
     // Where the division (1 - t) / (1 + t) of :147 is made (check_finish_exact): the rows-on-chip instantiations leave
     // it to the variable sweep.  A check costs 16 fp64 divisions (two per edge) and the check sweep of the persistent
     // teams is bound by them, not by the memory side; the variable sweep has no division at all and waits for its
@@ -725,6 +773,17 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
                 }
                 return;
             }
+            if constexpr (IRR) {
+                for (int i = c * kTeamCheckChunk; i < i1; ++i) {
+                    const int e0 = row_ptr[2 * i], lb = row_ptr[2 * i + 1];
+                    const int deg = row_ptr[2 * i + 2] - e0;
+                    const double sigma = ((syn[i] >> lane) & 1ull) ? -1.0 : 1.0;
+                    double *const M = lb >= 0 ? Lr + (size_t)lb * kTile : Mt + (size_t)e0 * kTile;   // (generic: LDS or the slot)
+                    if (first) check_update<DC, true>(M, deg, sigma, r);
+                    else check_update<DC, false>(M, deg, sigma, r);
+                }
+                return;
+            }
             if (kTeamCheckChunk == 2 && !first && tp.pairs && i1 == c * 2 + 2) {
                 // the usual case, two checks of the full degree: all 2 DC rows in flight at once
                 const int i = c * 2;
@@ -756,7 +815,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     // ---- variable-node sweep  (:152-178).  Across XCDs a chunk is 16 consecutive bits, so that a 128-byte line of
     //      decision words has one writer; inside one XCD (one L2) 4 bits, for an even finish
     auto var_sweep = [&]() {
-        const int vb = (one_xcd || LROWS) ? 4 : 16;     // (LROWS: the host dealt the bits in chunks of 4)
+        const int vb = (one_xcd || LROWS || IRR) ? 4 : 16;     // (LROWS / IRR: the host dealt the bits in chunks of 4)
         const int nch = (n + vb - 1) / vb;
         // LLR capture (tp.llr_raw 4 / 5, TeamParams): a store instruction costs the address path the same whatever its
         // width -- a 4-byte store per bit made the variable sweep 12 % longer, one 16-byte store per chunk of four
@@ -867,6 +926,15 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
                 for (; q < j1; ++q) single(team_vrec_load<DV>(csc2csr + (size_t)q * VT), q);
                 return;
             }
+            if constexpr (IRR) {
+                for (; j < j1; ++j) {                          // j = position in the dealt order
+                    const int c0 = col_ptr[2 * j], bw = col_ptr[2 * j + 1];
+                    const int deg = col_ptr[2 * j + 2] - c0;
+                    const double T = bw >= 0 ? bit_update<DV>(Mt, csc2csr + c0, deg, r) : bit_update_flat<DV>(Mt, Lr, csc2csr + c0, deg, r);
+                    decide(j, bw & 0x7fffffff, T);
+                }
+                return;
+            }
             for (; tp.pairs && j + 1 < j1; j += 2) {           // two bits of the full degree: all 2 DV rows in flight at once
                 const int c0 = col_ptr[j], c1 = col_ptr[j + 1], c2 = col_ptr[j + 2];
                 if (c1 - c0 != DV || c2 - c1 != DV) break;
@@ -898,8 +966,8 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
             u64 par = 0;
             // (regular graphs of the rows-on-chip instantiations: check i's edges are rows DC i ... DC i + DC - 1 -- one
             //  dependent round trip less in front of the decision words)
-            const int e1 = LROWS ? (i + 1) * DC : row_ptr[i + 1];
-            for (int e = LROWS ? i * DC : row_ptr[i]; e < e1; e += 8) {
+            const int e1 = LROWS ? (i + 1) * DC : row_ptr[RS * (i + 1)];
+            for (int e = LROWS ? i * DC : row_ptr[RS * i]; e < e1; e += 8) {
                 int jb[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) jb[q] = (e + q < e1) ? edge_bit[e + q] : -1;
@@ -988,7 +1056,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
         // few stragglers left: hand them, with their messages, to the next level (decided alike by every member;
         // rank 0 reserves the room and tells the others through the team's control block, then all copy)
         if (p.defer_thresh != 0 && active != 0 && it >= p.defer_min_iter && (int)__popcll(active) <= p.defer_thresh) {
-            if (LROWS) {   // the rows this member keeps in LDS go back to their places in the slot: the copy below reads the slot
+            if (LROWS || IRR) {   // the rows this member keeps in LDS go back to their places in the slot: the copy below reads the slot
                 const int *const le = tp.rows.lds_edge + (size_t)rank * tp.rows.R;
                 for (int q = w; q < tp.rows.R; q += W) {
                     const int e = le[q];

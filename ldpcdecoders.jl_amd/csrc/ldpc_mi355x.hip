@@ -63,8 +63,8 @@ std::string g_stall_msg[kMaxDev];
 
 ldpc_status expired(int device, const char *what, int64_t limit_ms)
 {
-    const std::string msg = std::string(what) + ": the device did not get there within " + std::to_string(limit_ms / 1000) + "." +
-                            std::to_string(limit_ms % 1000 / 100) + " s (ldpc_set_wait_limit_ms); device " + std::to_string(device) +
+    const std::string msg = std::string(what) + ": the device did not get there within " + std::to_string(limit_ms) +
+                            " ms (ldpc_set_wait_limit_ms); device " + std::to_string(device) +
                             " is taken to be stalled: every later call on it fails with this message, and what it may still be "
                             "using is not freed";
     if (device >= 0 && device < kMaxDev) {
@@ -481,6 +481,11 @@ struct ldpc_bp_decoder {
     // rows in LDS (bp_team_kernels.hpp, TeamRows): regular graphs of the (8,4) bucket keep the host copy of csc2csr;
     // the tables are built for the member count of the first persistent launch (team_rows_build())
     std::vector<int> h_csc2csr;
+    // irregular graphs (and regular ones without a rows-on-chip instantiation): host copies of the whole graph for
+    // team_irr_tables() -- whole checks in the LDS of their owners (bp_team_kernels.hpp, IRR)
+    std::vector<int> h_row_ptr, h_edge_bit, h_col_ptr, h_irr_c2r;
+    int irr_G = 0, irr_R = 0, irr_on_chip = 0;   // what the tables below were built for: members, LDS rows per member, rows in LDS in all
+    DevBuf irr_ctab, irr_ptab, irr_ploc, irr_lds_edge, irr_posmap;
     bool team_rows_on = true;         // LDPC_TEAM_ROWS at create (0 = every row in the slot)
     int rows_dc = 0, rows_dv = 0;     // the graph's (check, bit) degree when it is regular and has a rows-in-LDS instantiation
     int rows_G = 0, rows_R = 0;       // what the tables below were built for: members per team, LDS rows per member
@@ -572,7 +577,8 @@ struct ldpc_bp_decoder {
         const bool idle = device_idle && !stalled;
         DevBuf *all[] = {&row_ptr, &edge_bit, &col_ptr, &csc2csr, &msg, &ctrl, &synmask, &nevermask,
                          &errmask, &finmask, &llr_t, &st_all, &node_msg, &done_ctr, &team_ws, &team_ws_lvl[0], &team_ws_lvl[1], &cold,
-                         &rows_ctab, &rows_vtab, &rows_lds_edge, &rows_reg_edge, &rows_posmap};
+                         &rows_ctab, &rows_vtab, &rows_lds_edge, &rows_reg_edge, &rows_posmap,
+                         &irr_ctab, &irr_ptab, &irr_ploc, &irr_lds_edge, &irr_posmap};
         for (DevBuf *b : all) b->release(idle);
         for (int l = 0; l < 2; ++l)
             for (DevBuf *b : {&lvl_state[l], &lvl_list[l], &lvl_it[l], &lvl_syn[l], &lvl_never[l], &lvl_err[l], &lvl_fin[l], &lvl_llr[l]}) b->release(idle);
@@ -896,6 +902,8 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     if (nnz > 0 && nnz == (int64_t)d->max_cdeg * s && nnz == (int64_t)d->max_bdeg * n && team_rows_degrees_ok(d->max_cdeg, d->max_bdeg)) {
         d->h_csc2csr = csc2csr;
         d->rows_dc = d->max_cdeg; d->rows_dv = d->max_bdeg;
+    } else if (nnz > 0) {   // (the tables are only built once a plan with teams of >= 3 members is in sight: team_plan())
+        d->h_row_ptr = row_ptr; d->h_edge_bit = edge_bit; d->h_col_ptr = col_ptr; d->h_irr_c2r = csc2csr;
     }
     if (const char *e = exp_env("LDPC_TEAM_ROWS")) d->team_rows_on = std::atoi(e) != 0;
 
@@ -1040,7 +1048,8 @@ ldpc_status ldpc_bp_get_info(const ldpc_bp_decoder *d, ldpc_bp_info *info)
                            &d->lvl_state[0], &d->lvl_state[1], &d->lvl_list[0], &d->lvl_list[1], &d->lvl_it[0], &d->lvl_it[1],
                            &d->lvl_syn[0], &d->lvl_syn[1], &d->lvl_never[0], &d->lvl_never[1], &d->lvl_err[0], &d->lvl_err[1], &d->lvl_fin[0], &d->lvl_fin[1],
                            &d->lvl_llr[0], &d->lvl_llr[1], &d->team_ws, &d->team_ws_lvl[0], &d->team_ws_lvl[1],
-                           &d->rows_ctab, &d->rows_vtab, &d->rows_lds_edge, &d->rows_reg_edge, &d->rows_posmap};
+                           &d->rows_ctab, &d->rows_vtab, &d->rows_lds_edge, &d->rows_reg_edge, &d->rows_posmap,
+                           &d->irr_ctab, &d->irr_ptab, &d->irr_ploc, &d->irr_lds_edge, &d->irr_posmap};
     for (const DevBuf *b : all) info->workspace_bytes += (int64_t)b->cap;
     info->last_kernel = d->last_kernel;
     info->last_team_size = d->last_team;
@@ -1158,6 +1167,7 @@ static bool team_geometry(ldpc_bp_decoder *d, bool want_llr, int *per_xcd, int *
 constexpr int kTeamRowsMax = 312;
 
 static bool team_rows_possible(const ldpc_bp_decoder *d) { return d->team_rows_on && !d->h_csc2csr.empty() && !d->wpt_fixed; }
+static bool team_irr_possible(const ldpc_bp_decoder *d) { return d->team_rows_on && !d->h_row_ptr.empty() && !d->wpt_fixed && d->max_cdeg <= 16; }   // (pick_team_kernel_irr: no 32-wide bucket)
 
 // What the team plan depends on (pure data: ldpc_debug_team_plan() plans without a device for a CPU test)
 struct TeamPlanIn {
@@ -1182,6 +1192,10 @@ struct TeamPlanIn {
     // bytes a team keeps rewriting besides its message slot: with LLRs wanted the posterior odds of every bit of the tile in
     // hand, n x 512 B per iteration (they live in the cache with the slot, and count against the same budget)
     size_t extra = 0;
+    // an irregular graph whose tables (team_irr_tables()) were built for teams of irr_G members keep irr_on_chip of the
+    // tile's rows in LDS: counted off the slots of such teams
+    bool irr_possible = false;
+    int irr_G = 0, irr_on_chip = 0;
     // WIDE teams (round 4): T < 8 persistent teams of (all workgroups) / T members each, dealt over ALL XCDs, rows on
     // chip -- for graphs of which eight slots do not fit the Infinity Cache but a few do (n = 65536: 128 MiB a slot, 96 MiB
     // with a quarter of the rows on chip: two; n = 32768: four).  Every barrier then writes the XCDs' L2s back (the
@@ -1196,6 +1210,7 @@ struct TeamPlanIn {
 // are candidates; the LDS holds kTeamRowsMax of them, the waves' registers reg_rows more).
 static int team_rows_expected(const TeamPlanIn &in, int G)
 {
+    if (!in.rows_possible && in.irr_possible) return G == in.irr_G ? in.irr_on_chip / std::max(G, 1) : 0;
     return in.rows_possible ? (int)std::min<int64_t>(kTeamRowsMax + in.reg_rows, in.nnz / std::max(in.rows_dv, 1) / std::max(G, 1)) : 0;
 }
 
@@ -1415,6 +1430,142 @@ extern "C" ldpc_status ldpc_debug_team_rows(int64_t s, int64_t n, const int64_t 
     return LDPC_OK;
 }
 
+// IRREGULAR graphs (round 4): whole checks in the LDS of their owners (bp_team_kernels.hpp, IRR).  Checks are dealt as the
+// kernel deals them (chunk c of 2 checks to member c % G), positions of the bit order in chunks of 4.  A check can live
+// in its owner's LDS when EVERY one of its bits can be given to that member -- then nobody else ever touches its rows
+// in either sweep.  That is a set packing over the checks (two checks that share a bit exclude each other); it is
+// taken greedily in check order, within each member's capacity (kTeamRowsMax LDS rows, its share of the positions),
+// and only over nodes inside the kernel's register buckets (dcb / dvb).  Tables: ctab2 [s + 1][2], ptab [n + 1][2],
+// ploc [nnz], lds_edge [G][R] (the CSR rows held, -1 beyond a member's count), posmap [n] (position of every bit).
+// (pure host code: ldpc_debug_team_irr() hands the tables to a CPU test)
+struct TeamIrrTables {
+    int R = 1;
+    size_t in_lds = 0;
+    std::vector<int> ctab2, ptab, ploc, lds_edge, posmap;
+};
+static TeamIrrTables team_irr_tables(int n, int s, int nnz, const std::vector<int> &row_ptr, const std::vector<int> &edge_bit,
+                                     const std::vector<int> &col_ptr, const std::vector<int> &c2r, int G, int dcb, int dvb)
+{
+    TeamIrrTables out;
+    auto owner = [&](int i) { return (i / kTeamCheckChunk) % G; };
+    std::vector<int> room_pos((size_t)G, 0), next_lds((size_t)G, 0), member_of_bit((size_t)n, -1), lds_base((size_t)s, -1);
+    for (int p = 0; p < n; ++p) room_pos[(size_t)((p / 4) % G)]++;
+    for (int i = 0; i < s; ++i) {
+        const int e0 = row_ptr[(size_t)i], deg = row_ptr[(size_t)i + 1] - e0, m = owner(i);
+        if (deg <= 0 || deg > dcb || room_pos[(size_t)m] < deg || next_lds[(size_t)m] + deg > kTeamRowsMax) continue;
+        bool ok = true;
+        for (int k = 0; k < deg && ok; ++k) {
+            const int j = edge_bit[(size_t)e0 + k];
+            ok = member_of_bit[(size_t)j] < 0 && col_ptr[(size_t)j + 1] - col_ptr[(size_t)j] <= dvb;
+        }
+        if (!ok) continue;
+        for (int k = 0; k < deg; ++k) member_of_bit[(size_t)edge_bit[(size_t)e0 + k]] = m;
+        room_pos[(size_t)m] -= deg;
+        lds_base[(size_t)i] = next_lds[(size_t)m];
+        next_lds[(size_t)m] += deg;
+        out.in_lds += (size_t)deg;
+    }
+    for (int j = 0, m = 0; j < n; ++j) {             // the other bits: wherever there is room
+        if (member_of_bit[(size_t)j] >= 0) continue;
+        while (m < G && room_pos[(size_t)m] == 0) ++m;
+        if (m >= G) std::abort();                    // (cannot happen: the rooms add up to n positions)
+        member_of_bit[(size_t)j] = m; room_pos[(size_t)m]--;
+    }
+    // positions of every member in ascending order take its bits in ascending order
+    std::vector<std::vector<int>> bits_of((size_t)G);
+    for (int j = 0; j < n; ++j) bits_of[(size_t)member_of_bit[(size_t)j]].push_back(j);
+    std::vector<size_t> taken((size_t)G, 0);
+    std::vector<int> bit_at((size_t)n, -1);
+    out.posmap.assign((size_t)std::max(n, 1), 0);
+    for (int p = 0; p < n; ++p) {
+        const int m = (p / 4) % G;
+        const int j = bits_of[(size_t)m][taken[(size_t)m]++];
+        bit_at[(size_t)p] = j;
+        out.posmap[(size_t)j] = p;
+    }
+    for (int m = 0; m < G; ++m) out.R = std::max(out.R, next_lds[(size_t)m]);
+    std::vector<int> check_of((size_t)std::max(nnz, 1), 0);
+    for (int i = 0; i < s; ++i)
+        for (int e = row_ptr[(size_t)i]; e < row_ptr[(size_t)i + 1]; ++e) check_of[(size_t)e] = i;
+    out.ctab2.assign(((size_t)s + 1) * 2, -1);
+    for (int i = 0; i <= s; ++i) out.ctab2[(size_t)2 * i] = row_ptr[(size_t)i];
+    for (int i = 0; i < s; ++i) out.ctab2[(size_t)2 * i + 1] = lds_base[(size_t)i];
+    out.lds_edge.assign((size_t)G * out.R, -1);
+    for (int i = 0; i < s; ++i)
+        if (lds_base[(size_t)i] >= 0)
+            for (int e = row_ptr[(size_t)i]; e < row_ptr[(size_t)i + 1]; ++e)
+                out.lds_edge[(size_t)owner(i) * out.R + lds_base[(size_t)i] + (e - row_ptr[(size_t)i])] = e;
+    out.ptab.assign(((size_t)n + 1) * 2, 0);
+    out.ploc.assign((size_t)std::max(nnz, 1), 0);
+    int at = 0;
+    for (int p = 0; p < n; ++p) {
+        const int j = bit_at[(size_t)p];
+        out.ptab[(size_t)2 * p] = at;
+        bool any = false;
+        for (int k = col_ptr[(size_t)j]; k < col_ptr[(size_t)j + 1]; ++k) {
+            const int q = c2r[(size_t)k], i = check_of[(size_t)q];
+            if (lds_base[(size_t)i] >= 0) { out.ploc[(size_t)at++] = -1 - (lds_base[(size_t)i] + (q - row_ptr[(size_t)i])); any = true; }
+            else out.ploc[(size_t)at++] = q;
+        }
+        out.ptab[(size_t)2 * p + 1] = any ? (j | (int)0x80000000u) : j;
+    }
+    out.ptab[(size_t)2 * n] = at;
+    return out;
+}
+
+// include/ldpc_mi355x_debug.h: the tables above for a CPU test
+extern "C" ldpc_status ldpc_debug_team_irr(int64_t s, int64_t n, const int64_t *colptr, const int64_t *rowval, int32_t members,
+                                           int32_t dc_bucket, int32_t dv_bucket, int32_t *shape, int32_t *ctab2, int32_t *ptab,
+                                           int32_t *ploc, int32_t *lds_edge, int32_t *posmap)
+{
+    if (!colptr || !rowval || !shape || !ctab2 || !ptab || !ploc || !lds_edge || !posmap) return fail(LDPC_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (s <= 0 || n <= 0 || members < 1 || members > kTeamMaxMembers || dc_bucket < 1 || dv_bucket < 1) return fail(LDPC_ERR_INVALID_ARGUMENT, "bad dimension");
+    const int64_t nnz = colptr[n];
+    if (nnz <= 0 || nnz >= INT32_MAX) return fail(LDPC_ERR_INVALID_ARGUMENT, "bad graph");
+    std::vector<int> row_ptr((size_t)s + 1, 0), edge_bit((size_t)nnz), col_ptr((size_t)n + 1), c2r((size_t)nnz);
+    for (int64_t k = 0; k < nnz; ++k) {
+        if (rowval[k] < 0 || rowval[k] >= s) return fail(LDPC_ERR_INVALID_ARGUMENT, "rowval entry outside [0, s)");
+        row_ptr[(size_t)rowval[k] + 1]++;
+    }
+    for (int64_t i = 0; i < s; ++i) row_ptr[(size_t)i + 1] += row_ptr[(size_t)i];
+    std::vector<int> fill(row_ptr.begin(), row_ptr.end() - 1);
+    for (int64_t j = 0; j < n; ++j) {
+        col_ptr[(size_t)j] = (int)colptr[j];
+        for (int64_t k = colptr[j]; k < colptr[j + 1]; ++k) { const int q = fill[(size_t)rowval[k]]++; edge_bit[(size_t)q] = (int)j; c2r[(size_t)k] = q; }
+    }
+    col_ptr[(size_t)n] = (int)nnz;
+    const TeamIrrTables t = team_irr_tables((int)n, (int)s, (int)nnz, row_ptr, edge_bit, col_ptr, c2r, members, dc_bucket, dv_bucket);
+    shape[0] = t.R; shape[1] = (int32_t)t.in_lds;
+    std::memcpy(ctab2, t.ctab2.data(), t.ctab2.size() * sizeof(int));
+    std::memcpy(ptab, t.ptab.data(), t.ptab.size() * sizeof(int));
+    std::memcpy(ploc, t.ploc.data(), (size_t)nnz * sizeof(int));
+    std::memcpy(lds_edge, t.lds_edge.data(), t.lds_edge.size() * sizeof(int));
+    std::memcpy(posmap, t.posmap.data(), (size_t)n * sizeof(int));
+    return LDPC_OK;
+}
+
+static ldpc_status team_irr_build(ldpc_bp_decoder *d, int G)
+{
+    if (d->irr_G == G) return LDPC_OK;
+    const TeamIrrTables t = team_irr_tables((int)d->n, (int)d->s, (int)d->nnz, d->h_row_ptr, d->h_edge_bit, d->h_col_ptr, d->h_irr_c2r, G,
+                                            team_bucket_dc(d->max_cdeg), team_bucket_dv(d->max_bdeg));
+    auto up = [&](DevBuf &b, const std::vector<int> &v) -> ldpc_status {
+        ldpc_status r = b.ensure(std::max<size_t>(v.size() * 4, 4));
+        if (r != LDPC_OK) return r;
+        if (hipMemcpy(b.p, v.data(), v.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return fail(LDPC_ERR_HIP, "hipMemcpy of the team tables failed"); }
+        return LDPC_OK;
+    };
+    ldpc_status st;
+    if ((st = ldpc_detail::wait_device(d->device, "team tables of an irregular graph (device synchronise before the tables are replaced)")) != LDPC_OK) return st;
+    if ((st = up(d->irr_ctab, t.ctab2)) != LDPC_OK || (st = up(d->irr_ptab, t.ptab)) != LDPC_OK || (st = up(d->irr_ploc, t.ploc)) != LDPC_OK ||
+        (st = up(d->irr_lds_edge, t.lds_edge)) != LDPC_OK || (st = up(d->irr_posmap, t.posmap)) != LDPC_OK)
+        return st;
+    d->irr_G = G; d->irr_R = t.R; d->irr_on_chip = (int)t.in_lds;
+    if (exp_env("LDPC_TEAM_DEBUG"))
+        std::fprintf(stderr, "[ldpc] team tables (irregular graph): %d members, %d LDS rows each at most, %zu of %d edges in LDS\n", G, t.R, t.in_lds, (int)d->nnz);
+    return LDPC_OK;
+}
+
 // include/ldpc_mi355x_debug.h: div_core against `/` on the device (a GPU test)
 extern "C" ldpc_status ldpc_debug_div_check(int64_t count, const double *num, const double *den, double *out_core, double *out_ieee)
 {
@@ -1507,7 +1658,11 @@ static bool team_fit(const TeamPlanIn &in, int64_t ntiles, bool rows, int *xcds,
     // iterations, teams against the tile kernel: n = 40960, 80 MiB a slot: 16,384 syndromes 693 against 874 ms, 65,536
     // syndromes 2.76 against 2.94 s; n = 49152: 874 against 1071 ms, 3.51 against 3.70 s).  Beyond that (n = 65536,
     // 128 MiB a slot: 4.96 against 4.85 s) the tile kernel stays.  (profiles/r03_midsize_plan.txt)
-    if (!in.xcds_forced && (size_t)8 * state <= cache / 10 * 33 && std::min(gcap, per_xcd) >= 3) {
+    // (Graphs WITHOUT rows on chip -- irregular ones beyond what team_irr_tables() can credit, degree pairs without an
+    //  instantiation -- only up to a quarter over the budget: an irregular n = 32768 graph, 8 x 56 MiB of slots, 16,384
+    //  syndromes x 50 iterations: eight teams 570 ms, with whole checks in LDS 626 ms, the tile kernel 518 ms --
+    //  profiles/r04_irregular.txt.  Regular graphs with rows on chip get wide teams long before this: team_wide_auto().)
+    if (!in.xcds_forced && (size_t)8 * state <= (in.rows_possible ? cache / 10 * 33 : cache + cache / 4) && std::min(gcap, per_xcd) >= 3) {
         *xcds = 8; *tpx = 1; *G = std::min(gcap, per_xcd);
         return true;
     }
@@ -1529,6 +1684,7 @@ struct TeamPlan {
     int xcds = 8, tpx = 0;   // XCDs that host teams, teams per XCD (not in scatter mode)
     bool scatter = false;
     bool wide = false;       // a few persistent teams over all XCDs (TeamPlanIn::wide)
+    bool irr = false;        // an irregular graph: members keep whole checks in LDS (team_irr_tables())
     bool rows = false;       // members keep the rows that only they touch in LDS (TeamRows)
 };
 
@@ -1586,7 +1742,7 @@ static TeamPlan team_plan_pure(const TeamPlanIn &in, int64_t batch)
         // 8 x 27 MiB, measured 981 ms for the full batch, seven 957.  With rows in the waves' registers as well a quarter
         // of a tile is on chip and the rows on chip are taken off the slots: 8 x 24 MiB fit, and eight teams measured
         // 833 ms against 877 on seven -- round 3.)
-        if (one_round || !team_fit(in, ntiles, in.rows_possible && in.reg_rows > 0, &x, &t, &g)) {
+        if (one_round || !team_fit(in, ntiles, (in.rows_possible && in.reg_rows > 0) || (in.irr_possible && in.irr_on_chip > 0), &x, &t, &g)) {
             if (!one_round && ntiles > in.num_cus) return pl;
             x = 8; t = (int)need;
             g = (int)std::min<int64_t>(gcap, (int64_t)per_xcd / t);
@@ -1598,6 +1754,7 @@ static TeamPlan team_plan_pure(const TeamPlanIn &in, int64_t batch)
     if (team < 3) return pl;   // two workgroups per tile measured no better than the tile kernel's one of 16 waves
     pl.G = (int)std::min<int64_t>(team, kTeamMaxMembers);
     pl.rows = (!pl.scatter || pl.wide) && in.rows_possible && team_rows_expected(in, pl.G) >= 16;
+    pl.irr = !pl.scatter && !in.rows_possible && in.irr_possible;
     pl.nteams = (int)nteams;
     pl.grid = pl.scatter ? pl.nteams * pl.G : 8 * pl.G * pl.tpx;
     return pl;
@@ -1622,7 +1779,15 @@ static TeamPlan team_plan(ldpc_bp_decoder *d, int64_t batch, bool want_llr)
 {
     int per_xcd = 0, gcap = 0, gcap_one = 0;
     if (!team_geometry(d, want_llr, &per_xcd, &gcap, &gcap_one)) return TeamPlan();
-    return team_plan_pure(team_plan_in(d, per_xcd, gcap, gcap_one, want_llr), batch);
+    TeamPlanIn in = team_plan_in(d, per_xcd, gcap, gcap_one, want_llr);
+    if (!in.rows_possible && team_irr_possible(d)) {
+        // an irregular graph: its tables are built once for the team size the plan is most likely to choose (all the CUs
+        // of an XCD, or the most members the 2048-row rule admits), so that the plan can count the rows in LDS off the slots
+        const int G0 = std::min(std::max(gcap, gcap_one), per_xcd);
+        if (d->irr_G == 0 && G0 >= 3) (void)team_irr_build(d, G0);
+        in.irr_possible = true; in.irr_G = d->irr_G; in.irr_on_chip = d->irr_on_chip;
+    }
+    return team_plan_pure(in, batch);
 }
 
 // include/ldpc_mi355x_debug.h: the plan for a CPU test (an MI355X's geometry: 256 CUs, one team workgroup per CU)
@@ -2104,7 +2269,25 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         if (plan.scatter && !d->team_ahead_set && tp.ahead_min > 0) tp.ahead_min = 1;
         team_kernel_t tk = pick_team_kernel(d->max_cdeg, d->max_bdeg, want_llr);
         size_t team_lds = team_lds_bytes();
-        const int *t_col = a_col, *t_c2r = a_c2r;
+        const int *t_col = a_col, *t_c2r = a_c2r, *t_row = a_row;
+        if (plan.irr && !team_scatter && team_irr_build(d, team) == LDPC_OK && d->irr_on_chip > 0) {
+            // an irregular graph: whole checks in the LDS of their owners (bp_team_kernels.hpp, IRR)
+            team_kernel_t tki = pick_team_kernel_irr(d->max_cdeg, d->max_bdeg, want_llr);
+            const size_t need = (size_t)d->irr_R * kTile * sizeof(double);
+            int occ_irr = 0;
+            if (tki && d->prepare_kernel((const void *)tki, LDPC_TEAM_THREADS, need, &occ_irr) == LDPC_OK && occ_irr >= 1) {
+                tk = tki; team_lds = need;
+                d->last_lds_rows = d->irr_R; d->last_rows_on_chip = d->irr_on_chip;
+                tp.rows.lds_edge = (const int *)d->irr_lds_edge.p;
+                tp.rows.R = d->irr_R;
+                tp.rows.reg_edge = nullptr; tp.rows.regs = 0;
+                tp.rows.static_c = tp.rows.static_v = LDPC_TEAM_THREADS / 64; tp.rows.flip = 0;
+                t_row = (const int *)d->irr_ctab.p;      // (this instantiation reads its tables through these three arguments)
+                t_col = (const int *)d->irr_ptab.p;
+                t_c2r = (const int *)d->irr_ploc.p;
+                llr_posmap = (const int *)d->irr_posmap.p;
+            }
+        }
         if (plan.rows && team_rows_build(d, team) == LDPC_OK) {   // (also with LDPC_TEAM_SCATTER: members over all XCDs, a test)
             // rows that only one member touches live in its LDS (TeamRows)
             team_kernel_t tkr = pick_team_kernel_rows(d->rows_dc, d->rows_dv, want_llr, d->rows_regs > 0);
@@ -2124,7 +2307,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
             }
         }
         const u64 *a_syn = (const u64 *)d->synmask.p, *a_nev = (const u64 *)d->nevermask.p;
-        void *args[] = {&p, &tp, &a_row, &a_eb, &t_col, &t_c2r, &a_syn, &a_nev};
+        void *args[] = {&p, &tp, &t_row, &a_eb, &t_col, &t_c2r, &a_syn, &a_nev};
         const hipError_t te = launch_team_grid(d, tk, team_grid, args, stream, team_lds);
         if (te != hipSuccess) {
             // a team grid the runtime refuses must not fail the call: the tile kernel decodes the batch (one

@@ -28,7 +28,29 @@ team_kernel_t team_pick_dc(int dc, int dv)
 #ifndef LDPC_TEAM_ROWS
 #define LDPC_TEAM_ROWS 0
 #endif
-#if LDPC_TEAM_ROWS
+#ifndef LDPC_TEAM_IRR
+#define LDPC_TEAM_IRR 0
+#endif
+#if LDPC_TEAM_IRR
+// (one more compilation: -DLDPC_TEAM_IRR=1) irregular graphs with whole checks in LDS (bp_team_kernels.hpp, IRR), by register
+// bucket like the plain team kernel
+namespace {
+template <int DC, bool LLR>
+team_kernel_t irr_pick_dv(int dv)
+{
+    if (dv <= 4) return bp_team_kernel<DC, 4, LLR, LDPC_TEAM_THREADS, false, false, 0, true>;
+    return bp_team_kernel<DC, 16, LLR, LDPC_TEAM_THREADS, false, false, 0, true>;
+}
+template <bool LLR>
+team_kernel_t irr_pick_dc(int dc, int dv)
+{
+    if (dc <= 8) return irr_pick_dv<8, LLR>(dv);
+    if (dc <= 16) return irr_pick_dv<16, LLR>(dv);
+    return nullptr;   // (checks of 17 ... 32 edges: the 32-wide bucket on generic pointers spills -- such graphs keep every row in the slot)
+}
+}  // namespace
+team_kernel_t pick_team_kernel_irr(int dc, int dv, bool llr) { return llr ? irr_pick_dc<true>(dc, dv) : irr_pick_dc<false>(dc, dv); }
+#elif LDPC_TEAM_ROWS
 // (further compilations: -DLDPC_TEAM_ROWS=1 -DLDPC_TEAM_ROWS_DC=6 ... 10, one object per check degree so that they build in
 // parallel) rows on chip: regular graphs, EXACT degrees (team_rows_degrees_ok(): check degree 6 ... 10 x bit degree
 // 3 ... 5, north_star's "row-weight ~6-10"), fresh tiles.  nullptr: no instantiation for this pair.

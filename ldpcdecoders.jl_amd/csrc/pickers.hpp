@@ -21,5 +21,9 @@ lds_kernel_t pick_lds_kernel(int dc, int dv, bool llr, int threads);            
 node_kernel_t pick_node_kernel(int dc, int dv, bool llr, int threads, int msg);   // pick_node.hip; msg: bp_node_kernels.hpp
 team_kernel_t pick_team_kernel(int dc, int dv, bool llr, bool resumed = false);        // pick_team.hip
 team_kernel_t pick_team_kernel_rows(int dc, int dv, bool llr, bool regs);   // pick_team.hip: regular graphs of these exact degrees, rows in LDS (nullptr: none)
+team_kernel_t pick_team_kernel_irr(int dc, int dv, bool llr);              // pick_team.hip: irregular graphs, whole checks in LDS (by register bucket)
+// the register buckets of the team kernels: nodes up to this degree are straight-line code (wider ones: the O(deg^2) path)
+inline int team_bucket_dc(int dc) { return dc <= 8 ? 8 : dc <= 16 ? 16 : 32; }
+inline int team_bucket_dv(int dv) { return dv <= 4 ? 4 : 16; }
 
 }  // namespace ldpc

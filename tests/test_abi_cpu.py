@@ -207,9 +207,14 @@ def test_hot_kernels_keep_their_register_budget(tmp_path):
         assert info[k]["vgpr_count"] <= 80 and info[k]["private_segment_fixed_size"] == 0, (k, info[k])
     # every rows-on-chip instantiation of the team kernel -- check degree 6 ... 10 x bit degree 3 ... 5, with and without
     # LLRs --: one 8-wave workgroup per CU (156 KB of LDS), not a byte of scratch memory
-    rows = [k for k in info if re.match(r"_ZN4ldpc14bp_team_kernelILi\d+ELi\d+ELb[01]ELi512ELb0ELb1ELi0EEE", k)]
+    rows = [k for k in info if re.match(r"_ZN4ldpc14bp_team_kernelILi\d+ELi\d+ELb[01]ELi512ELb0ELb1ELi0ELb0EEE", k)]
     assert len(rows) == 30, [k for k in info if "bp_team_kernel" in k][:8]
     for k in rows:
+        assert info[k]["private_segment_fixed_size"] == 0 and info[k]["vgpr_count"] <= 256, (k, info[k])
+    # the instantiations for IRREGULAR graphs (whole checks in LDS, by register bucket): one workgroup per CU as well, no scratch
+    irr = [k for k in info if re.match(r"_ZN4ldpc14bp_team_kernelILi\d+ELi\d+ELb[01]ELi512ELb0ELb0ELi0ELb1EEE", k)]
+    assert len(irr) == 8, [k for k in info if "bp_team_kernel" in k][:8]
+    for k in irr:
         assert info[k]["private_segment_fixed_size"] == 0 and info[k]["vgpr_count"] <= 256, (k, info[k])
     # ... and the ones that also keep rows in the top 64 registers of every wave (bp_team_kernels.hpp "Rows in
     # REGISTERS"; the headline instantiation is one of them): 256 registers a lane, no accumulator registers (the
@@ -217,7 +222,7 @@ def test_hot_kernels_keep_their_register_budget(tmp_path):
     # v192 | v193 under s_set_gpr_idx_on) may touch v192 and up
     for tag, path in (("prod", ldpc._capi.LIB_PATH), ("exp", ldpc._capi.EXP_LIB_PATH)):
         xinfo, cos = _kernel_metadata(path, tmp_path, tag + "2")
-        regs = [k for k in xinfo if re.match(r"_ZN4ldpc14bp_team_kernelILi\d+ELi\d+ELb[01]ELi512ELb0ELb1ELi32EEE", k)]
+        regs = [k for k in xinfo if re.match(r"_ZN4ldpc14bp_team_kernelILi\d+ELi\d+ELb[01]ELi512ELb0ELb1ELi32ELb0EEE", k)]
         assert len(regs) == 30
         for k in regs:
             assert xinfo[k]["private_segment_fixed_size"] == 0 and xinfo[k]["agpr_count"] == 0 and xinfo[k]["vgpr_count"] == 256, (k, xinfo[k])
@@ -226,7 +231,7 @@ def test_hot_kernels_keep_their_register_budget(tmp_path):
         checked = idx_pairs = 0
         for co in cos:
             dis = subprocess.run([f"{llvm}/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout
-            if "ELb0ELb1ELi32EEE" not in dis:
+            if "ELb0ELb1ELi32ELb0EEE" not in dis:
                 continue
             cur = None
             # M0: s_set_gpr_idx_on writes it, so every accessor saves it into a scalar register first and puts it back after

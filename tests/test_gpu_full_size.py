@@ -255,3 +255,65 @@ def test_c3_full_batch_with_llrs(ldpc, gpu, per, exact):
     assert worst <= (1e-9 if exact else 1e-5), worst
     if not exact:
         assert worst <= 1e-6, worst      # (the cut is 2^-21 relative in the odds: 4.8e-7 in the logarithm)
+
+
+def _irregular_graph(n, s, seed):
+    """Bits of degree 2 ... 5 on random checks (checks of degree ~3 ... 14), one check wider than any register bucket's
+    straight-line code would like and one wide bit."""
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(seed)
+    rows, cols = [], []
+    for j in range(n):
+        for i in rng.choice(s, int(rng.integers(2, 6)), replace=False):
+            rows.append(int(i)); cols.append(j)
+    for j in rng.choice(n, 40, replace=False):
+        rows.append(5); cols.append(int(j))
+    for i in rng.choice(s, 19, replace=False):
+        rows.append(int(i)); cols.append(9)
+    H = sp.csc_matrix((np.ones(len(rows), dtype=np.uint8), (rows, cols)), shape=(s, n))
+    H.sum_duplicates()
+    H.data[:] = 1
+    H.sort_indices()
+    return H
+
+
+@pytest.mark.parametrize("per", [0.10, 0.02])
+def test_irregular_graph_keeps_whole_checks_in_lds(ldpc, gpu, per):
+    """Rows on chip for an IRREGULAR graph of the C3 size (round 4; the reference takes any H, belief_propagation.jl:61-67):
+    the host packs whole checks into the LDS of the workgroups that own them (team_irr_tables()), the team kernel's IRR
+    instantiation updates them there.  16,384 syndromes through the default path against the tile kernel bit for bit
+    (LLRs included) and against the oracle on a sample, above and below the graph's threshold."""
+    n, s, batch = 16384, 8192, 16384
+    H = _irregular_graph(n, s, seed=2024)
+    syn_h = ldpc.codes.syndromes_of(H, ldpc.codes.random_errors(n, batch, per, seed=int(per * 1000)))
+    syn = torch.from_numpy(syn_h).cuda()
+    res = {}
+    for variant in (0, 1):
+        dec = ldpc.BeliefPropagationDecoder(H, per, ITERS, kernel_variant=variant, defer_threshold=0 if variant == 0 else -1)
+        err = torch.empty((batch, n), dtype=torch.uint8, device="cuda"); conv = torch.empty(batch, dtype=torch.uint8, device="cuda")
+        its = torch.empty(batch, dtype=torch.int32, device="cuda"); llr = torch.empty((batch, n), dtype=torch.float64, device="cuda")
+        dec.decode_batch_device(syn, err, conv, llr, its)
+        dec.last_status()
+        info = dec.info()
+        if variant == 0:
+            assert info.last_kernel == 4 and info.last_team_size >= 16 and info.last_lds_rows >= 200, (info.last_kernel, info.last_team_size, info.last_lds_rows)
+            assert info.last_rows_on_chip >= 0.08 * H.nnz, (info.last_rows_on_chip, H.nnz)
+            # ... and once more without LLRs (the other instantiation)
+            e2 = torch.empty_like(err); c2 = torch.empty_like(conv); i2 = torch.empty_like(its)
+            dec.decode_batch_device(syn, e2, c2, None, i2)
+            dec.last_status()
+            assert torch.equal(e2, err) and torch.equal(c2, conv) and torch.equal(i2, its)
+            del e2, c2, i2
+        else:
+            assert info.last_kernel == 1
+        dec.close()
+        res[variant] = (err, conv, its, llr.view(torch.int64))
+    assert all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
+    err, conv, its, _ = res[0]
+    conv_b = conv.bool()
+    assert bool((its[~conv_b] == ITERS).all()) and bool((its >= 1).all()) and bool((its <= ITERS).all())
+    idx = np.sort(np.random.default_rng(3).choice(batch, 384, replace=False))
+    oerr, oconv, oits = _oracle_subset(H, per, syn_h[idx])
+    assert np.array_equal(conv.cpu().numpy()[idx], oconv) and np.array_equal(its.cpu().numpy()[idx], oits)
+    assert np.array_equal(err.cpu().numpy()[idx], oerr)

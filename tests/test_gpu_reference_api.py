@@ -351,3 +351,48 @@ def test_two_c3_size_handles_from_two_threads(ldpc, gpu):
     assert torch.cuda.mem_get_info()[0] < free_start - (20 << 30)
     ldpc._capi.check(ldpc._capi.lib().ldpc_trim_memory())
     assert torch.cuda.mem_get_info()[0] >= free_start - (2 << 30)     # every group, level and candidate was given back
+
+
+def test_a_host_side_wait_that_expires_names_itself(gpu):
+    """csrc/host_wait.hpp: every wait of the host for the device is bounded (ldpc_set_wait_limit_ms).  With the limit
+    at 20 ms a decode that needs hundreds of milliseconds on the device (the n = 16384 code, 50 iterations, 4,096
+    syndromes through the synchronous host entry) must come back with LDPC_ERR_HIP NAMING the wait instead of blocking;
+    the device then counts as stalled for the process: the next call fails at once with the same message, and closing
+    the decoder returns (what the device may still use is leaked, not freed under it).  In a process of its own, since
+    the mark is for the life of the process; that process must still exit by itself."""
+    import subprocess
+    import sys
+    import textwrap
+
+    code = textwrap.dedent("""
+        import sys, time
+        import numpy as np
+        import ldpcdecoders_jl_amd as ldpc
+        L = ldpc._capi.lib()
+        H = ldpc.codes.parity_check_csc(16384, 8, 4)
+        syn = ldpc.codes.syndromes_of(H, ldpc.codes.random_errors(16384, 4096, 0.10, seed=1))
+        dec = ldpc.BeliefPropagationDecoder(H, 0.10, 50)
+        dec.decode_batch_host(syn)                            # (first call: workspace, tables, code objects -- under the default limit;
+        assert L.ldpc_set_wait_limit_ms(20) == 0              #  a first call spends tens of ms loading kernels while the device already computes)
+        t0 = time.time()
+        try:
+            dec.decode_batch_host(syn)
+            print("NOT BOUNDED")
+            sys.exit(3)
+        except ldpc.LdpcError as e:
+            msg = e.message
+            assert e.status == 3 and "did not get there within" in msg and "ldpc_bp_decode_batch" in msg, msg
+        assert time.time() - t0 < 5.0
+        try:
+            dec.decode_batch_host(syn[:64])
+            sys.exit(4)
+        except ldpc.LdpcError as e:
+            assert e.message == msg, (e.message, msg)         # stalled: the same message, at once
+        t0 = time.time()
+        dec.close()
+        assert time.time() - t0 < 5.0
+        print("BOUNDED", msg[:60])
+        """)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                         cwd=__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+    assert out.returncode == 0 and "BOUNDED" in out.stdout and "NOT BOUNDED" not in out.stdout, (out.returncode, out.stdout[-500:], out.stderr[-1500:])

@@ -206,9 +206,12 @@ def test_team_plan_by_graph_and_batch():
     assert plan(49140, 65536, dv=3) == dict(members=32, teams=8, grid=256, xcds=8, scatter=0, rows=1)
     # 64 MiB slots (n = 32768): eight of them are twice the cache.  With rows on chip (46 MiB a slot) FOUR fit: four WIDE
     # teams of 64 members each, dealt over all XCDs (round 4: 442 ms for 16,384 syndromes x 50 iterations against 496 ms
-    # for one persistent team per XCD); a graph without rows on chip keeps the second tier, one persistent team per XCD
+    # for one persistent team per XCD); a graph without rows on chip goes to the HBM-streaming tile kernel (an irregular
+    # graph of that size: eight partly cached teams 570 ms, the tile kernel 518 ms), teams only while eight whole slots
+    # miss the budget by less than a quarter (n = 20480: 8 x 40 MiB)
     assert plan(131072, 65536) == dict(members=64, teams=4, grid=256, xcds=8, scatter=1, rows=1)
-    assert plan(131072, 65536, regular=0) == dict(members=32, teams=8, grid=256, xcds=8, scatter=0, rows=0)
+    assert plan(131072, 65536, regular=0)["members"] == 1
+    assert plan(81920, 65536, regular=0)["members"] == 1 and plan(73728, 65536, regular=0) == dict(members=32, teams=8, grid=256, xcds=8, scatter=0, rows=0)
     # 128 MiB slots (n = 65536; 96 MiB with a quarter of the rows on chip): TWO wide teams of 128 (910 ms against the
     # tile kernel's 1238 ms); without rows on chip the tile kernel for more tiles than CUs, one team per tile below
     assert plan(262144, 65536) == dict(members=128, teams=2, grid=256, xcds=8, scatter=1, rows=1)
@@ -228,3 +231,98 @@ def test_team_plan_by_graph_and_batch():
     # graphs too small for teams (fewer than 3 x 2048 rows) and batches whose mismatch words would not fit
     assert plan(4096, 65536)["members"] == 1
     assert plan(c3, 1 << 26, max_iters=4000)["members"] == 1
+
+
+def _irr_tables(H, members, dcb=8, dvb=4):
+    H = H.tocsc()
+    H.sort_indices()
+    s, n = H.shape
+    colptr = np.ascontiguousarray(H.indptr, dtype=np.int64)
+    rowval = np.ascontiguousarray(H.indices, dtype=np.int64)
+    shape = (ctypes.c_int32 * 2)()
+    ctab2 = np.zeros((s + 1, 2), dtype=np.int32); ptab = np.zeros((n + 1, 2), dtype=np.int32)
+    ploc = np.zeros(H.nnz, dtype=np.int32); lds_edge = np.full(members * RMAX, -7, dtype=np.int32); posmap = np.zeros(n, dtype=np.int32)
+    ldpc._capi.check(ldpc._capi.lib().ldpc_debug_team_irr(s, n, colptr.ctypes.data, rowval.ctypes.data, members, dcb, dvb, ctypes.byref(shape),
+                                                          ctab2.ctypes.data, ptab.ctypes.data, ploc.ctypes.data, lds_edge.ctypes.data, posmap.ctypes.data))
+    R, in_lds = list(shape)
+    return H, R, in_lds, ctab2, ptab, ploc, lds_edge[: members * R].reshape(members, R), posmap
+
+
+def _irregular_graph(n, s, seed, heavy=False):
+    """Bits of degree 2 ... 5, checks of whatever degree that gives (about 6 ... 12), a few empty and heavy nodes."""
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(seed)
+    rows, cols = [], []
+    for j in range(n):
+        d = int(rng.integers(2, 6))
+        for i in rng.choice(s, d, replace=False):
+            rows.append(int(i)); cols.append(j)
+    if heavy:
+        for j in rng.choice(n, 20, replace=False):       # a check wider than any register bucket, a few wide bits
+            rows.append(7); cols.append(int(j))
+        for i in rng.choice(s, 19, replace=False):
+            rows.append(int(i)); cols.append(11)
+    H = sp.csc_matrix((np.ones(len(rows), dtype=np.uint8), (rows, cols)), shape=(s, n))
+    H.data[:] = 1
+    H.sum_duplicates()
+    H.data[:] = 1
+    return H
+
+
+@pytest.mark.parametrize("n,s,members,heavy", [(4096, 2048, 8, False), (16384, 8192, 32, False), (16384, 8192, 32, True), (1000, 700, 3, True)])
+def test_irregular_graph_tables_describe_the_graph(n, s, members, heavy):
+    """Whole checks of an IRREGULAR graph in the LDS of their owners (ldpc_mi355x.hip team_irr_tables(); bp_team_kernels.hpp,
+    IRR), checked without a GPU: the dealt bit order is a permutation; a position's edge list is its bit's (checks
+    ascending), every entry either the CSR row itself or an LDS row of the member that owns the position; a check in LDS is
+    there WHOLE, consecutively, with its owner, and every one of its bits sits in a position of that member (so nobody
+    else ever touches those rows in either sweep); no two rows share an LDS slot; nodes wider than the register buckets
+    stay in the slot; and the packing is worth having."""
+    H0 = _irregular_graph(n, s, seed=n + members, heavy=heavy)
+    # the kernel's register buckets for this graph's widest nodes (pickers.hpp): checks 8 / 16 / 32, bits 4 / 16
+    maxc, maxv = int(np.diff(H0.tocsr().indptr).max()), int(np.diff(H0.tocsc().indptr).max())
+    dcb, dvb = (8 if maxc <= 8 else 16 if maxc <= 16 else 32), (4 if maxv <= 4 else 16)
+    H, R, in_lds, ctab2, ptab, ploc, lds_edge, posmap = _irr_tables(H0, members, dcb, dvb)
+    nnz = H.nnz
+    csr = H.tocsr(); csr.sort_indices()
+    assert 1 <= R <= RMAX and np.array_equal(ctab2[:, 0], csr.indptr) and ptab[n, 0] == nnz
+    bits = ptab[:n, 1] & 0x7FFFFFFF
+    assert np.array_equal(np.sort(bits), np.arange(n)) and np.array_equal(posmap[bits], np.arange(n))
+    place = {}
+    for i in range(s):
+        for k, j in enumerate(csr.indices[csr.indptr[i]:csr.indptr[i + 1]]):
+            place[(i, int(j))] = int(csr.indptr[i]) + k
+    member_of_pos = (np.arange(n) // 4) % members
+    member_of_check = (np.arange(s) // 2) % members
+    check_of_row = np.repeat(np.arange(s), np.diff(csr.indptr))
+    seen = set()
+    counted = 0
+    for p in range(n):
+        j = int(bits[p])
+        rows = [place[(int(i), j)] for i in H.indices[H.indptr[j]:H.indptr[j + 1]]]
+        loc = ploc[ptab[p, 0]:ptab[p + 1, 0]]
+        assert len(loc) == len(rows)
+        any_lds = False
+        for q, l in zip(rows, loc):
+            if l >= 0:
+                assert l == q
+                continue
+            any_lds = True
+            counted += 1
+            i, m, lr = int(check_of_row[q]), int(member_of_pos[p]), -1 - int(l)
+            assert member_of_check[i] == m, "a row in LDS must belong to ONE member in both sweeps"
+            assert ctab2[i, 1] >= 0 and lr == ctab2[i, 1] + (q - csr.indptr[i]) and lr < R
+            assert (m, lr) not in seen and lds_edge[m, lr] == q
+            seen.add((m, lr))
+            assert len(rows) <= dvb, "a bit wider than the register bucket never has a row in LDS"
+        assert bool(ptab[p, 1] < 0) == any_lds
+    assert counted == in_lds == int((lds_edge >= 0).sum()) and np.all(lds_edge[lds_edge < 0] == -1)
+    for i in range(s):                         # a check in LDS is there whole; the others not at all
+        deg = int(csr.indptr[i + 1] - csr.indptr[i])
+        if ctab2[i, 1] >= 0:
+            assert 0 < deg <= dcb and all(lds_edge[member_of_check[i], ctab2[i, 1] + k] == csr.indptr[i] + k for k in range(deg))
+        else:
+            assert not np.isin(np.arange(csr.indptr[i], csr.indptr[i + 1]), lds_edge).any() if deg and i % 97 == 0 else True
+    # worth having: a random graph of mean bit degree 3.5 packs ~1 check in 4 (the bound is n / mean check degree), unless the
+    # members' LDS is what limits it (312 rows each)
+    assert in_lds >= min(0.08 * nnz, 0.7 * RMAX * members), (in_lds, nnz)
