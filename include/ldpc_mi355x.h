@@ -92,7 +92,8 @@ typedef struct ldpc_bp_options {
                                  fewer nearly-empty sweeps).  0 = auto (16), -1 = off, else 1..48 */
     int32_t llr_exact;        /* What `llr` holds.  0 (default): log(1 / T~), T~ = the posterior odds T of :163 cut to their upper
                                  32 bits (20 fraction bits) -- the same bits whatever kernel finishes a syndrome, within
-                                 5e-7 of the reference's log(1 / T) (BASELINE.json asks for 1e-5); +-Inf come out exactly.
+                                 5e-7 of the reference's log(1 / T) (2e-6 where T is denormal, LLR > 708.39; BASELINE.json asks
+                                 for 1e-5); +-Inf come out exactly.
                                  The team kernel of large codes then captures 4 bytes per bit and iteration instead of 8
                                  (LLRs at the C3 size: +5 % kernel time at 50 iterations instead of +19 %).  1: log(1 / T) of T itself, as
                                  before ABI version 4 -- what the BP+OSD hosts ask for, because OSD orders the bits by

@@ -66,6 +66,13 @@ ldpc_status ldpc_debug_adopt_process_state(void *state);
    in, edges included.  No reference counterpart (Julia's `/` is the IEEE division). */
 ldpc_status ldpc_debug_div_check(int64_t count, const double *num, const double *den, double *out_core, double *out_ieee);
 
+/* ... and one more: out_fast[i] = the LLR every kernel of the library returns for posterior odds odds[i] (bp_kernels.hpp
+   llr_of without llr_exact: the odds cut to their upper 32 bits, then llr_cut -- frexp, one division, seven terms of
+   2 atanh), out_lib[i] = the library's log(1 / .) of the same cut odds; HOST arrays of `count` doubles.  A GPU test holds
+   them against each other (<= 1e-12, end cases identical) and against log(1 / odds) (<= 5e-7).  Reference:
+   belief_propagation.jl:163. */
+ldpc_status ldpc_debug_llr_check(int64_t count, const double *odds, double *out_fast, double *out_lib);
+
 #ifdef __cplusplus
 }
 #endif

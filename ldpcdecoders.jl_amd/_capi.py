@@ -63,7 +63,7 @@ EXPORTED_SYMBOLS = (
 )
 # ... and include/ldpc_mi355x_debug.h (test hooks, not part of the boundary)
 DEBUG_SYMBOLS = ("ldpc_debug_team_rows", "ldpc_debug_team_plan", "ldpc_debug_div_check", "ldpc_debug_process_state",
-                 "ldpc_debug_adopt_process_state", "ldpc_debug_team_irr")
+                 "ldpc_debug_adopt_process_state", "ldpc_debug_team_irr", "ldpc_debug_llr_check")
 
 MULTI_MAX_DEVICES = 16
 EXCHANGE_AUTO, EXCHANGE_COPY, EXCHANGE_RCCL, EXCHANGE_NONE = 0, 1, 2, 3
@@ -163,6 +163,8 @@ def lib(experiments: bool = False) -> ctypes.CDLL:
     L.ldpc_debug_team_plan.argtypes = [i64, i64, i64, i32, i32, ctypes.POINTER(i32 * 6)]
     L.ldpc_debug_div_check.restype = i32
     L.ldpc_debug_div_check.argtypes = [i64, vp, vp, vp, vp]
+    L.ldpc_debug_llr_check.restype = i32
+    L.ldpc_debug_llr_check.argtypes = [i64, vp, vp, vp]
     L.ldpc_debug_team_irr.restype = i32
     L.ldpc_debug_team_irr.argtypes = [i64, i64, vp, vp, i32, i32, i32, ctypes.POINTER(i32 * 2), vp, vp, vp, vp, vp]
     L.ldpc_debug_team_rows.restype = i32

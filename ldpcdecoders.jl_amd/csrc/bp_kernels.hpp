@@ -152,7 +152,8 @@ struct BPParams {
 // LLRs from 32 bits.  The reference's log_probabs[j] = log(1 / T) (:163) is wanted to 1e-5 (BASELINE.json north_star).
 // The UPPER 32 BITS of the posterior odds T -- sign, exponent, the 20 leading fraction bits -- cost nothing to make (they
 // are a register of T already) and halve what the team kernel has to write per bit and iteration (TeamParams::llr_raw =
-// 4); the decoder puts the middle of what was cut off back (2^-21 relative: the LLR good to 5e-7), except under an all-ones exponent (+-infinity stays itself).
+// 4); the decoder puts the middle of what was cut off back (2^-21 relative: the LLR good to 5e-7; denormal odds with a finite
+// LLR, 2^-1024 <= T < 2^-1022, LLR 708.4 ... 709.8, keep 18-19 significant bits: 2e-6), except under an all-ones exponent (+-infinity stays itself).
 // T = +-0 comes back as a denormal whose reciprocal overflows, so log(1 / T) = +-Inf exactly as for 0; and every T
 // below 2^-1024 -- where the reference's own 1 / T overflows to Inf -- still decodes below 2^-1024.
 __device__ __forceinline__ unsigned int llr_hi32(double T) { return (unsigned int)__double2hiint(T); }
@@ -165,9 +166,34 @@ __device__ __forceinline__ double llr_from_hi32(unsigned int hi)
 // upper 32 bits (above) -- whatever kernel finishes a syndrome, its LLRs are the same bits, and within 5e-7 of the
 // reference's, inside the 1e-5 of BASELINE.json -- unless the decoder was created with llr_exact (ldpc_bp_options):
 // then log(1 / T) of T itself, as before round 4 (the team kernel then captures 8 bytes per bit and iteration, not 4).
+// log(1 / v) for a v that llr_from_hi32 made (21 significant bits), to 6e-13 absolute -- a thousandth of a millionth of what
+// the cut itself costs -- in some 40 instructions instead of the 150 of a division and the library's log: v = m 2^e with m
+// in [sqrt(1/2), sqrt(2)), log m = 2 atanh(s) for s = (m - 1) / (m + 1) (|s| < 0.172: seven terms), and the end cases as
+// log(1 / v) has them: +Inf wherever the reference's own 1 / T overflows (v < 2^-1024: exact for these v, see above),
+// -Inf for Inf, NaN for NaN and below zero.  Explicit fma()s: the same bits in every kernel.
+__device__ __forceinline__ double llr_cut(double v)
+{
+    double m = __builtin_amdgcn_frexp_mant(v);            // [1/2, 1)
+    int e = __builtin_amdgcn_frexp_exp(v);
+    const bool low = m < 0.70710678118654752440;
+    m = low ? m + m : m;
+    e = low ? e - 1 : e;
+    const double s = (m - 1.0) / (m + 1.0), z = s * s;
+    double p = fma(z, 1.0 / 13.0, 1.0 / 11.0);
+    p = fma(z, p, 1.0 / 9.0);
+    p = fma(z, p, 1.0 / 7.0);
+    p = fma(z, p, 1.0 / 5.0);
+    p = fma(z, p, 1.0 / 3.0);
+    p = fma(z, p, 1.0);
+    double l = -fma((double)e, 0.69314718055994530942, (s + s) * p);
+    l = (v == __builtin_inf()) ? -__builtin_inf() : l;
+    l = (v >= 0x1p-1024) ? l : (v >= 0.0 ? __builtin_inf() : __builtin_nan(""));
+    return l;
+}
+
 __device__ __forceinline__ double llr_of(double T, int exact)
 {
-    return log(1.0 / (exact ? T : llr_from_hi32(llr_hi32(T))));
+    return exact ? log(1.0 / T) : llr_cut(llr_from_hi32(llr_hi32(T)));
 }
 
 // a value known to be the same in every lane -> scalar registers
@@ -267,13 +293,13 @@ __device__ __forceinline__ void check_to_odds(const double (&t)[D], double (&out
 // same operations on the same operands, so the same bits; what a sweep leaves behind at an iteration boundary (and
 // hands to other kernels) is never in t form.
 template <int D, bool TF = false>
-__device__ __forceinline__ void check_finish_exact(double *M, const double (&a)[D], double sigma)
+__device__ __forceinline__ double check_finish_exact(double *M, const double (&a)[D], double sigma, double S0 = 1.0)
 {
     double pre[D];
     double P = sigma;                                     // :136
 #pragma unroll
     for (int k = 0; k < D; ++k) { pre[k] = P; P = P * a[k]; }          // :139-140
-    double S = 1.0;                                       // :143
+    double S = S0;                                        // :143 (1.0; check_update_halves: the product over the edges behind these)
 #if LDPC_FAST_DIV
     double t[D], o[D];
 #pragma unroll
@@ -281,7 +307,7 @@ __device__ __forceinline__ void check_finish_exact(double *M, const double (&a)[
     if (TF) {
 #pragma unroll
         for (int k = D - 1; k >= 0; --k) stm(M + (size_t)k * kTile, t[k]);
-        return;
+        return S;
     }
     check_to_odds<D>(t, o);                               // :147
 #pragma unroll
@@ -294,6 +320,7 @@ __device__ __forceinline__ void check_finish_exact(double *M, const double (&a)[
         S = S * a[k];                                     // :148
     }
 #endif
+    return S;
 }
 
 // ... the same with the D new messages handed back instead of stored (rows that do not lie k * 64 doubles apart:
@@ -327,7 +354,7 @@ __device__ __forceinline__ void check_compute_exact(const double (&a)[D], double
 }
 
 template <int D, bool FIRST, bool TF = false>
-__device__ __forceinline__ void check_update_exact(double *M, double sigma, double r)
+__device__ __forceinline__ double check_update_exact(double *M, double sigma, double r, double S0 = 1.0)
 {
     double a[D];
     if (FIRST) {
@@ -340,7 +367,7 @@ __device__ __forceinline__ void check_update_exact(double *M, double sigma, doub
         for (int k = 0; k < D; ++k) m[k] = ldm(M + (size_t)k * kTile);
         check_factors<D>(m, a);                                        // :140 / :148 (same value both times)
     }
-    check_finish_exact<D, TF>(M, a, sigma);
+    return check_finish_exact<D, TF>(M, a, sigma, S0);
 }
 
 // Two checks of degree D at once: all 2 D row loads are issued before anything is computed (twice the bytes in
@@ -384,23 +411,56 @@ __device__ __noinline__ void check_update_any(double *M, int deg, double sigma, 
 
 // wave-uniform dispatch on the degree: deg in [LO, HI] -> check_update_exact<deg>
 template <int LO, int HI, bool FIRST>
-__device__ __forceinline__ void check_dispatch(double *M, int deg, double sigma, double r)
+__device__ __forceinline__ double check_dispatch(double *M, int deg, double sigma, double r, double S0 = 1.0)
 {
     if constexpr (LO == HI) {
-        check_update_exact<LO, FIRST>(M, sigma, r);
+        return check_update_exact<LO, FIRST>(M, sigma, r, S0);
     } else {
         constexpr int MID = (LO + HI) / 2;
-        if (deg <= MID) check_dispatch<LO, MID, FIRST>(M, deg, sigma, r);
-        else check_dispatch<MID + 1, HI, FIRST>(M, deg, sigma, r);
+        if (deg <= MID) return check_dispatch<LO, MID, FIRST>(M, deg, sigma, r, S0);
+        return check_dispatch<MID + 1, HI, FIRST>(M, deg, sigma, r, S0);
     }
 }
 
+// A check of DC < deg <= 2 DC edges as two halves of straight-line code instead of the O(deg^2) path: the prefix
+// product over the first DC edges (nothing stored), then the other deg - DC edges as a check of their own that starts
+// from that prefix and hands back its suffix product, then the first DC edges once more (their rows are in the L2 by
+// now) with the suffix starting there.  The same multiplications on the same operands in the same order as one pass
+// over all deg edges (:136-148) -- the first half's factors are simply formed twice.
 template <int DC, bool FIRST>
+__device__ __forceinline__ void check_update_halves(double *M, int deg, double sigma, double r)
+{
+    double a[DC];
+    auto factors = [&]() {
+        if (FIRST) {
+            const double a0 = 2.0 / (1.0 + r) - 1.0;
+#pragma unroll
+            for (int k = 0; k < DC; ++k) a[k] = a0;
+        } else {
+            double m[DC];
+#pragma unroll
+            for (int k = 0; k < DC; ++k) m[k] = ldm(M + (size_t)k * kTile);
+            check_factors<DC>(m, a);
+        }
+    };
+    factors();
+    double P = sigma;
+#pragma unroll
+    for (int k = 0; k < DC; ++k) P = P * a[k];                          // :139-140
+    const double S = check_dispatch<1, DC, FIRST>(M + (size_t)DC * kTile, deg - DC, P, r);
+    factors();
+    check_finish_exact<DC>(M, a, sigma, S);
+}
+
+// HALVES: checks of up to 2 DC edges in two halves (instantiations whose widest bucket is narrower than their graphs'
+// widest checks: bp_team_kernels.hpp, IRR)
+template <int DC, bool FIRST, bool HALVES = false>
 __device__ __forceinline__ void check_update(double *M, int deg, double sigma, double r)
 {
     if (deg == DC) check_update_exact<DC, FIRST>(M, sigma, r);   // the regular-code case first
     else if (deg == 0) return;
     else if (deg < DC) check_dispatch<1, DC - 1, FIRST>(M, deg, sigma, r);
+    else if (HALVES && deg <= 2 * DC) check_update_halves<DC, FIRST>(M, deg, sigma, r);
     else check_update_any<FIRST>(M, deg, sigma, r);
 }
 
@@ -819,6 +879,16 @@ __global__ void __launch_bounds__(256) div_check_kernel(const double *num, const
     out_ieee[i] = num[i] / den[i];
 }
 
+// include/ldpc_mi355x_debug.h ldpc_debug_llr_check: the LLR every kernel returns (llr_of: llr_cut of the cut odds) against
+// the library's log(1 / .) of the same cut odds
+__global__ void __launch_bounds__(256) llr_check_kernel(const double *T, double *out_fast, double *out_lib, long long count)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    out_fast[i] = llr_of(T[i], 0);
+    out_lib[i] = log(1.0 / llr_from_hi32(llr_hi32(T[i])));
+}
+
 // ---------------------------------------------------------------------------
 // placement probe: the two sweeps' access patterns on a candidate workspace, with the real kernel's geometry (one
 // 8-wave workgroup per slot, three per CU, every workgroup starting at a rotation of its own) -- every wave gathers
@@ -907,41 +977,84 @@ __global__ void __launch_bounds__(64) unpack_errors_kernel(const u64 *errmask, l
 
 // llr transpose: llr_t[tile][n][64] -> llr[batch][n]; 64x64 tile through LDS.  raw = 4 / 5: llr_t holds the posterior odds T
 // as the team kernel's fresh pass left them (TeamParams::llr_raw: upper 32 bits / all of T, position-chunk layout) and
-// log(1 / T) (:163) is taken here, once per syndrome and bit
+// log(1 / T) (:163) is taken here, once per syndrome and bit.  All 16 loads of a thread are issued before anything is
+// computed (one load after the other behind its own index load, as this kernel first was, took 7.2 ms for a batch of
+// 65,536 x 16384: the latency of 2 x 16 dependent loads per workgroup, not bytes).
+#ifndef LDPC_UNPACK_XCD
+#define LDPC_UNPACK_XCD 1
+#endif
 __global__ void __launch_bounds__(256) unpack_llr_kernel(const double *llr_t, long long batch, int n,
                                                          double *llr, const int *index,
                                                          const unsigned int *count_dev, unsigned int count_skip, int raw, int exact,
                                                          const int *posmap)
 {
     __shared__ double t[64][65];
+    __shared__ int spos[64];
     if (count_dev) { batch = (long long)*count_dev; if (batch <= (long long)count_skip) return; }   // uniform
+    // Workgroups go round-robin over the 8 XCDs in launch order: all the workgroups of a tile are given the same residue,
+    // so that one L2 sees the tile's scratch rows -- in the position-chunk layout a wave's 4-byte gather uses a quarter
+    // of every line it touches, and the other three quarters belong to workgroups of the same tile.  (gridDim.y is a
+    // multiple of 8: tiles beyond the batch leave below.)
+#if LDPC_UNPACK_XCD
+    const unsigned int lin = blockIdx.y * gridDim.x + blockIdx.x, per8 = 8u * gridDim.x;
+    const int tile = (int)((lin / per8) * 8u + (lin % per8) % 8u);
+    const int j0 = (int)((lin % per8) / 8u) * 64;
+#else
     const int tile = blockIdx.y;
     const int j0 = blockIdx.x * 64;
+#endif
     const long long b0 = (long long)tile * kTile;
     if (b0 >= batch) return;   // uniform for the whole workgroup
     const int rows = (int)((batch - b0) < kTile ? (batch - b0) : kTile);
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int jj = ty; jj < 64; jj += 4)
-        if (j0 + jj < n) {
-            if (raw == 4 || raw == 5) {
-                // the team kernel's scratch layout (bp_team_kernels.hpp): element (position, lane) of a tile at
-                // ((position / 4) * 64 + lane) * 4 + position % 4, rows rounded up to a multiple of 4; posmap = the
-                // position of every bit in the dealt order (nullptr: the bit itself)
-                const int pos = posmap ? posmap[j0 + jj] : j0 + jj;
-                const size_t at = (size_t)tile * (((size_t)n + 3) & ~(size_t)3) * kTile + ((size_t)(pos >> 2) * kTile + tx) * 4 + (size_t)(pos & 3);
-                t[jj][tx] = raw == 4 ? llr_from_hi32(((const unsigned int *)llr_t)[at]) : llr_t[at];
-            } else {
-                const size_t at = ((size_t)tile * n + j0 + jj) * kTile + tx;
-                t[jj][tx] = llr_t[at];
+    if (raw == 4 || raw == 5) {
+        // the team kernel's scratch layout (bp_team_kernels.hpp): element (position, lane) of a tile at
+        // ((position / 4) * 64 + lane) * 4 + position % 4, rows rounded up to a multiple of 4; posmap = the
+        // position of every bit in the dealt order (nullptr: the bit itself)
+        if (threadIdx.x < 64) spos[tx] = j0 + tx < n ? (posmap ? posmap[j0 + tx] : j0 + tx) : -1;
+        __syncthreads();
+        const size_t base = (size_t)tile * (((size_t)n + 3) & ~(size_t)3) * kTile + (size_t)tx * 4;
+        if (raw == 4) {
+            const unsigned int *const src = (const unsigned int *)llr_t + base;
+            unsigned int u[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int pos = spos[ty + 4 * q];
+                u[q] = pos >= 0 ? src[(size_t)(pos >> 2) * (kTile * 4) + (size_t)(pos & 3)] : 0u;
             }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t[ty + 4 * q][tx] = llr_cut(llr_from_hi32(u[q]));
+        } else {
+            const double *const src = llr_t + base;
+            double u[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int pos = spos[ty + 4 * q];
+                u[q] = pos >= 0 ? src[(size_t)(pos >> 2) * (kTile * 4) + (size_t)(pos & 3)] : 1.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t[ty + 4 * q][tx] = llr_of(u[q], exact);
         }
+    } else {
+        double u[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int jj = ty + 4 * q;
+            u[q] = j0 + jj < n ? llr_t[((size_t)tile * n + j0 + jj) * kTile + tx] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t[ty + 4 * q][tx] = u[q];
+    }
     __syncthreads();
-    for (int rr = ty; rr < rows; rr += 4)
-        if (j0 + tx < n) {
+    if (j0 + tx >= n) return;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int rr = ty + 4 * q;
+        if (rr < rows) {
             const long long b = index ? (long long)index[b0 + rr] : b0 + rr;
-            const double v = t[tx][rr];
-            llr[(size_t)b * n + j0 + tx] = !raw ? v : raw == 4 ? log(1.0 / v) : llr_of(v, exact);   // (raw 4: v is the cut T already)
+            llr[(size_t)b * n + j0 + tx] = t[tx][rr];
         }
+    }
 }
 
 #endif  // LDPC_AUX_KERNELS

@@ -779,8 +779,8 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
                     const int deg = row_ptr[2 * i + 2] - e0;
                     const double sigma = ((syn[i] >> lane) & 1ull) ? -1.0 : 1.0;
                     double *const M = lb >= 0 ? Lr + (size_t)lb * kTile : Mt + (size_t)e0 * kTile;   // (generic: LDS or the slot)
-                    if (first) check_update<DC, true>(M, deg, sigma, r);
-                    else check_update<DC, false>(M, deg, sigma, r);
+                    if (first) check_update<DC, true, true>(M, deg, sigma, r);     // (checks of up to 2 DC edges in two halves)
+                    else check_update<DC, false, true>(M, deg, sigma, r);
                 }
                 return;
             }

@@ -485,6 +485,7 @@ struct ldpc_bp_decoder {
     // team_irr_tables() -- whole checks in the LDS of their owners (bp_team_kernels.hpp, IRR)
     std::vector<int> h_row_ptr, h_edge_bit, h_col_ptr, h_irr_c2r;
     int irr_G = 0, irr_R = 0, irr_on_chip = 0;   // what the tables below were built for: members, LDS rows per member, rows in LDS in all
+    int irr_dcb = 0;                             // check-degree bucket of the IRR instantiation for this graph (team_irr_dc_bucket(); 0: none)
     DevBuf irr_ctab, irr_ptab, irr_ploc, irr_lds_edge, irr_posmap;
     bool team_rows_on = true;         // LDPC_TEAM_ROWS at create (0 = every row in the slot)
     int rows_dc = 0, rows_dv = 0;     // the graph's (check, bit) degree when it is regular and has a rows-in-LDS instantiation
@@ -814,6 +815,30 @@ int32_t ldpc_device_count(void)
     return usable;
 }
 
+// The check-degree bucket of the IRR instantiation (bp_team_kernels.hpp) an irregular graph is decoded with: 8 or 16 --
+// the 32-wide straight-line code on generic pointers does not fit the registers.  A graph with a FEW wider checks (the
+// tail of a random construction; one wide check of a test) still takes the 16-wide instantiation: those checks stay in
+// the slot (the packing never puts them in LDS); up to 32 edges they are updated in two halves (check_update_halves:
+// the first half's rows are read twice), beyond that on the O(deg^2) path of every kernel (check_update_any: deg^2 / 2
+// divisions instead of 2 deg).  Admitted while the checks of 17 ... 32 edges hold at most an eighth of the edges and the
+// O(deg^2) ones cost at most 1 / 32 more divisions than the graph has anyway (2 nnz); otherwise 0: every row in the
+// slot, the plain 32-wide team kernel.
+static int team_irr_dc_bucket(const std::vector<int> &row_ptr, int s, int64_t nnz)
+{
+    int max_deg = 0;
+    int64_t halves = 0;   // edges of the checks of 17 ... 32 edges
+    int64_t wide = 0;     // sum of deg^2 over the checks beyond 32 edges
+    for (int i = 0; i < s; ++i) {
+        const int deg = row_ptr[(size_t)i + 1] - row_ptr[(size_t)i];
+        max_deg = std::max(max_deg, deg);
+        if (deg > 32) wide += (int64_t)deg * deg;
+        else if (deg > 16) halves += deg;
+    }
+    if (max_deg <= 8) return 8;
+    if (max_deg <= 16) return 16;
+    return (halves * 8 <= nnz && wide * 8 <= nnz) ? 16 : 0;      // (deg^2 / 2 against 2 nnz / 32)
+}
+
 ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *colptr,
                            const int64_t *rowval, double per, int64_t max_iters,
                            const ldpc_bp_options *options, ldpc_bp_decoder **out)
@@ -904,6 +929,7 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
         d->rows_dc = d->max_cdeg; d->rows_dv = d->max_bdeg;
     } else if (nnz > 0) {   // (the tables are only built once a plan with teams of >= 3 members is in sight: team_plan())
         d->h_row_ptr = row_ptr; d->h_edge_bit = edge_bit; d->h_col_ptr = col_ptr; d->h_irr_c2r = csc2csr;
+        d->irr_dcb = team_irr_dc_bucket(row_ptr, (int)s, nnz);
     }
     if (const char *e = exp_env("LDPC_TEAM_ROWS")) d->team_rows_on = std::atoi(e) != 0;
 
@@ -1167,7 +1193,7 @@ static bool team_geometry(ldpc_bp_decoder *d, bool want_llr, int *per_xcd, int *
 constexpr int kTeamRowsMax = 312;
 
 static bool team_rows_possible(const ldpc_bp_decoder *d) { return d->team_rows_on && !d->h_csc2csr.empty() && !d->wpt_fixed; }
-static bool team_irr_possible(const ldpc_bp_decoder *d) { return d->team_rows_on && !d->h_row_ptr.empty() && !d->wpt_fixed && d->max_cdeg <= 16; }   // (pick_team_kernel_irr: no 32-wide bucket)
+static bool team_irr_possible(const ldpc_bp_decoder *d) { return d->team_rows_on && !d->h_row_ptr.empty() && !d->wpt_fixed && d->irr_dcb > 0; }
 
 // What the team plan depends on (pure data: ldpc_debug_team_plan() plans without a device for a CPU test)
 struct TeamPlanIn {
@@ -1548,7 +1574,7 @@ static ldpc_status team_irr_build(ldpc_bp_decoder *d, int G)
 {
     if (d->irr_G == G) return LDPC_OK;
     const TeamIrrTables t = team_irr_tables((int)d->n, (int)d->s, (int)d->nnz, d->h_row_ptr, d->h_edge_bit, d->h_col_ptr, d->h_irr_c2r, G,
-                                            team_bucket_dc(d->max_cdeg), team_bucket_dv(d->max_bdeg));
+                                            d->irr_dcb, team_bucket_dv(d->max_bdeg));
     auto up = [&](DevBuf &b, const std::vector<int> &v) -> ldpc_status {
         ldpc_status r = b.ensure(std::max<size_t>(v.size() * 4, 4));
         if (r != LDPC_OK) return r;
@@ -1586,6 +1612,27 @@ extern "C" ldpc_status ldpc_debug_div_check(int64_t count, const double *num, co
     if (e == hipSuccess) e = hipMemcpy(out_ieee, dv + 3 * count, bytes, hipMemcpyDeviceToHost);
     (void)hipFree(dv);
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(LDPC_ERR_HIP, std::string("ldpc_debug_div_check: ") + hipGetErrorString(e)); }
+    return LDPC_OK;
+}
+
+extern "C" ldpc_status ldpc_debug_llr_check(int64_t count, const double *odds, double *out_fast, double *out_lib)
+{
+    if (count < 0 || (count > 0 && (!odds || !out_fast || !out_lib))) return fail(LDPC_ERR_INVALID_ARGUMENT, "bad argument");
+    if (count == 0) return LDPC_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return fail(LDPC_ERR_NO_DEVICE, "no HIP device available"); }
+    const size_t bytes = (size_t)count * sizeof(double);
+    double *dv = nullptr;
+    HIP_TRY(hipMalloc((void **)&dv, 3 * bytes));
+    hipError_t e = hipMemcpy(dv, odds, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(llr_check_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, nullptr, dv, dv + count, dv + 2 * count, (long long)count);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out_fast, dv + count, bytes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_lib, dv + 2 * count, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(dv);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(LDPC_ERR_HIP, std::string("ldpc_debug_llr_check: ") + hipGetErrorString(e)); }
     return LDPC_OK;
 }
 
@@ -1658,11 +1705,12 @@ static bool team_fit(const TeamPlanIn &in, int64_t ntiles, bool rows, int *xcds,
     // iterations, teams against the tile kernel: n = 40960, 80 MiB a slot: 16,384 syndromes 693 against 874 ms, 65,536
     // syndromes 2.76 against 2.94 s; n = 49152: 874 against 1071 ms, 3.51 against 3.70 s).  Beyond that (n = 65536,
     // 128 MiB a slot: 4.96 against 4.85 s) the tile kernel stays.  (profiles/r03_midsize_plan.txt)
-    // (Graphs WITHOUT rows on chip -- irregular ones beyond what team_irr_tables() can credit, degree pairs without an
-    //  instantiation -- only up to a quarter over the budget: an irregular n = 32768 graph, 8 x 56 MiB of slots, 16,384
-    //  syndromes x 50 iterations: eight teams 570 ms, with whole checks in LDS 626 ms, the tile kernel 518 ms --
-    //  profiles/r04_irregular.txt.  Regular graphs with rows on chip get wide teams long before this: team_wide_auto().)
-    if (!in.xcds_forced && (size_t)8 * state <= (in.rows_possible ? cache / 10 * 33 : cache + cache / 4) && std::min(gcap, per_xcd) >= 3) {
+    // (Graphs WITHOUT rows on chip of this kind -- irregular ones, degree pairs without an instantiation -- stay inside
+    //  the budget: 16,384 syndromes x 50 iterations of an irregular n = 20480 graph, 8 x 35 MiB of slots: eight teams
+    //  381-392 ms, the tile kernel 319-328 ms, seven teams with whole checks in LDS 319 ms; n = 32768, 8 x 56 MiB: 570 /
+    //  626 ms against 518 ms -- profiles/r04_irregular.txt.  Regular graphs with rows on chip get wide teams long before
+    //  this: team_wide_auto().)
+    if (!in.xcds_forced && in.rows_possible && (size_t)8 * state <= cache / 10 * 33 && std::min(gcap, per_xcd) >= 3) {
         *xcds = 8; *tpx = 1; *G = std::min(gcap, per_xcd);
         return true;
     }
@@ -2272,7 +2320,7 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         const int *t_col = a_col, *t_c2r = a_c2r, *t_row = a_row;
         if (plan.irr && !team_scatter && team_irr_build(d, team) == LDPC_OK && d->irr_on_chip > 0) {
             // an irregular graph: whole checks in the LDS of their owners (bp_team_kernels.hpp, IRR)
-            team_kernel_t tki = pick_team_kernel_irr(d->max_cdeg, d->max_bdeg, want_llr);
+            team_kernel_t tki = pick_team_kernel_irr(d->irr_dcb, d->max_bdeg, want_llr);
             const size_t need = (size_t)d->irr_R * kTile * sizeof(double);
             int occ_irr = 0;
             if (tki && d->prepare_kernel((const void *)tki, LDPC_TEAM_THREADS, need, &occ_irr) == LDPC_OK && occ_irr >= 1) {
@@ -2408,7 +2456,8 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
                            (long long)batch, (int)n, d_err, (const int *)nullptr, (const unsigned int *)nullptr, 0u);
         HIP_TRY(hipGetLastError());
         if (want_llr) {
-            hipLaunchKernelGGL(unpack_llr_kernel, g, dim3(256), 0, stream, (const double *)d->llr_t.p,
+            const dim3 gl(g.x, (g.y + 7u) & ~7u);     // (unpack_llr_kernel deals the tiles over the XCDs in eights)
+            hipLaunchKernelGGL(unpack_llr_kernel, gl, dim3(256), 0, stream, (const double *)d->llr_t.p,
                                (long long)batch, (int)n, d_llr, (const int *)nullptr, (const unsigned int *)nullptr, 0u, llr_raw_out, d->llr_exact ? 1 : 0, llr_posmap);
             HIP_TRY(hipGetLastError());
         }
@@ -2419,7 +2468,8 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
                                (const unsigned int *)lv[l].count, lv[l].node_take);
             HIP_TRY(hipGetLastError());
             if (want_llr) {
-                hipLaunchKernelGGL(unpack_llr_kernel, g2, dim3(256), 0, stream, (const double *)d->lvl_llr[l - 1].p,
+                const dim3 gl2(g2.x, (g2.y + 7u) & ~7u);
+                hipLaunchKernelGGL(unpack_llr_kernel, gl2, dim3(256), 0, stream, (const double *)d->lvl_llr[l - 1].p,
                                    (long long)0, (int)n, d_llr, (const int *)d->lvl_list[l - 1].p,
                                    (const unsigned int *)lv[l].count, lv[l].node_take, 0, 0, (const int *)nullptr);
                 HIP_TRY(hipGetLastError());

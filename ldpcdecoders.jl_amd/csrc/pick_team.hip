@@ -46,7 +46,7 @@ team_kernel_t irr_pick_dc(int dc, int dv)
 {
     if (dc <= 8) return irr_pick_dv<8, LLR>(dv);
     if (dc <= 16) return irr_pick_dv<16, LLR>(dv);
-    return nullptr;   // (checks of 17 ... 32 edges: the 32-wide bucket on generic pointers spills -- such graphs keep every row in the slot)
+    return nullptr;   // (the 32-wide bucket on generic pointers spills: the host asks for 8 or 16 -- team_irr_dc_bucket(), ldpc_mi355x.hip)
 }
 }  // namespace
 team_kernel_t pick_team_kernel_irr(int dc, int dv, bool llr) { return llr ? irr_pick_dc<true>(dc, dv) : irr_pick_dc<false>(dc, dv); }

@@ -271,6 +271,9 @@ def _irregular_graph(n, s, seed):
         rows.append(5); cols.append(int(j))
     for i in rng.choice(s, 19, replace=False):
         rows.append(int(i)); cols.append(9)
+    for i in rng.choice(s, 6, replace=False):           # six checks of some 20 edges (the 16-wide bucket's two halves)
+        for j in rng.choice(n, 13, replace=False):
+            rows.append(int(i)); cols.append(int(j))
     H = sp.csc_matrix((np.ones(len(rows), dtype=np.uint8), (rows, cols)), shape=(s, n))
     H.sum_duplicates()
     H.data[:] = 1
@@ -286,6 +289,8 @@ def test_irregular_graph_keeps_whole_checks_in_lds(ldpc, gpu, per):
     (LLRs included) and against the oracle on a sample, above and below the graph's threshold."""
     n, s, batch = 16384, 8192, 16384
     H = _irregular_graph(n, s, seed=2024)
+    cdeg = np.diff(H.tocsr().indptr)
+    assert int(((cdeg > 16) & (cdeg <= 32)).sum()) >= 6 and int((cdeg > 32).sum()) == 1     # both wide-check paths of the IRR kernel
     syn_h = ldpc.codes.syndromes_of(H, ldpc.codes.random_errors(n, batch, per, seed=int(per * 1000)))
     syn = torch.from_numpy(syn_h).cuda()
     res = {}

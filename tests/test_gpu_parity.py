@@ -554,6 +554,45 @@ def test_one_handle_driven_from_two_streams_alternately(ldpc, gpu):
         dec.close()
 
 
+def test_llrs_from_the_cut_odds_without_the_library_log(ldpc, gpu):
+    """bp_kernels.hpp llr_cut: log_probabs[j] = log(1 / T) (belief_propagation.jl:163) from the posterior odds cut to 21
+    significant bits, by frexp, one division and seven terms of 2 atanh instead of a division and the library's log (the
+    decoder that turns the team kernel's captured odds into LLRs was bound by those).  On the device, over everything a
+    double can be: against the library's log(1 / .) of the same cut odds to 1e-12 -- end cases (+Inf wherever 1 / T
+    overflows, -Inf, NaN) identical --, and against log(1 / T) of the odds themselves to the 5e-7 the headers promise (2e-6 for denormal odds)."""
+    rng = np.random.default_rng(163)
+    L = ldpc._capi.lib()
+    bits = rng.integers(0, 0x7FF0_0000_0000_0000, size=3_000_000, dtype=np.uint64)          # every exponent, denormals too
+    T = np.concatenate([bits.view(np.float64), np.exp(rng.normal(0, 4, 1_000_000)), 1.0 + rng.normal(0, 1e-4, 200_000),
+                        2.0 ** np.arange(-1074, 1024, dtype=np.float64), np.nextafter(2.0 ** np.arange(-1022, 1024, dtype=np.float64), 0),
+                        [0.0, 5e-324, 2.0 ** -1024, np.nextafter(2.0 ** -1024, 0), np.nextafter(2.0 ** -1024, 1), 2.0 ** -1023, 1.0,
+                         np.sqrt(0.5), np.sqrt(2.0), np.nextafter(1.0, 0), np.nextafter(1.0, 2), 1.7976931348623157e308, np.inf, np.nan]])
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    fast = np.empty_like(T); lib = np.empty_like(T)
+    ldpc._capi.check(L.ldpc_debug_llr_check(T.size, T.ctypes.data, fast.ctypes.data, lib.ctypes.data), L)
+    fin = np.isfinite(lib)
+    assert np.array_equal(np.isnan(fast), np.isnan(lib)) and np.array_equal(fast[~fin & ~np.isnan(lib)], lib[~fin & ~np.isnan(lib)])
+    assert np.all(np.isfinite(fast[fin]))
+    worst = float(np.max(np.abs(fast[fin] - lib[fin])))
+    assert worst <= 1e-12, worst
+    with np.errstate(all="ignore"):
+        ref = np.log(1.0 / T)                         # the reference's own expression on the uncut odds
+    # (the one place where the cut shows in the end cases: 1 / T overflows for T <= 2^-1024 (1 + 2^-53), the cut puts half a
+    #  step of 2^-20 back on, so the odds of the lowest step from 2^-1024 on get a finite LLR of 709.78 -- outside this check)
+    band = (T >= 2.0 ** -1024) & (T < 2.0 ** -1024 * (1 + 2.0 ** -20))
+    rfin = np.isfinite(ref)
+    ends = ~rfin & ~np.isnan(ref) & ~band
+    assert np.array_equal(rfin[~band], fin[~band]) and np.array_equal(fast[ends], ref[ends])
+    rfin &= ~band
+    norm = rfin & (T >= 2.0 ** -1022)
+    worst_ref = float(np.max(np.abs(fast[norm] - ref[norm])))
+    assert worst_ref <= 5e-7, worst_ref
+    # (denormal odds with a finite LLR, 2^-1024 <= T < 2^-1022, LLR 708.4 ... 709.8: the upper 32 bits hold 18-19 of their
+    #  significant bits, not 21)
+    den = rfin & ~norm
+    assert den.any() and float(np.max(np.abs(fast[den] - ref[den]))) <= 2e-6
+
+
 def test_short_division_equals_the_ieee_division_where_the_kernels_take_it(ldpc, gpu):
     """bp_kernels.hpp div_core (LDPC_FAST_DIV): hipcc's double division without v_div_scale / v_div_fixup, taken by
     the check sweep for 2 / (1 + m) with 1 <= 1 + m < 2^500 and for (1 - t) / (1 + t) with |t| < 1.  On the device,
@@ -620,3 +659,24 @@ def test_llr_precision_is_a_decoder_option_and_the_same_in_every_kernel(ldpc, gp
                     assert np.array_equal(seen.view(np.int64), llr.view(np.int64)), (variant, exact)
             if not exact and fin.any():
                 assert float(np.max(np.abs(seen[fin] - ollr[fin]))) > 0.0   # (it IS a cut: not the exact logarithm)
+
+
+def test_the_one_team_of_an_xcd_takes_all_its_cus_by_default(ldpc, gpu):
+    """ldpc_mi355x.hip team_geometry(): a persistent team that has an XCD to itself gets all 32 CUs down to 1100 message rows a
+    member (kTeamMinRowsOne), not only as many members as keep 2048 rows each -- the plan of (4,8)-regular codes between
+    n = 9216 and n = 12288.  Through the DEFAULT path (no LDPC_TEAM_MIN_ROWS: the fuzz tool's tiny-graph setting switches
+    this rule off), n = 10240 (1280 rows a member), against the oracle, LLRs included."""
+    n = 10240
+    H = ldpc.codes.parity_check_csc(n, 8, 4)
+    syn = ldpc.codes.syndromes_of(H, ldpc.codes.random_errors(n, 1000, 0.05, seed=10240))
+    dec = ldpc.BeliefPropagationDecoder(H, 0.05, 25)
+    err, conv, llr, its = dec.decode_batch_host(syn, want_llr=True, want_iters=True)
+    info = dec.info()
+    assert info.last_kernel == 4 and info.last_team_size == 32 and info.resident_tiles == 8 * 32, (info.last_kernel, info.last_team_size, info.resident_tiles)
+    assert info.last_rows_on_chip >= 0.9 * H.nnz // 4
+    dec.close()
+    oc = BPOracle(csc=(H.indptr, H.indices), shape=H.shape, per=0.05, max_iters=25)
+    oerr, oconv, ollr, oits = oc.batchdecode(syn[:300])
+    assert np.array_equal(err[:300], oerr) and np.array_equal(conv[:300], oconv) and np.array_equal(its[:300], oits)
+    fin = np.isfinite(ollr)
+    assert np.array_equal(llr[:300][~fin], ollr[~fin]) and np.max(np.abs(llr[:300][fin] - ollr[fin])) <= 1e-6

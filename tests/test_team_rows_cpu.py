@@ -207,11 +207,12 @@ def test_team_plan_by_graph_and_batch():
     # 64 MiB slots (n = 32768): eight of them are twice the cache.  With rows on chip (46 MiB a slot) FOUR fit: four WIDE
     # teams of 64 members each, dealt over all XCDs (round 4: 442 ms for 16,384 syndromes x 50 iterations against 496 ms
     # for one persistent team per XCD); a graph without rows on chip goes to the HBM-streaming tile kernel (an irregular
-    # graph of that size: eight partly cached teams 570 ms, the tile kernel 518 ms), teams only while eight whole slots
-    # miss the budget by less than a quarter (n = 20480: 8 x 40 MiB)
+    # graph of that size: eight partly cached teams 570 ms, the tile kernel 518 ms), teams only while seven whole slots
+    # are inside the budget (an irregular n = 20480 graph, 8 x 35 MiB: eight teams 381-392 ms, the tile kernel 319-328 ms)
     assert plan(131072, 65536) == dict(members=64, teams=4, grid=256, xcds=8, scatter=1, rows=1)
     assert plan(131072, 65536, regular=0)["members"] == 1
-    assert plan(81920, 65536, regular=0)["members"] == 1 and plan(73728, 65536, regular=0) == dict(members=32, teams=8, grid=256, xcds=8, scatter=0, rows=0)
+    assert plan(81920, 65536, regular=0)["members"] == 1 and plan(73728, 65536, regular=0)["members"] == 1
+    assert plan(69632, 65536, regular=0) == dict(members=32, teams=7, grid=256, xcds=7, scatter=0, rows=0)      # 7 x 34 MiB
     # 128 MiB slots (n = 65536; 96 MiB with a quarter of the rows on chip): TWO wide teams of 128 (910 ms against the
     # tile kernel's 1238 ms); without rows on chip the tile kernel for more tiles than CUs, one team per tile below
     assert plan(262144, 65536) == dict(members=128, teams=2, grid=256, xcds=8, scatter=1, rows=1)

@@ -50,12 +50,30 @@ while time.time() - t0 < budget and cases < MAXCASES:
     elif kind == 4:    # regular with a rows-on-chip instantiation, large enough for the waves of a small team to own chunks
         wr, wc = int(rng.integers(6, 11)), int(rng.integers(3, 6))       # (round 4: every pair of check degree 6 ... 10 x bit degree 3 ... 5)
         big = rng.random() < 0.12
-        if big:        # >= 35,200 message rows: the plan's own rules apply (no LDPC_TEAM_MIN_ROWS): the one team of an XCD takes all its CUs
+        irr = (not big) and rng.random() < 0.25
+        if irr:        # irregular, large enough for small teams: whole checks in the LDS of their owners (IRR), a few checks of 17 ... 32
+            #            edges (two halves of the 16-wide code) and now and then one beyond 32 (the O(deg^2) path)
+            n = int(rng.integers(1200, 4000)); s_ = n // 2
+            rows_, cols_ = [], []
+            for j in range(n):
+                for i in rng.choice(s_, int(rng.integers(2, 6)), replace=False):
+                    rows_.append(int(i)); cols_.append(j)
+            for i in rng.choice(s_, int(rng.integers(0, 6)), replace=False):
+                for j in rng.choice(n, int(rng.integers(10, 24)), replace=False):
+                    rows_.append(int(i)); cols_.append(int(j))
+            if rng.random() < 0.4:
+                i = int(rng.integers(0, s_))
+                for j in rng.choice(n, 40, replace=False):
+                    rows_.append(i); cols_.append(int(j))
+            H = sp.csc_matrix((np.ones(len(rows_), dtype=np.uint8), (rows_, cols_)), shape=(s_, n))
+            H.sum_duplicates(); H.data[:] = 1
+        elif big:      # >= 35,200 message rows: the plan's own rules apply (no LDPC_TEAM_MIN_ROWS): the one team of an XCD takes all its CUs
             n = wr * int(rng.integers(36000 // (wr * wc) + 1, 50000 // (wr * wc)))
             n -= n % (wr * 4)   # (so that n * wc / wr is whole and the Gallager blocks divide)
         else:
             n = wr * int(rng.integers(150, 500))
-        H = ldpc.codes.parity_check_csc(n, wr, wc, seed=int(rng.integers(1 << 30)))
+        if not irr:
+            H = ldpc.codes.parity_check_csc(n, wr, wc, seed=int(rng.integers(1 << 30)))
         mid = True
     else:              # irregular random, with empty and heavy nodes now and then
         s, n = int(rng.integers(1, 80)), int(rng.integers(1, 160))
