@@ -651,7 +651,7 @@ def main():
                                "sharded_matches_local": verified}
         if not args.no_cpu_baseline and shards == 1 and not bposd_workload:
             cores = max(1, min(len(os.sched_getaffinity(0)), 16))   # a one-GPU box grants 16 cores
-            k_edge = min(batch, 2048)
+            k_edge = min(batch, 4096)       # (the gate of a reported C3 number is >= 4,096 syndromes)
             h_syn, h_err, h_conv, h_it = (t[:k_edge].cpu().numpy() for t in (syn0, err, conv, iters))
             e_rate, e_done, e_ok = cpu_baseline_edge_list(H, per, max_iters, h_syn, h_err, h_conv, h_it, cores)
             k_dense = min(batch, 64)

@@ -931,47 +931,77 @@ __global__ void __launch_bounds__(512, 6) placement_probe_kernel(double *base, l
 // syndrome index[q] of the batch, and there are *count_dev of them -- unless that is at most
 // count_skip, in which case the tile-kernel second pass does not run at all (the node-parallel
 // kernel decodes those few syndromes straight from / into the caller's arrays).
+// V = 4: a lane takes four consecutive checks (bits) -- one 4-byte load (store) per syndrome instead of four single bytes, a
+// wave 256 contiguous bytes per instruction instead of 64 --; the host picks it when s (n) is a multiple of 4 and the
+// caller's array is 4-byte aligned, V = 1 otherwise.
+template <int V>
 __global__ void __launch_bounds__(64) pack_syndromes_kernel(const unsigned char *syn, long long batch,
                                                             int s, u64 *synmask, u64 *nevermask,
                                                             const int *index, const unsigned int *count_dev,
                                                             unsigned int count_skip)
 {
+    static_assert(V == 1 || V == 4, "one check or four per lane");
     if (count_dev) { batch = (long long)*count_dev; if (batch <= (long long)count_skip) return; }
     const int tile = blockIdx.y;
-    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int i = (blockIdx.x * 64 + threadIdx.x) * V;
     const long long b0 = (long long)tile * kTile;
     if (b0 >= batch) return;
     const int rows = (int)((batch - b0) < kTile ? (batch - b0) : kTile);
-    u64 m = 0, hi = 0;
+    u64 m[V], hi = 0;
+#pragma unroll
+    for (int q = 0; q < V; ++q) m[q] = 0;
     if (i < s) {
+#pragma unroll 8
         for (int rr = 0; rr < rows; ++rr) {
             const long long b = index ? (long long)index[b0 + rr] : b0 + rr;
-            unsigned v = syn[(size_t)b * s + i];
-            m |= (u64)(v & 1u) << rr;
-            hi |= (u64)(v > 1u) << rr;
+            if constexpr (V == 4) {
+                const unsigned v = *(const unsigned *)(syn + (size_t)b * s + i);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned c = (v >> (8 * q)) & 0xffu;
+                    m[q] |= (u64)(c & 1u) << rr;
+                    hi |= (u64)(c > 1u) << rr;
+                }
+            } else {
+                const unsigned v = syn[(size_t)b * s + i];
+                m[0] |= (u64)(v & 1u) << rr;
+                hi |= (u64)(v > 1u) << rr;
+            }
         }
-        synmask[(size_t)tile * s + i] = m;
+#pragma unroll
+        for (int q = 0; q < V; ++q) synmask[(size_t)tile * s + i + q] = m[q];
     }
     hi = wave_or(hi);
     if (threadIdx.x == 0 && hi) atomicOr(&nevermask[tile], hi);
 }
 
-// unpack: errmask[tile][n] -> errors uint8 [batch][n]; one wave per (tile, 64 bits)
+// unpack: errmask[tile][n] -> errors uint8 [batch][n]; one wave per (tile, 64 V bits)
+template <int V>
 __global__ void __launch_bounds__(64) unpack_errors_kernel(const u64 *errmask, long long batch, int n,
                                                            unsigned char *errors, const int *index,
                                                            const unsigned int *count_dev, unsigned int count_skip)
 {
+    static_assert(V == 1 || V == 4, "one bit or four per lane");
     if (count_dev) { batch = (long long)*count_dev; if (batch <= (long long)count_skip) return; }
     const int tile = blockIdx.y;
-    const int j = blockIdx.x * 64 + threadIdx.x;
+    const int j = (blockIdx.x * 64 + threadIdx.x) * V;
     const long long b0 = (long long)tile * kTile;
     if (b0 >= batch) return;
     const int rows = (int)((batch - b0) < kTile ? (batch - b0) : kTile);
     if (j >= n) return;
-    const u64 m = errmask[(size_t)tile * n + j];
+    u64 m[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) m[q] = errmask[(size_t)tile * n + j + q];
+#pragma unroll 8
     for (int rr = 0; rr < rows; ++rr) {
         const long long b = index ? (long long)index[b0 + rr] : b0 + rr;
-        errors[(size_t)b * n + j] = (unsigned char)((m >> rr) & 1ull);
+        if constexpr (V == 4) {
+            const unsigned v = (unsigned)((m[0] >> rr) & 1ull) | (unsigned)((m[1] >> rr) & 1ull) << 8 |
+                               (unsigned)((m[2] >> rr) & 1ull) << 16 | (unsigned)((m[3] >> rr) & 1ull) << 24;
+            *(unsigned *)(errors + (size_t)b * n + j) = v;
+        } else {
+            errors[(size_t)b * n + j] = (unsigned char)((m[0] >> rr) & 1ull);
+        }
     }
 }
 

@@ -2210,9 +2210,11 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     d->ctrl_clean[slot] = false;
     HIP_TRY(hipMemsetAsync(d->nevermask.p, 0, (size_t)ntiles * sizeof(u64), stream));
     HIP_TRY(hipEventRecord(ev[0], stream));
+    // four checks (bits) per lane in the pack / unpack kernels where the caller's arrays allow 4-byte accesses
+    const bool syn_v4 = s % 4 == 0 && ((uintptr_t)d_syn & 3u) == 0, err_v4 = n % 4 == 0 && ((uintptr_t)d_err & 3u) == 0;
     if (s > 0) {
-        dim3 g((unsigned)((s + 63) / 64), (unsigned)ntiles);
-        hipLaunchKernelGGL(pack_syndromes_kernel, g, dim3(64), 0, stream, d_syn, (long long)batch, (int)s,
+        dim3 g((unsigned)((s + (syn_v4 ? 255 : 63)) / (syn_v4 ? 256 : 64)), (unsigned)ntiles);
+        hipLaunchKernelGGL(syn_v4 ? pack_syndromes_kernel<4> : pack_syndromes_kernel<1>, g, dim3(64), 0, stream, d_syn, (long long)batch, (int)s,
                            (u64 *)d->synmask.p, (u64 *)d->nevermask.p, (const int *)nullptr,
                            (const unsigned int *)nullptr, 0u);
         HIP_TRY(hipGetLastError());
@@ -2414,8 +2416,8 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         Level &L = lv[l];
         const u64 *l_syn = (const u64 *)d->lvl_syn[l - 1].p, *l_nev = (const u64 *)d->lvl_never[l - 1].p;
         if (s > 0) {
-            dim3 g((unsigned)((s + 63) / 64), (unsigned)L.cap_tiles);
-            hipLaunchKernelGGL(pack_syndromes_kernel, g, dim3(64), 0, stream, d_syn, (long long)0, (int)s,
+            dim3 g((unsigned)((s + (syn_v4 ? 255 : 63)) / (syn_v4 ? 256 : 64)), (unsigned)L.cap_tiles);
+            hipLaunchKernelGGL(syn_v4 ? pack_syndromes_kernel<4> : pack_syndromes_kernel<1>, g, dim3(64), 0, stream, d_syn, (long long)0, (int)s,
                                (u64 *)d->lvl_syn[l - 1].p, (u64 *)d->lvl_never[l - 1].p, (const int *)d->lvl_list[l - 1].p,
                                (const unsigned int *)L.count, L.node_take);
             HIP_TRY(hipGetLastError());
@@ -2452,7 +2454,8 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
     // ---- results out: level 0 first, then every level over the rows its lower levels gave up
     if (n > 0) {
         dim3 g((unsigned)((n + 63) / 64), (unsigned)ntiles);
-        hipLaunchKernelGGL(unpack_errors_kernel, g, dim3(64), 0, stream, (const u64 *)d->finmask.p,
+        const dim3 ge((unsigned)((n + (err_v4 ? 255 : 63)) / (err_v4 ? 256 : 64)), (unsigned)ntiles);
+        hipLaunchKernelGGL(err_v4 ? unpack_errors_kernel<4> : unpack_errors_kernel<1>, ge, dim3(64), 0, stream, (const u64 *)d->finmask.p,
                            (long long)batch, (int)n, d_err, (const int *)nullptr, (const unsigned int *)nullptr, 0u);
         HIP_TRY(hipGetLastError());
         if (want_llr) {
@@ -2463,7 +2466,8 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
         }
         for (int l = 1; l <= nlevels; ++l) {
             dim3 g2((unsigned)((n + 63) / 64), (unsigned)lv[l].cap_tiles);
-            hipLaunchKernelGGL(unpack_errors_kernel, g2, dim3(64), 0, stream, (const u64 *)d->lvl_fin[l - 1].p,
+            const dim3 ge2((unsigned)((n + (err_v4 ? 255 : 63)) / (err_v4 ? 256 : 64)), (unsigned)lv[l].cap_tiles);
+            hipLaunchKernelGGL(err_v4 ? unpack_errors_kernel<4> : unpack_errors_kernel<1>, ge2, dim3(64), 0, stream, (const u64 *)d->lvl_fin[l - 1].p,
                                (long long)0, (int)n, d_err, (const int *)d->lvl_list[l - 1].p,
                                (const unsigned int *)lv[l].count, lv[l].node_take);
             HIP_TRY(hipGetLastError());

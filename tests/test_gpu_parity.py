@@ -554,6 +554,39 @@ def test_one_handle_driven_from_two_streams_alternately(ldpc, gpu):
         dec.close()
 
 
+@pytest.mark.parametrize("n,shift", [(1008, 0), (1008, 1), (1008, 2), (222, 0), (222, 3)])
+def test_device_arrays_of_any_alignment(ldpc, gpu, n, shift):
+    """The pack / unpack kernels of the tile and team kernels take four checks (bits) per lane where the caller's device
+    arrays allow 4-byte accesses (s, n multiples of 4 and 4-byte aligned pointers) and one per lane otherwise
+    (ldpc_mi355x.hip syn_v4 / err_v4): syndromes and decisions at odd addresses and an n that is no multiple of 4, a ragged
+    batch, through the HBM-streaming and the team kernel, against the oracle.  (batchdecode! takes any matrix:
+    belief_propagation.jl:220-231.)"""
+    import torch
+
+    H = ldpc.codes.parity_check_csc(n, 6, 3)
+    s_ = H.shape[0]
+    B, per, iters = 200, 0.03, 20
+    syn_h = ldpc.codes.syndromes_of(H, ldpc.codes.random_errors(n, B, per, seed=n + shift))
+    oc = BPOracle(csc=(H.indptr, H.indices), shape=H.shape, per=per, max_iters=iters)
+    oerr, oconv, ollr, oits = oc.batchdecode(syn_h, want_llr=True)
+    sbuf = torch.zeros(B * s_ + 8, dtype=torch.uint8, device="cuda"); ebuf = torch.full((B * n + 8,), 7, dtype=torch.uint8, device="cuda")
+    syn = sbuf[shift:shift + B * s_].view(B, s_); err = ebuf[shift:shift + B * n].view(B, n)
+    syn.copy_(torch.from_numpy(syn_h).cuda())
+    assert syn.data_ptr() % 4 == shift % 4 and err.data_ptr() % 4 == shift % 4
+    for variant in (1, 4):
+        dec = ldpc.BeliefPropagationDecoder(H, per, iters, kernel_variant=variant)
+        conv = torch.empty(B, dtype=torch.uint8, device="cuda"); its = torch.empty(B, dtype=torch.int32, device="cuda")
+        llr = torch.empty((B, n), dtype=torch.float64, device="cuda")
+        ebuf.fill_(7)
+        dec.decode_batch_device(syn, err, conv, llr, its)
+        dec.last_status()
+        assert np.array_equal(err.cpu().numpy(), oerr) and np.array_equal(conv.cpu().numpy(), oconv) and np.array_equal(its.cpu().numpy(), oits), variant
+        assert bool((ebuf[:shift] == 7).all()) and bool((ebuf[shift + B * n:] == 7).all()), "bytes outside the caller's array written"
+        g = llr.cpu().numpy(); fin = np.isfinite(ollr)
+        assert np.array_equal(g[~fin], ollr[~fin]) and np.max(np.abs(g[fin] - ollr[fin])) <= LLR_TOL
+        dec.close()
+
+
 def test_llrs_from_the_cut_odds_without_the_library_log(ldpc, gpu):
     """bp_kernels.hpp llr_cut: log_probabs[j] = log(1 / T) (belief_propagation.jl:163) from the posterior odds cut to 21
     significant bits, by frexp, one division and seven terms of 2 atanh instead of a division and the library's log (the
