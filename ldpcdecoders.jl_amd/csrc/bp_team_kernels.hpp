@@ -256,6 +256,9 @@ constexpr int kTeamCtlMember = 64;                                  // first mem
 constexpr int kTeamCtlWords = 64 + 32 * kTeamMaxMembers;            // per team
 constexpr int kTeamCheckChunk = 2;                                  // checks per chunk of the check sweep
 
+#ifndef LDPC_TEAM_BARRIER_COUNTER
+#define LDPC_TEAM_BARRIER_COUNTER 0
+#endif
 __device__ __forceinline__ bool team_barrier(unsigned int *ctl, int G, int rank, unsigned int k, unsigned int *fault,
                                              unsigned int ticket, int *sh_ok, bool one_xcd, unsigned int *sh_deal)
 {
@@ -268,14 +271,22 @@ __device__ __forceinline__ bool team_barrier(unsigned int *ctl, int G, int rank,
         }
         int ok = 1;
         const unsigned int prev = __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (Experiment, -DLDPC_TEAM_BARRIER_COUNTER=1: a team inside one XCD -- one L2 -- waits on the arrival counter
+        // itself, so that the last arrival is seen one round trip earlier than through a flag the last member writes for
+        // everybody after its own fetch_add has come back.  Measured SLOWER, round 4, alternating builds on one box: C3
+        // full-50 720.9 / 721.0 against 713.4 / 714.3 ms, (3,6) n = 16380 514.9 against 505.3 ms -- 31 pollers on the line
+        // hold up the 32 adds more than the round trip saves.  Off.)
+        const bool on_counter = LDPC_TEAM_BARRIER_COUNTER && one_xcd;
         if (prev + 1u == k * (unsigned)G) {
-            for (int m = 0; m < G; ++m)
-                __hip_atomic_store(ctl + kTeamCtlMember + 32 * m, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!on_counter)
+                for (int m = 0; m < G; ++m)
+                    __hip_atomic_store(ctl + kTeamCtlMember + 32 * m, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            unsigned int *mine = ctl + kTeamCtlMember + 32 * rank;
+            unsigned int *mine = on_counter ? ctl : ctl + kTeamCtlMember + 32 * rank;
+            const unsigned int want = on_counter ? k * (unsigned)G : k;
             const u64 t0 = wall_clock64();
             unsigned int polls = 0;
-            while (__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k) {
+            while (__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                 __builtin_amdgcn_s_sleep(LDPC_TEAM_SLEEP);
                 // the fault word lives in HOST memory (a poll of it is a PCIe read: 256 pollers doing that every
                 // turn tripled the barrier time) -- look at it, and at the clock, once in 256 turns
@@ -565,6 +576,10 @@ __device__ __forceinline__ void bit_update_multi_first(double *Mt, double *L, co
 // A check in LDS takes the ordinary update on a generic pointer (the hardware routes LDS and global accesses alike); a
 // bit with an edge in LDS takes bit_update_flat (a pointer per edge).  Nodes wider than the register buckets never
 // get rows in LDS (the host sees to it), so the O(deg^2) paths stay on the slot.
+#ifndef LDPC_TEAM_TEST_SPREAD
+#define LDPC_TEAM_TEST_SPREAD 1
+#endif
+
 template <int D>
 __device__ __forceinline__ double bit_update_exact_flat(double *Mt, double *L, const int *__restrict__ loc, double r)
 {
@@ -962,7 +977,15 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     //      the team ORs into mw[it_t - 1]
     auto run_test = [&](const int it_t, const u64 *em_t) {
         u64 mism = 0;
-        for (int i = gw * 64 + lane; i < s; i += GW * 64) {
+        // (a lane = a check, so s / 64 waves have work here -- at the C3 size half of a team's.  Counted member-minor: the
+        //  first waves of EVERY member rather than all the waves of the first members, so that no member comes late to
+        //  the sweep that follows as a whole -- its other waves take more of its dealt chunks meanwhile)
+#if LDPC_TEAM_TEST_SPREAD
+        const int gt = w * G + rank;
+#else
+        const int gt = gw;
+#endif
+        for (int i = gt * 64 + lane; i < s; i += GW * 64) {
             u64 par = 0;
             // (regular graphs of the rows-on-chip instantiations: check i's edges are rows DC i ... DC i + DC - 1 -- one
             //  dependent round trip less in front of the decision words)
