@@ -1273,9 +1273,15 @@ struct TeamRowTables {
     std::vector<int> vtab, ctab, lds_edge, reg_edge;
 };
 // the static part of a member's share under a plan: `frac_num / 4` of the smallest member's chunks, whole rounds of W
-static TeamRegPlan team_reg_plan(int n, int s, int G, int regs_per_wave, int quarters)
+static TeamRegPlan team_reg_plan(int n, int s, int G, int regs_per_wave, int quarters, int dv)
 {
     TeamRegPlan rp;
+    // Rows of checks that are only PARTLY on chip (a member's room beyond the whole checks of its block: 2-3 % of the
+    // rows) put those checks and their bits on the general per-edge updates.  Round 4, 65,536 syndromes x 50 iterations,
+    // alternating on one box, with them / whole checks only: bit degree 3 -- (3,6) n = 16380 505.2 / 491.2 ms, (3,9)
+    // 503.0 / 498.5 ms: whole checks only; bit degree 4 and 5 -- C3 703.6 / 706.5 ms, (4,10) 354.5 / 358.2 ms, (5,10)
+    // 488.9 / 493.4 ms: with them.  (profiles/r04_tform_ab.txt)
+    rp.whole_checks = dv == 3;
     const int W = rp.W;
     const int nch_c = (s + kTeamCheckChunk - 1) / kTeamCheckChunk, nch_v = (n + 3) / 4;
     const int min_c = nch_c / G, min_v = nch_v / G;           // the smallest member's share
@@ -1445,7 +1451,7 @@ extern "C" ldpc_status ldpc_debug_team_rows(int64_t s, int64_t n, const int64_t 
             c2r[(size_t)k] = (int)(dc * i + fill[(size_t)i]++);   // bits ascending inside a check, as ldpc_bp_create lays the rows out
         }
     }
-    const TeamRegPlan rp = team_reg_plan((int)n, (int)s, members, regs_per_wave, static_quarters);
+    const TeamRegPlan rp = team_reg_plan((int)n, (int)s, members, regs_per_wave, static_quarters, dv);
     const TeamRowTables t = team_rows_tables((int)n, (int)s, (int)nnz, dc, dv, c2r, members, rp);
     degrees[0] = dc; degrees[1] = dv;
     shape[0] = t.vt; shape[1] = t.R; shape[2] = rp.static_c; shape[3] = rp.static_v; shape[4] = rp.regs_per_wave;
@@ -1641,7 +1647,7 @@ static ldpc_status team_rows_build(ldpc_bp_decoder *d, int G)
     if (d->rows_G == G) return LDPC_OK;
     // (three quarters of a member's share dealt statically measured 1 % faster than dealing all but the first chunk from
     // the counter -- 873 against 883 ms on the full C3 batch --; rows in registers need it)
-    TeamRegPlan rp = team_reg_plan((int)d->n, (int)d->s, G, d->team_regs, d->team_static_quarters);
+    TeamRegPlan rp = team_reg_plan((int)d->n, (int)d->s, G, d->team_regs, d->team_static_quarters, d->rows_dv);
     if (const char *e = exp_env("LDPC_TEAM_CONCENTRATE")) { rp.concentrate = std::atoi(e) != 0; rp.whole_checks = std::atoi(e) == 2; }
     const TeamRowTables t = team_rows_tables((int)d->n, (int)d->s, (int)d->nnz, d->rows_dc, d->rows_dv, d->h_csc2csr, G, rp);
     auto up = [&](DevBuf &b, const std::vector<int> &v) -> ldpc_status {
