@@ -535,7 +535,10 @@ __device__ __forceinline__ void bit_update_pair_first(double *Mt, double *L, con
 
 // ... and NB bits at once (the four positions of a chunk): all NB (D - 1) slot rows in flight before anything is computed.
 // The variable sweep waits for scattered rows; a wave that asks for 6 of them at a time leaves the fabric idle.
-template <int D, int NB, bool TF, class RGet, class RPut>
+// KIND: where the first edges of ALL NB bits are -- 1: in LDS, 2: in this wave's registers, 0: anywhere (a wave-uniform
+// branch per bit and side).  The host fills a wave's register rows with the bits of whole position chunks
+// (team_rows_tables()), so nearly every chunk is of one kind and takes straight-line code.
+template <int D, int NB, bool TF, int KIND, class RGet, class RPut>
 __device__ __forceinline__ void bit_update_multi_first(double *Mt, double *L, const int (&pos)[NB][D], const int (&loc)[NB], double r,
                                                        RGet &&rget, RPut &&rput, double (&T)[NB])
 {
@@ -547,7 +550,9 @@ __device__ __forceinline__ void bit_update_multi_first(double *Mt, double *L, co
     }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        if (loc[b] == -1) c[b][0] = ldm(Mt + (size_t)pos[b][0] * kTile);
+        if (KIND == 1) c[b][0] = L[(size_t)loc[b] * kTile];
+        else if (KIND == 2) c[b][0] = rget(-2 - loc[b]);
+        else if (loc[b] == -1) c[b][0] = ldm(Mt + (size_t)pos[b][0] * kTile);
         else if (loc[b] >= 0) c[b][0] = L[(size_t)loc[b] * kTile];
         else c[b][0] = rget(-2 - loc[b]);
     }
@@ -559,7 +564,9 @@ __device__ __forceinline__ void bit_update_multi_first(double *Mt, double *L, co
         T[b] = bit_compute_exact<D>(c[b], r, o);
 #pragma unroll
         for (int k = D - 1; k >= 1; --k) stm(Mt + (size_t)pos[b][k] * kTile, o[k]);
-        if (loc[b] == -1) stm(Mt + (size_t)pos[b][0] * kTile, o[0]);
+        if (KIND == 1) L[(size_t)loc[b] * kTile] = o[0];
+        else if (KIND == 2) rput(true, -2 - loc[b], o[0]);
+        else if (loc[b] == -1) stm(Mt + (size_t)pos[b][0] * kTile, o[0]);
         else if (loc[b] >= 0) L[(size_t)loc[b] * kTile] = o[0];
         else rput(true, -2 - loc[b], o[0]);
     }
@@ -578,6 +585,30 @@ __device__ __forceinline__ void bit_update_multi_first(double *Mt, double *L, co
 // get rows in LDS (the host sees to it), so the O(deg^2) paths stay on the slot.
 #ifndef LDPC_TEAM_TEST_SPREAD
 #define LDPC_TEAM_TEST_SPREAD 1
+#endif
+#ifndef LDPC_TEAM_FAULT_BLOCKS   // the two early exits of the fault injection (tests): compiled into the experiments build
+#ifdef LDPC_EXPERIMENTS
+#define LDPC_TEAM_FAULT_BLOCKS 1
+#else
+#define LDPC_TEAM_FAULT_BLOCKS 0
+#endif
+#endif
+// Where the compiler puts the basic blocks of the sweeps matters by 2 %: the headline instantiation ran 725 ms as it was and
+// 709-713 ms under ANY of four small perturbations of the source (the experiments build's two early exits, these hints, both,
+// straight-line chunk kinds) -- round 4, alternating builds on one box, profiles/r04_tform_ab.txt.  The hints say what is
+// true -- nearly every chunk of either sweep is the usual one -- and measured best: C3 full-50 724.9 -> 709.0 ms, per 0.02
+// 50.2 -> 49.0 ms; (3,6) n = 16380 and (4,10) n = 16380 unchanged (+0.2 %).
+#ifndef LDPC_TEAM_LIKELY
+#define LDPC_TEAM_LIKELY 1
+#endif
+// (check degree 10 lost by them -- (5,10) n = 16000 491.2 against 487.2 ms, (4,10) 353.9 against 353.1 -- and stays without:
+//  kTeamHints in the kernel)
+#define LDPC_HOT(x) (kTeamHints ? __builtin_expect(!!(x), 1) : !!(x))
+// The four first edges of a position chunk all in LDS / all in this wave's registers: straight-line code for the chunk
+// (bit_update_multi_first<KIND>) instead of a wave-uniform branch per bit and side.  -1: for bit degree 3 only, where it
+// measured -1 % ((3,6) n = 16380: 490.4 against 494.6 ms); C3 +0.4 %, (4,10) +1 % slower with it.
+#ifndef LDPC_TEAM_CHUNK_KINDS
+#define LDPC_TEAM_CHUNK_KINDS -1
 #endif
 
 template <int D>
@@ -637,6 +668,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     static_assert(RR == 0 || (LROWS && RR == kTeamRegRows), "rows in registers come on top of the rows in LDS");
     static_assert(!IRR || (!LROWS && !RESUMED && RR == 0), "irregular graphs: whole checks in LDS, fresh tiles");
     constexpr int RS = IRR ? 2 : 1;   // stride of row_ptr / col_ptr entries (IRR: pairs, see above)
+    constexpr bool kTeamHints = (LDPC_TEAM_LIKELY != 0) && DC <= 9;   // (LDPC_HOT, above)
     // Where the division (1 - t) / (1 + t) of :147 is made (check_finish_exact): the rows-on-chip instantiations leave
     // it to the variable sweep.  A check costs 16 fp64 divisions (two per edge) and the check sweep of the persistent
     // teams is bound by them, not by the memory side; the variable sweep has no division at all and waits for its
@@ -671,7 +703,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     const double r = p.r;
     if (threadIdx.x == 0) { sh_deal[0] = 0u; sh_deal[1] = 0u; }
     __syncthreads();
-#ifdef LDPC_EXPERIMENTS
+#if LDPC_TEAM_FAULT_BLOCKS
     if (tp.inject_fault == 1) {
         if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(tp.fault, tp.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
@@ -699,7 +731,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     unsigned int *const tile_queue = tp.ctl + (size_t)nteams * kTeamCtlWords;
     unsigned int epoch = 0;                                    // barriers passed
     __shared__ int sh_one_xcd;
-#ifdef LDPC_EXPERIMENTS
+#if LDPC_TEAM_FAULT_BLOCKS
     if (tp.inject_fault == 2 && team == 0 && rank == G - 1) return;   // (tests) a member that never gets its CU
 #endif
     if (!team_rollcall(ctr + 36, G, tp.fault, tp.ticket, tp.rollcall_ticks, &sh_ok)) return;
@@ -769,7 +801,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
                     }
                 };
                 const int i = c * kTeamCheckChunk;
-                if (kTeamCheckChunk == 2 && i + 2 == i1) {
+                if (LDPC_HOT(kTeamCheckChunk == 2 && i + 2 == i1)) {
                     const v8i ct = *(const v8i *)(col_ptr + 4 * i);   // both checks' table rows in one scalar load
                     const u64 s0 = syn[i], s1 = syn[i + 1];
                     const double sg0 = ((s0 >> lane) & 1ull) ? -1.0 : 1.0, sg1 = ((s1 >> lane) & 1ull) ? -1.0 : 1.0;
@@ -906,21 +938,25 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
                     }
                 };
                 int q = j;
-                if (q + 4 == j1) {                          // the usual chunk: the table rows of all four positions at once
+                if (LDPC_HOT(q + 4 == j1)) {                // the usual chunk: the table rows of all four positions at once
                     const int *const vt = csc2csr + (size_t)q * VT;
                     const TeamVRec<DV> A = team_vrec_load<DV>(vt), B = team_vrec_load<DV>(vt + VT), C = team_vrec_load<DV>(vt + 2 * VT),
                                        D = team_vrec_load<DV>(vt + 3 * VT);
-                    if (tp.pairs & 2) {
+                    if (LDPC_HOT(tp.pairs & 2)) {
                         int rest = -1;                        // stays -1: the edges 1 ... DV-1 of all four are rows of the slot
 #pragma unroll
                         for (int k = 1; k < DV; ++k) rest &= A.lrow[k] & B.lrow[k] & C.lrow[k] & D.lrow[k];
-                        if (rest == -1) {
+                        if (LDPC_HOT(rest == -1)) {
                             int ps[4][DV];
 #pragma unroll
                             for (int k = 0; k < DV; ++k) { ps[0][k] = A.pos[k]; ps[1][k] = B.pos[k]; ps[2][k] = C.pos[k]; ps[3][k] = D.pos[k]; }
                             const int lc[4] = {A.lrow[0], B.lrow[0], C.lrow[0], D.lrow[0]};
                             double T[4];
-                            bit_update_multi_first<DV, 4, TF>(Mt, Lr, ps, lc, r, rget, rput, T);
+                            constexpr bool KINDS = LDPC_TEAM_CHUNK_KINDS < 0 ? DV == 3 : LDPC_TEAM_CHUNK_KINDS != 0;
+                            const int lmin = min(min(lc[0], lc[1]), min(lc[2], lc[3])), lmax = max(max(lc[0], lc[1]), max(lc[2], lc[3]));
+                            if (KINDS && RR > 0 && lmax <= -2) bit_update_multi_first<DV, 4, TF, 2>(Mt, Lr, ps, lc, r, rget, rput, T);
+                            else if (KINDS && lmin >= 0) bit_update_multi_first<DV, 4, TF, 1>(Mt, Lr, ps, lc, r, rget, rput, T);
+                            else bit_update_multi_first<DV, 4, TF, 0>(Mt, Lr, ps, lc, r, rget, rput, T);
                             decide(q, A.bit & 0x7fffffff, T[0], false);
                             decide(q + 1, B.bit & 0x7fffffff, T[1], false);
                             decide(q + 2, C.bit & 0x7fffffff, T[2], false);
