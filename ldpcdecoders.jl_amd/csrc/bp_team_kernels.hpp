@@ -806,7 +806,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
                     const u64 s0 = syn[i], s1 = syn[i + 1];
                     const double sg0 = ((s0 >> lane) & 1ull) ? -1.0 : 1.0, sg1 = ((s1 >> lane) & 1ull) ? -1.0 : 1.0;
                     double *const M0 = Mt + (size_t)i * DC * kTile, *const M1 = M0 + (size_t)DC * kTile;
-                    if ((ct.s0 | ct.s2 | ct.s4 | ct.s6) == 0 && !first && tp.pairs) {
+                    if ((ct.s0 | ct.s2 | ct.s4 | ct.s6) == 0 && !first && tp.pairs) {   // (a hint here: no difference)
                         check_update_pair<DC, TF>(M0, M1, sg0, sg1);
                     } else {
                         one(M0, v4i{ct.s0, ct.s1, ct.s2, ct.s3}, sg0);
