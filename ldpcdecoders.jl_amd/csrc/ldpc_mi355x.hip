@@ -1265,6 +1265,7 @@ struct TeamRegPlan {
     int W = LDPC_TEAM_THREADS / 64;
     bool concentrate = true;       // bits go to the owner of their first check where there is room (team_rows_tables())
     bool whole_checks = false;     // ... and only checks with ALL their rows on chip keep them there
+    bool strays_last = true;       // bits with a later edge on chip take a member's last positions (team_rows_tables(); LDPC_TEAM_STRAYS_LAST=0: by number)
 };
 struct TeamRowTables {
     int R = 0;                    // LDS rows per member (the largest count; kTeamRowsMax at most)
@@ -1273,7 +1274,7 @@ struct TeamRowTables {
     std::vector<int> vtab, ctab, lds_edge, reg_edge;
 };
 // the static part of a member's share under a plan: `frac_num / 4` of the smallest member's chunks, whole rounds of W
-static TeamRegPlan team_reg_plan(int n, int s, int G, int regs_per_wave, int quarters, int dv)
+static TeamRegPlan team_reg_plan(int n, int s, int G, int regs_per_wave, int quarters, int dv, int dc)
 {
     TeamRegPlan rp;
     // Rows of checks that are only PARTLY on chip (a member's room beyond the whole checks of its block: 2-3 % of the
@@ -1282,6 +1283,10 @@ static TeamRegPlan team_reg_plan(int n, int s, int G, int regs_per_wave, int qua
     // 503.0 / 498.5 ms: whole checks only; bit degree 4 and 5 -- C3 703.6 / 706.5 ms, (4,10) 354.5 / 358.2 ms, (5,10)
     // 488.9 / 493.4 ms: with them.  (profiles/r04_tform_ab.txt)
     rp.whole_checks = dv == 3;
+    // ... and where they stay, their bits take a member's last positions (team_rows_tables()): C3 full-50 702.5 -> 700.9 ms, per
+    // 0.02 49.1 -> 48.7 ms, with LLRs 739.8 -> 735.2 ms; check degree 10 lost by it ((4,10) 353.2 -> 354.5 ms, (5,10) 488.5 ->
+    // 491.4 ms) and keeps them dealt by number.
+    rp.strays_last = dc <= 9;
     const int W = rp.W;
     const int nch_c = (s + kTeamCheckChunk - 1) / kTeamCheckChunk, nch_v = (n + 3) / 4;
     const int min_c = nch_c / G, min_v = nch_v / G;           // the smallest member's share
@@ -1329,14 +1334,19 @@ static TeamRowTables team_rows_tables(int n, int s, int nnz, int dc, int dv, con
     for (int p = 0; p < n; ++p) pos_of[(size_t)((p / 4) % G)].push_back(p);
     for (int j = 0; j < n; ++j) bits_of[(size_t)member_of_bit[(size_t)j]].push_back(j);
     std::vector<int> bit((size_t)n, -1), reg_of((size_t)nnz, -1);
+    std::vector<std::vector<char>> placed_of((size_t)G);        // per member: which of bits_of[m] already have a position (register rows)
     std::vector<std::vector<int>> reg_rows((size_t)G * W);       // per (member, wave): the CSR rows held in registers
     // (whole checks: a wave's registers take a multiple of dc rows, so that no check is split between registers and LDS --
     //  a split check is all on chip and still pays the general update: 30 of 32 rows a wave for dc = 6 and 10)
     const int RCw = rp.concentrate ? RC / dc * dc : RC;
-    for (int m = 0; m < G; ++m) {
-        std::vector<std::vector<int>> spos((size_t)W);           // static positions of each wave, ascending, not yet taken
+    std::vector<std::vector<int>> reg_bits((size_t)G * W);      // ... and the bits those rows belong to (they get that wave's static positions)
+    auto static_positions = [&](int m) {                         // of each wave of member m, ascending
+        std::vector<std::vector<int>> spos((size_t)W);
         for (int p : pos_of[(size_t)m]) { const int w = pos_wave(p); if (w >= 0) spos[(size_t)w].push_back(p); }
-        std::vector<size_t> snext((size_t)W, 0);
+        return spos;
+    };
+    for (int m = 0; m < G; ++m) {
+        const std::vector<std::vector<int>> spos = static_positions(m);
         std::vector<char> placed(bits_of[(size_t)m].size(), 0);
         if (RC > 0)
             for (size_t b = 0; b < bits_of[(size_t)m].size(); ++b) {
@@ -1345,21 +1355,14 @@ static TeamRowTables team_rows_tables(int n, int s, int nnz, int dc, int dv, con
                     const int q = c2r[(size_t)dv * j + k], i = q / dc;
                     if (check_owner(i) != m) continue;
                     const int w = check_wave(i);
-                    if (w < 0 || (int)reg_rows[(size_t)m * W + w].size() >= RCw || snext[(size_t)w] >= spos[(size_t)w].size()) continue;
-                    bit[(size_t)spos[(size_t)w][snext[(size_t)w]++]] = j;
+                    if (w < 0 || (int)reg_rows[(size_t)m * W + w].size() >= RCw || reg_bits[(size_t)m * W + w].size() >= spos[(size_t)w].size()) continue;
+                    reg_bits[(size_t)m * W + w].push_back(j);
                     reg_rows[(size_t)m * W + w].push_back(q);
                     placed[b] = 1;
                     break;
                 }
             }
-        // the other bits fill the positions that are left, both in ascending order
-        size_t b = 0;
-        for (int p : pos_of[(size_t)m]) {
-            if (bit[(size_t)p] >= 0) continue;
-            while (b < placed.size() && placed[b]) ++b;
-            if (b >= placed.size()) std::abort();   // (cannot happen: a member has as many bits as positions)
-            bit[(size_t)p] = bits_of[(size_t)m][b++];
-        }
+        placed_of[(size_t)m] = std::move(placed);   // (positions are given out once the LDS rows are known: below)
     }
     // LDS candidates per member (check and bit share the owner, not in registers), in check order; the first kTeamRowsMax of each get rows
     std::vector<char> is_reg((size_t)nnz, 0);
@@ -1380,6 +1383,46 @@ static TeamRowTables team_rows_tables(int n, int s, int nnz, int dc, int dv, con
         auto partial = [&](int q) { return on_chip[(size_t)(q / dc)] < dc; };
         for (auto &v : reg_rows) v.erase(std::remove_if(v.begin(), v.end(), partial), v.end());
         for (auto &v : cand) v.erase(std::remove_if(v.begin(), v.end(), partial), v.end());
+    }
+    // The other bits fill the positions that are left, in ascending order -- first the bits with at most their FIRST edge on
+    // chip, then the "strays" (a later edge in LDS: the room a member has beyond the whole checks of its block).  A position
+    // chunk with one stray in it leaves the four-at-once update for the general one, and dealt by number the strays sat
+    // in a third of all chunks (30 ... 52 of a member's 128 at the C3 size, and the members with most were the slowest of
+    // every variable sweep); together they fill a tenth, at the upper end of the member's positions, which its waves deal
+    // among themselves.
+    {
+        std::vector<char> in_cand((size_t)nnz, 0);
+        for (auto &v : cand) for (int q : v) in_cand[(size_t)q] = 1;
+        auto is_stray = [&](int j) {
+            bool stray = false;
+            if (!rp.strays_last) return false;
+            for (int k = 1; k < dv; ++k) stray = stray || in_cand[(size_t)c2r[(size_t)dv * j + k]];
+            return stray;
+        };
+        for (int m = 0; m < G; ++m) {
+            // the bits with a row in a wave's registers: that wave's static positions, strays last as well
+            const std::vector<std::vector<int>> spos = static_positions(m);
+            for (int w = 0; w < W; ++w) {
+                size_t at = 0;
+                for (int pass = 0; pass < 2; ++pass)
+                    for (int j : reg_bits[(size_t)m * W + w])
+                        if ((int)is_stray(j) == pass) bit[(size_t)spos[(size_t)w][at++]] = j;
+            }
+            const std::vector<int> &bm = bits_of[(size_t)m];
+            const std::vector<char> &placed = placed_of[(size_t)m];
+            std::vector<int> order;
+            for (int pass = 0; pass < 2; ++pass)
+                for (size_t b = 0; b < bm.size(); ++b) {
+                    if (placed[b]) continue;
+                    if ((int)is_stray(bm[b]) == pass) order.push_back(bm[b]);
+                }
+            size_t b = 0;
+            for (int p : pos_of[(size_t)m]) {
+                if (bit[(size_t)p] >= 0) continue;
+                if (b >= order.size()) std::abort();   // (cannot happen: a member has as many bits as positions)
+                bit[(size_t)p] = order[b++];
+            }
+        }
     }
     for (int mw = 0; mw < G * W; ++mw) {
         std::sort(reg_rows[(size_t)mw].begin(), reg_rows[(size_t)mw].end());
@@ -1451,7 +1494,7 @@ extern "C" ldpc_status ldpc_debug_team_rows(int64_t s, int64_t n, const int64_t 
             c2r[(size_t)k] = (int)(dc * i + fill[(size_t)i]++);   // bits ascending inside a check, as ldpc_bp_create lays the rows out
         }
     }
-    const TeamRegPlan rp = team_reg_plan((int)n, (int)s, members, regs_per_wave, static_quarters, dv);
+    const TeamRegPlan rp = team_reg_plan((int)n, (int)s, members, regs_per_wave, static_quarters, dv, dc);
     const TeamRowTables t = team_rows_tables((int)n, (int)s, (int)nnz, dc, dv, c2r, members, rp);
     degrees[0] = dc; degrees[1] = dv;
     shape[0] = t.vt; shape[1] = t.R; shape[2] = rp.static_c; shape[3] = rp.static_v; shape[4] = rp.regs_per_wave;
@@ -1647,8 +1690,9 @@ static ldpc_status team_rows_build(ldpc_bp_decoder *d, int G)
     if (d->rows_G == G) return LDPC_OK;
     // (three quarters of a member's share dealt statically measured 1 % faster than dealing all but the first chunk from
     // the counter -- 873 against 883 ms on the full C3 batch --; rows in registers need it)
-    TeamRegPlan rp = team_reg_plan((int)d->n, (int)d->s, G, d->team_regs, d->team_static_quarters, d->rows_dv);
+    TeamRegPlan rp = team_reg_plan((int)d->n, (int)d->s, G, d->team_regs, d->team_static_quarters, d->rows_dv, d->rows_dc);
     if (const char *e = exp_env("LDPC_TEAM_CONCENTRATE")) { rp.concentrate = std::atoi(e) != 0; rp.whole_checks = std::atoi(e) == 2; }
+    if (const char *e = exp_env("LDPC_TEAM_STRAYS_LAST")) rp.strays_last = std::atoi(e) != 0;
     const TeamRowTables t = team_rows_tables((int)d->n, (int)d->s, (int)d->nnz, d->rows_dc, d->rows_dv, d->h_csc2csr, G, rp);
     auto up = [&](DevBuf &b, const std::vector<int> &v) -> ldpc_status {
         ldpc_status r = b.ensure(std::max<size_t>(v.size() * 4, 4));
