@@ -164,6 +164,26 @@ def test_only_regular_graphs_with_an_instantiation():
     assert status(H.tocsc()) == 5
 
 
+def test_stray_bits_share_position_chunks():
+    """A bit with a LATER edge on chip (the room a member has beyond the whole checks of its block) takes its position
+    chunk off the four-at-once update of the variable sweep (bp_team_kernels.hpp bit_update_multi_first wants every
+    non-first edge in the slot).  team_rows_tables() gives such bits a member's -- and, among the bits with a row in a wave's
+    registers, that wave's -- LAST positions, so they share chunks: at the C3 size 12 ... 18 chunks of a member's 128 (dealt
+    by number they sat in 30 ... 52).  Check degree 10 keeps them dealt by number (measured: team_reg_plan())."""
+    def stray_chunks(n, wr, wc):
+        H, R, vtab, ctab, lds_edge, reg_edge, _ = tables(n, 32, wr, wc, RREGS)
+        stray = (vtab[:, wc + 1:2 * wc] != -1).any(axis=1)
+        per_chunk = stray[: n // 4 * 4].reshape(-1, 4)
+        member = np.arange(n // 4) % 32
+        return int(stray.sum()), [int(per_chunk[member == m].any(axis=1).sum()) for m in range(32)]
+
+    total, chunks = stray_chunks(16384, 8, 4)
+    assert total > 1000 and max(chunks) <= 20 and sum(chunks) <= total / 4 + 32 * (W + 1), (total, chunks)
+    total10, chunks10 = stray_chunks(16380, 10, 4)
+    assert sum(chunks10) > 0.6 * total10, (total10, chunks10)          # dealt by number: nearly one chunk per stray
+    assert stray_chunks(16380, 6, 3)[0] == 0                           # bit degree 3: whole checks only, no strays at all
+
+
 def plan(nnz, batch, cache_mib=240, max_iters=50, regular=1, dv=4):
     out = (ctypes.c_int32 * 6)()
     ldpc._capi.check(ldpc._capi.lib().ldpc_debug_team_plan(nnz, max_iters, batch, cache_mib, dv if regular else 0, ctypes.byref(out)))
