@@ -180,6 +180,8 @@ struct TeamRows {
     int regs;                   // register rows per wave (0 ... kTeamRegRows)
     int static_c, static_v;     // chunks of a member's share of the check / variable sweep that its waves own by right
                                 // (multiples of W, at least W, at most the smallest member's share)
+    int first_c;                // the first first_c chunks of EVERY member's share of the check sweep are two checks with all their rows on
+                                // chip (a multiple of W; the whole checks of a Gallager code's first block) -- see TeamParams::pre
     int flip;                   // bit 0 / 1: the upper half of a member's waves walks its chunks by right of the check /
                                 // variable sweep from the last to the first (the chunks whose rows are all on chip come
                                 // first in the dealt order: so one wave of every SIMD computes while the other one loads)
@@ -191,6 +193,9 @@ struct TeamParams {
     int xcds;                   // XCDs that host teams (8; fewer = the blocks of the others leave at once, and so many fewer
                                 // slots are in flight) -- not in scatter mode
     int nteams;                 // teams launched; team t works in message slot t (fresh tiles) and starts on tile t
+    int pre;                    // chunks of on-chip checks (rows.first_c) that every wave updates BETWEEN telling the team that its variable
+                                // sweep is through and waiting for the others (team_arrive / team_wait), when the next check sweep is
+                                // certain to run: they need nobody else's rows, and the barrier's own round trips are idle time
     int pairs;                  // 1 = two nodes of the full degree are loaded together (twice the bytes in flight per wave)
     int dynamic;                // 1 = the waves of a member take the chunks of its share from a counter in LDS; 0 = every W-th
     // per team one control block of kTeamCtlWords words, zero at launch (see team_barrier); block number nteams
@@ -304,6 +309,52 @@ __device__ __forceinline__ bool team_barrier(unsigned int *ctl, int G, int rank,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // holds the barrier until the invalidate is through
         *sh_ok = ok;
         sh_deal[0] = 0u;   // no wave of this workgroup is inside a sweep here: the dealers start afresh
+        sh_deal[1] = 0u;
+    }
+    __syncthreads();
+    return *sh_ok != 0;
+}
+
+// The two halves of team_barrier for a caller with work of its own between them (TeamParams::pre): what a member does after
+// team_arrive must touch nothing that another member reads or writes.
+__device__ __forceinline__ void team_arrive(unsigned int *ctl, int G, unsigned int k, bool one_xcd)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its own stores
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (!one_xcd) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const unsigned int prev = __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev + 1u == k * (unsigned)G)
+            for (int m = 0; m < G; ++m)
+                __hip_atomic_store(ctl + kTeamCtlMember + 32 * m, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ bool team_wait(unsigned int *ctl, int rank, unsigned int k, unsigned int *fault, unsigned int ticket,
+                                          int *sh_ok, unsigned int *sh_deal)
+{
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        unsigned int *mine = ctl + kTeamCtlMember + 32 * rank;   // (the last arriver finds its own flag set)
+        const u64 t0 = wall_clock64();
+        unsigned int polls = 0;
+        while (__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k) {
+            __builtin_amdgcn_s_sleep(LDPC_TEAM_SLEEP);
+            if ((++polls & 255u) == 0u) {                        // (as in team_barrier)
+                if (__hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) { ok = 0; break; }
+                if (wall_clock64() - t0 > 1000000000ull) {
+                    __hip_atomic_store(fault, ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    ok = 0;
+                    break;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *sh_ok = ok;
+        sh_deal[0] = 0u;
         sh_deal[1] = 0u;
     }
     __syncthreads();
@@ -771,7 +822,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     bool quiet = true;                                         // the last verdict stopped no lane (running ahead: TeamParams)
 
     // ---- check-node sweep  (:135-150) in chunks of kTeamCheckChunk checks
-    auto check_sweep = [&](const bool first) {
+    auto check_sweep = [&](const bool first, const int skip = 0) {   // skip: this wave's first `skip` chunks were updated already (check_pre)
         const int nch = (s + kTeamCheckChunk - 1) / kTeamCheckChunk;
         auto chunk = [&](int c) {
             const int i1 = min(s, (c + 1) * kTeamCheckChunk);
@@ -855,8 +906,25 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
         const int stat = LROWS ? tp.rows.static_c : W;
         const int mirror = (LROWS && (tp.rows.flip & 1) && w >= W / 2) ? 2 * w + stat - W : -1;
         for (int l = w; l < mine;) {
-            chunk(((mirror >= 0 && l < stat) ? mirror - l : l) * G + rank);
+            const int lc = (mirror >= 0 && l < stat) ? mirror - l : l;
+            if (!(LROWS && lc < skip * W)) chunk(lc * G + rank);
             l = !tp.dynamic ? l + W : (l + W < stat ? l + W : stat + team_deal(&sh_deal[0], lane));
+        }
+    };
+    // ... the first `pre` chunks of this wave's share of the NEXT check sweep, all of whose rows are on chip (TeamParams::pre)
+    auto check_pre = [&](const int pre) {
+        if constexpr (LROWS) {
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            constexpr int FULL = (1 << DC) - 1;
+            for (int k = 0; k < pre; ++k) {
+                const int c = (w + k * W) * G + rank;
+                for (int i = c * kTeamCheckChunk; i < (c + 1) * kTeamCheckChunk; ++i) {
+                    const v4i ct = *(const v4i *)(col_ptr + 4 * i);
+                    const double sg = ((syn[i] >> lane) & 1ull) ? -1.0 : 1.0;
+                    if (RR > 0 && ct.z == FULL) check_update_regs<DC, false, TF>(ct.w, sg, r, rget, rput);
+                    else check_update_exact<DC, false, TF>(Lr + (size_t)ct.y * kTile, sg, r);   // (ct.x == FULL: the host's promise, rows.first_c)
+                }
+            }
         }
     };
     // ---- variable-node sweep  (:152-178).  Across XCDs a chunk is 16 consecutive bits, so that a 128-byte line of
@@ -1098,11 +1166,18 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
         const u64 t2 = wall_clock64();
         var_sweep();
         const u64 t3 = wall_clock64();
-        if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd, sh_deal)) return;
+        // (everything the decision to run ahead depends on is known before the barrier: `quiet` is the last verdict's)
+        const bool ahead = can_run_ahead && quiet && it >= tp.ahead_from && it + 2 <= horizon && it < p.max_iters && (int)__popcll(active) >= tp.ahead_min;
+        const int pre = (LROWS && ahead) ? tp.pre : 0;
+        if (pre > 0) {
+            team_arrive(ctr, G, ++epoch, one_xcd);
+            check_pre(pre);                                    // (on-chip checks of iteration it + 1: nobody else's rows)
+            if (!team_wait(ctr, rank, epoch, tp.fault, tp.ticket, &sh_ok, sh_deal)) return;
+        } else if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd, sh_deal)) return;
         run_test(it, em);
-        if (can_run_ahead && quiet && it >= tp.ahead_from && it + 2 <= horizon && it < p.max_iters && (int)__popcll(active) >= tp.ahead_min) {
+        if (ahead) {
             const u64 t3b = wall_clock64();
-            check_sweep(false);                                // iteration it + 1; the barrier at the top of the loop closes both
+            check_sweep(false, pre);                           // iteration it + 1; the barrier at the top of the loop closes both
             have_check = true;
             const u64 t4 = wall_clock64();
             tk_check += (t1 - t0) + (t4 - t3b); tk_var += t3 - t2; tk_rest += (t2 - t1) + (t3b - t3);

@@ -490,9 +490,11 @@ struct ldpc_bp_decoder {
     bool team_rows_on = true;         // LDPC_TEAM_ROWS at create (0 = every row in the slot)
     int rows_dc = 0, rows_dv = 0;     // the graph's (check, bit) degree when it is regular and has a rows-in-LDS instantiation
     int rows_G = 0, rows_R = 0;       // what the tables below were built for: members per team, LDS rows per member
+    int rows_first_c = 0;             // ... leading chunks of every member whose checks are whole on chip (TeamRows::first_c)
     int rows_regs = 0, rows_static_c = 0, rows_static_v = 0;   // ... register rows per wave, chunks per sweep that waves own by right
     DevBuf rows_ctab, rows_vtab, rows_lds_edge, rows_reg_edge, rows_posmap;   // (posmap [n]: position of every bit in the dealt order, for unpack_llr_kernel)
     int team_regs = kTeamRegRows;     // LDPC_TEAM_REGS: rows a wave may keep in its top registers (0 = none)
+    int team_pre = 2;                 // LDPC_TEAM_PRE: chunks of on-chip checks a wave updates between arriving at the barrier after the variable sweep and waiting at it (TeamParams::pre)
     int team_flip = 3;                // LDPC_TEAM_FLIP: bit 0 / 1: upper half of the waves walks its check / position chunks by right backwards (TeamRows::flip)
     int team_static_quarters = 3;     // LDPC_TEAM_STATIC: quarters of a member's chunks per sweep that its waves own by right (0: only each wave's first)
     unsigned int *team_fault = nullptr, *team_fault_dev = nullptr;
@@ -962,6 +964,7 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     if (const char *e = exp_env("LDPC_TEAM_LLR_FOOTPRINT")) d->team_llr_footprint = std::atoi(e) != 0;
     if (const char *e = exp_env("LDPC_TEAM_REGS")) d->team_regs = std::max(0, std::min(kTeamRegRows, std::atoi(e)));
     if (const char *e = exp_env("LDPC_TEAM_FLIP")) d->team_flip = std::atoi(e) & 3;
+    if (const char *e = exp_env("LDPC_TEAM_PRE")) d->team_pre = std::max(0, std::min(8, std::atoi(e)));
     if (const char *e = exp_env("LDPC_TEAM_STATIC")) d->team_static_quarters = std::max(0, std::min(4, std::atoi(e)));
     if (const char *e = exp_env("LDPC_TEAM_PER_CU")) d->team_per_cu_want = std::max(1, std::min(3, std::atoi(e)));
     if (const char *e = exp_env("LDPC_TEAM_MIN_ROWS")) { d->team_min_rows = std::max<int64_t>(1, std::atoll(e)); d->team_min_rows_set = true; }
@@ -1710,6 +1713,22 @@ static ldpc_status team_rows_build(ldpc_bp_decoder *d, int G)
         return st;
     d->rows_G = G; d->rows_R = t.R; d->rows_on_chip = (int)(t.in_lds + t.in_regs);
     d->rows_regs = rp.regs_per_wave; d->rows_static_c = rp.static_c; d->rows_static_v = rp.static_v;
+    {   // the leading chunks of EVERY member's share of the check sweep whose two checks have all their rows on chip (TeamRows::first_c)
+        const int full = (1 << d->rows_dc) - 1, W = LDPC_TEAM_THREADS / 64;
+        int first = rp.static_c;
+        for (int m = 0; m < G; ++m) {
+            int l = 0;
+            for (; l < first; ++l) {
+                const int64_t i = (int64_t)kTeamCheckChunk * ((int64_t)l * G + m);
+                bool whole = i + kTeamCheckChunk <= d->s;
+                for (int q = 0; whole && q < kTeamCheckChunk; ++q)
+                    whole = t.ctab[(size_t)4 * (i + q)] == full || t.ctab[(size_t)4 * (i + q) + 2] == full;
+                if (!whole) break;
+            }
+            first = std::min(first, l);
+        }
+        d->rows_first_c = first / W * W;
+    }
     if (exp_env("LDPC_TEAM_DEBUG"))
         std::fprintf(stderr, "[ldpc] team rows: %d members, %d LDS rows each at most, %zu of %d edges in LDS, %zu in registers (%d per wave at most; static chunks %d / %d)\n",
                      G, t.R, t.in_lds, (int)d->nnz, t.in_regs, rp.regs_per_wave, rp.static_c, rp.static_v);
@@ -2401,6 +2420,8 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
                 tp.rows.reg_edge = (const int *)d->rows_reg_edge.p;
                 tp.rows.regs = d->rows_regs;
                 tp.rows.static_c = d->rows_static_c; tp.rows.static_v = d->rows_static_v; tp.rows.flip = d->team_flip;
+                tp.rows.first_c = d->rows_first_c;
+                tp.pre = std::min(d->team_pre, d->rows_first_c / (LDPC_TEAM_THREADS / 64));
                 t_col = (const int *)d->rows_ctab.p;     // (this instantiation reads its tables through these two arguments)
                 t_c2r = (const int *)d->rows_vtab.p;
                 llr_posmap = (const int *)d->rows_posmap.p;

@@ -131,7 +131,8 @@ while time.time() - t0 < budget and cases < MAXCASES:
         # up and tiles must carry on), how many stragglers the node kernel finishes
         for k in ("LDPC_DEFER_T0", "LDPC_DEFER_T1", "LDPC_DEFER_CAP_TILES", "LDPC_NODE_TAKE_MAX", "LDPC_TEAM_CACHE_KIB",
                   "LDPC_TEAM_DYNAMIC", "LDPC_TEAM_PAIRS", "LDPC_TEAM_ROWS", "LDPC_TEAM_AHEAD", "LDPC_TEAM_REGS", "LDPC_TEAM_STATIC",
-                  "LDPC_TEAM_MAX", "LDPC_TEAM_CONCENTRATE", "LDPC_TEAM_FLIP", "LDPC_TEAM_AHEAD_FROM", "LDPC_TEAM_WIDE"):
+                  "LDPC_TEAM_MAX", "LDPC_TEAM_CONCENTRATE", "LDPC_TEAM_FLIP", "LDPC_TEAM_AHEAD_FROM", "LDPC_TEAM_WIDE", "LDPC_TEAM_PRE",
+                  "LDPC_TEAM_STRAYS_LAST"):
             os.environ.pop(k, None)
         # running ahead (two team barriers an iteration on quiet tiles), rows in the waves' accumulator registers and how
         # much of a member's share its waves own by right; few members on the mid-size graphs so that every wave owns chunks
@@ -166,6 +167,12 @@ while time.time() - t0 < budget and cases < MAXCASES:
             os.environ["LDPC_TEAM_CONCENTRATE"] = str(int(rng.integers(0, 3)))
         if rng.random() < 0.5:
             os.environ["LDPC_TEAM_FLIP"] = str(int(rng.integers(0, 4)))
+        # on-chip checks updated between arriving at the barrier behind the variable sweep and waiting at it (0 = a plain barrier);
+        # stray bits at the end of a member's positions or dealt by number
+        if rng.random() < 0.5:
+            os.environ["LDPC_TEAM_PRE"] = str(int(rng.integers(0, 5)))
+        if rng.random() < 0.3:
+            os.environ["LDPC_TEAM_STRAYS_LAST"] = str(int(rng.integers(0, 2)))
         if rng.random() < 0.3:
             os.environ["LDPC_TEAM_ROWS"] = "0"      # regular graphs: no rows in LDS / registers
         if rng.random() < 0.7:
