@@ -494,6 +494,7 @@ struct ldpc_bp_decoder {
     int rows_regs = 0, rows_static_c = 0, rows_static_v = 0;   // ... register rows per wave, chunks per sweep that waves own by right
     DevBuf rows_ctab, rows_vtab, rows_lds_edge, rows_reg_edge, rows_posmap;   // (posmap [n]: position of every bit in the dealt order, for unpack_llr_kernel)
     int team_regs = kTeamRegRows;     // LDPC_TEAM_REGS: rows a wave may keep in its top registers (0 = none)
+    bool team_pre_set = false;
     int team_pre = 2;                 // LDPC_TEAM_PRE: chunks of on-chip checks a wave updates between arriving at the barrier after the variable sweep and waiting at it (TeamParams::pre)
     int team_flip = 3;                // LDPC_TEAM_FLIP: bit 0 / 1: upper half of the waves walks its check / position chunks by right backwards (TeamRows::flip)
     int team_static_quarters = 3;     // LDPC_TEAM_STATIC: quarters of a member's chunks per sweep that its waves own by right (0: only each wave's first)
@@ -964,7 +965,7 @@ ldpc_status ldpc_bp_create(int64_t s, int64_t n, int64_t nnz, const int64_t *col
     if (const char *e = exp_env("LDPC_TEAM_LLR_FOOTPRINT")) d->team_llr_footprint = std::atoi(e) != 0;
     if (const char *e = exp_env("LDPC_TEAM_REGS")) d->team_regs = std::max(0, std::min(kTeamRegRows, std::atoi(e)));
     if (const char *e = exp_env("LDPC_TEAM_FLIP")) d->team_flip = std::atoi(e) & 3;
-    if (const char *e = exp_env("LDPC_TEAM_PRE")) d->team_pre = std::max(0, std::min(8, std::atoi(e)));
+    if (const char *e = exp_env("LDPC_TEAM_PRE")) { d->team_pre = std::max(0, std::min(8, std::atoi(e))); d->team_pre_set = true; }
     if (const char *e = exp_env("LDPC_TEAM_STATIC")) d->team_static_quarters = std::max(0, std::min(4, std::atoi(e)));
     if (const char *e = exp_env("LDPC_TEAM_PER_CU")) d->team_per_cu_want = std::max(1, std::min(3, std::atoi(e)));
     if (const char *e = exp_env("LDPC_TEAM_MIN_ROWS")) { d->team_min_rows = std::max<int64_t>(1, std::atoll(e)); d->team_min_rows_set = true; }
@@ -2421,7 +2422,9 @@ static ldpc_status decode_device_impl(ldpc_bp_decoder *d, int64_t batch, const u
                 tp.rows.regs = d->rows_regs;
                 tp.rows.static_c = d->rows_static_c; tp.rows.static_v = d->rows_static_v; tp.rows.flip = d->team_flip;
                 tp.rows.first_c = d->rows_first_c;
-                tp.pre = std::min(d->team_pre, d->rows_first_c / (LDPC_TEAM_THREADS / 64));
+                // (wide teams -- members over all XCDs, a barrier of ~20 us: every on-chip chunk fits its shadow.  n = 65536, 16,384
+                //  syndromes x 50 iterations: 905.6 / 892.3 / 880.9 ms with 0 / 2 / 4 chunks a wave; profiles/r04_wide_teams.txt)
+                tp.pre = std::min((plan.wide && !d->team_pre_set) ? 8 : d->team_pre, d->rows_first_c / (LDPC_TEAM_THREADS / 64));
                 t_col = (const int *)d->rows_ctab.p;     // (this instantiation reads its tables through these two arguments)
                 t_c2r = (const int *)d->rows_vtab.p;
                 llr_posmap = (const int *)d->rows_posmap.p;
