@@ -40,6 +40,9 @@ constexpr int kTile = 64;  // syndromes per tile == wavefront width on gfx950
 #ifndef LDPC_MIN_WAVES   // 2nd __launch_bounds__ argument = waves per SIMD the register budget must allow.
 #define LDPC_MIN_WAVES 6 // 6 => <=80 VGPRs => three 512-thread workgroups per CU (measured best: +9.6 % over 4)
 #endif
+#ifndef LDPC_STM_SC1     // 1 = message rows are stored write-through, agent-coherent (the team kernels: pick_team.hip)
+#define LDPC_STM_SC1 0
+#endif
 #ifndef LDPC_NT          // 1 = non-temporal loads/stores for the streamed edge messages
 #define LDPC_NT 0
 #endif
@@ -93,7 +96,9 @@ __device__ __forceinline__ double ldm(const double *p)
 }
 __device__ __forceinline__ void stm(double *p, double v)
 {
-#if LDPC_NT
+#if LDPC_STM_SC1   // (write-through, agent-coherent: the team kernels, pick_team.hip)
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#elif LDPC_NT
     __builtin_nontemporal_store(v, p);
 #else
     *p = v;

@@ -1,4 +1,11 @@
 // pick_team.hip -- instantiations of the team kernel (bp_team_kernels.hpp) (see pickers.hpp).
+// Message rows are stored WRITE-THROUGH and agent-coherent (sc1) in every team kernel: members of a team over several XCDs
+// (wide teams, a single decode!) read each other's rows, and with write-back stores the release side of every team barrier is a
+// write-back of a whole L2 (buffer_wbl2) -- n = 65536, 16,384 syndromes x 50 iterations: 885 -> 840 ms, n = 32768: 429 -> 415 ms;
+// one-XCD teams measure the same either way (C3 full-50 701.5 against 701.2 ms).  profiles/r04_wide_teams.txt.
+#ifndef LDPC_STM_SC1
+#define LDPC_STM_SC1 1
+#endif
 #include "pickers.hpp"
 
 namespace ldpc {
