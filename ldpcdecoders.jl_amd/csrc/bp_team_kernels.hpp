@@ -623,6 +623,31 @@ __device__ __forceinline__ void bit_update_multi_first(double *Mt, double *L, co
     }
 }
 
+// A bit in the first iteration of a fresh tile (LDPC_TEAM_FUSE_FIRST): its D incoming messages are table[sign of the check][place
+// of the edge in its check] (first[0 ... DC-1]: syndrome bit 0, first[DC ... 2 DC-1]: syndrome bit 1), CSR row q = DC * check + place.
+// loc[k] as in bit_update_onchip.  Same arithmetic as a bit whose rows the first check sweep had filled.
+template <int D, int DC, bool TF, class RPut>
+__device__ __forceinline__ double bit_update_first(double *Mt, double *L, const double *first, const u64 *__restrict__ syn, int lane,
+                                                   const int (&pos)[D], const int (&loc)[D], double r, RPut &&rput)
+{
+    double c[D], out[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const int i = pos[k] / DC, place = pos[k] - i * DC;
+        const bool odd = (syn[i] >> lane) & 1ull;
+        c[k] = first[(odd ? DC : 0) + place];
+    }
+    if (TF) check_to_odds<D>(c, c);   // :147
+    const double F = bit_compute_exact<D>(c, r, out);
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) {
+        if (loc[k] == -1) stm(Mt + (size_t)pos[k] * kTile, out[k]);
+        else if (loc[k] >= 0) L[(size_t)loc[k] * kTile] = out[k];
+        else rput(true, -2 - loc[k], out[k]);
+    }
+    return F;
+}
+
 // IRREGULAR graphs with rows in LDS (instantiations with IRR; round 4).  The host packs WHOLE checks into the LDS of their
 // owners (team_irr_tables(): a check qualifies when every one of its bits can be given to the check's owner -- a set
 // packing over the checks -- and the member has LDS rows and positions left) and relabels the bits by position, as the
@@ -652,7 +677,23 @@ __device__ __forceinline__ void bit_update_multi_first(double *Mt, double *L, co
 #ifndef LDPC_TEAM_LIKELY
 #define LDPC_TEAM_LIKELY 1
 #endif
-// (check degree 10 lost by them -- (5,10) n = 16000 491.2 against 487.2 ms, (4,10) 353.9 against 353.1 -- and stays without:
+// The FIRST iteration of a fresh tile without its check sweep (rows-on-chip kernels: regular graphs).  Every bit -> check
+// message is still r (:129), so what the first check sweep would store in row k of a check depends on the check's syndrome bit
+// and on k alone: 2 DC values, made once per workgroup by the same instruction sequence (check_compute_exact).  The first
+// variable sweep takes them from that table in LDS instead of loading rows that a sweep before it would have had to store:
+// one sweep of stores, one of loads and a team barrier less per tile -- a seventh of the traffic of a tile that converges in
+// three to four iterations.
+#ifndef LDPC_TEAM_FUSE_FIRST
+#define LDPC_TEAM_FUSE_FIRST 1
+#endif
+#ifndef LDPC_TEAM_FUSE_DC_MAX
+#define LDPC_TEAM_FUSE_DC_MAX 10
+#endif
+#ifndef LDPC_TEAM_LIKELY_DC_MAX
+#define LDPC_TEAM_LIKELY_DC_MAX 10
+#endif
+// (check degree 10 lost by them at first -- (5,10) n = 16000 491.2 against 487.2 ms, (4,10) 353.9 against 353.1 -- and has them
+//  since the fused first iteration: with it and without them (4,10) ran 357.6 ms, with both 346.6, with neither 348.1;
 //  kTeamHints in the kernel)
 #define LDPC_HOT(x) (kTeamHints ? __builtin_expect(!!(x), 1) : !!(x))
 // The four first edges of a position chunk all in LDS / all in this wave's registers: straight-line code for the chunk
@@ -719,7 +760,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     static_assert(RR == 0 || (LROWS && RR == kTeamRegRows), "rows in registers come on top of the rows in LDS");
     static_assert(!IRR || (!LROWS && !RESUMED && RR == 0), "irregular graphs: whole checks in LDS, fresh tiles");
     constexpr int RS = IRR ? 2 : 1;   // stride of row_ptr / col_ptr entries (IRR: pairs, see above)
-    constexpr bool kTeamHints = (LDPC_TEAM_LIKELY != 0) && DC <= 9;   // (LDPC_HOT, above)
+    constexpr bool kTeamHints = (LDPC_TEAM_LIKELY != 0) && DC <= LDPC_TEAM_LIKELY_DC_MAX;   // (LDPC_HOT, above)
     // Where the division (1 - t) / (1 + t) of :147 is made (check_finish_exact): the rows-on-chip instantiations leave
     // it to the variable sweep.  A check costs 16 fp64 divisions (two per edge) and the check sweep of the persistent
     // teams is bound by them, not by the memory side; the variable sweep has no division at all and waits for its
@@ -752,6 +793,19 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     constexpr int W = THREADS / 64;
     const int s = p.s, n = p.n;
     const double r = p.r;
+    constexpr bool kFuseFirst = LROWS && (LDPC_TEAM_FUSE_FIRST != 0) && DC <= LDPC_TEAM_FUSE_DC_MAX;   // (LROWS: fresh tiles only, every check of degree DC)
+    __shared__ double sh_first[kFuseFirst ? 2 * DC : 1];
+    if constexpr (kFuseFirst) {
+        if (threadIdx.x < 2) {   // what the first check sweep stores in the rows of a check: syndrome bit 0 / 1 (check_update_exact<DC, true, TF>)
+            const double a0 = 2.0 / (1.0 + p.r) - 1.0;
+            double a[DC], out[DC];
+#pragma unroll
+            for (int k = 0; k < DC; ++k) a[k] = a0;
+            check_compute_exact<DC, TF>(a, threadIdx.x ? -1.0 : 1.0, out);
+#pragma unroll
+            for (int k = 0; k < DC; ++k) sh_first[threadIdx.x * DC + k] = out[k];
+        }
+    }
     if (threadIdx.x == 0) { sh_deal[0] = 0u; sh_deal[1] = 0u; }
     __syncthreads();
 #if LDPC_TEAM_FAULT_BLOCKS
@@ -929,7 +983,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
     };
     // ---- variable-node sweep  (:152-178).  Across XCDs a chunk is 16 consecutive bits, so that a 128-byte line of
     //      decision words has one writer; inside one XCD (one L2) 4 bits, for an even finish
-    auto var_sweep = [&]() {
+    auto var_sweep = [&](const bool first = false) {   // first: iteration 1 of a fresh tile without its check sweep (kFuseFirst)
         const int vb = (one_xcd || LROWS || IRR) ? 4 : 16;     // (LROWS / IRR: the host dealt the bits in chunks of 4)
         const int nch = (n + vb - 1) / vb;
         // LLR capture (tp.llr_raw 4 / 5, TeamParams): a store instruction costs the address path the same whatever its
@@ -974,6 +1028,31 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
                 // positions of the dealt bit order; every bit has the full degree; csc2csr is vtab.  Everything the
                 // table says about the four positions of a chunk is asked for at once (one scalar round trip per chunk)
                 constexpr int VT = team_vtab_words(DV);
+                if constexpr (kFuseFirst) {
+                    if (first) {   // no rows to load: the messages of the first check sweep come from the table (bit_update_first)
+                        if (j + 4 == j1) {
+                            const int *const vt = csc2csr + (size_t)j * VT;
+                            const TeamVRec<DV> A = team_vrec_load<DV>(vt), B = team_vrec_load<DV>(vt + VT), C = team_vrec_load<DV>(vt + 2 * VT),
+                                               D = team_vrec_load<DV>(vt + 3 * VT);
+                            double T[4];
+                            T[0] = bit_update_first<DV, DC, TF>(Mt, Lr, sh_first, syn, lane, A.pos, A.lrow, r, rput);
+                            T[1] = bit_update_first<DV, DC, TF>(Mt, Lr, sh_first, syn, lane, B.pos, B.lrow, r, rput);
+                            T[2] = bit_update_first<DV, DC, TF>(Mt, Lr, sh_first, syn, lane, C.pos, C.lrow, r, rput);
+                            T[3] = bit_update_first<DV, DC, TF>(Mt, Lr, sh_first, syn, lane, D.pos, D.lrow, r, rput);
+                            decide(j, A.bit & 0x7fffffff, T[0], false);
+                            decide(j + 1, B.bit & 0x7fffffff, T[1], false);
+                            decide(j + 2, C.bit & 0x7fffffff, T[2], false);
+                            decide(j + 3, D.bit & 0x7fffffff, T[3], false);
+                            capture4(j, T);
+                            return;
+                        }
+                        for (; j < j1; ++j) {
+                            const TeamVRec<DV> A = team_vrec_load<DV>(csc2csr + (size_t)j * VT);
+                            decide(j, A.bit & 0x7fffffff, bit_update_first<DV, DC, TF>(Mt, Lr, sh_first, syn, lane, A.pos, A.lrow, r, rput));
+                        }
+                        return;
+                    }
+                }
                 auto single = [&](const TeamVRec<DV> &a, const int pa) {
                     if (a.bit >= 0) { decide(pa, a.bit, bit_update_exact_v<DV, TF>(Mt, a.pos, r)); return; }
                     if constexpr (RR > 0) {
@@ -1148,9 +1227,12 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
         ++it;
         em = (it & 1) ? em_odd : em_even;
         const u64 t0 = wall_clock64();
-        if (!have_check) check_sweep((it == 1) && !resumed);
+        // (kFuseFirst: a fresh tile's first iteration has no check sweep -- and, once the team knows where it runs, no barrier in
+        //  front of its variable sweep: nothing that sweep reads was written by another member)
+        const bool fused = kFuseFirst && it == 1 && !resumed;
+        if (!have_check && !fused) check_sweep((it == 1) && !resumed);
         const u64 t1 = wall_clock64();
-        if (!team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd, sh_deal)) return;
+        if (!(fused && placed) && !team_barrier(ctr, G, rank, ++epoch, tp.fault, tp.ticket, &sh_ok, one_xcd, sh_deal)) return;
         if (!placed) {
             if (threadIdx.x == 0)
                 sh_one_xcd = __popc(__hip_atomic_load(xccs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 1;
@@ -1164,7 +1246,7 @@ bp_team_kernel(BPParams p, TeamParams tp, const int *__restrict__ row_ptr, const
             if (active == 0) break;                            // (every lane stopped: the sweep ahead was for nothing)
         }
         const u64 t2 = wall_clock64();
-        var_sweep();
+        var_sweep(fused);
         const u64 t3 = wall_clock64();
         // (everything the decision to run ahead depends on is known before the barrier: `quiet` is the last verdict's)
         const bool ahead = can_run_ahead && quiet && it >= tp.ahead_from && it + 2 <= horizon && it < p.max_iters && (int)__popcll(active) >= tp.ahead_min;
